@@ -1,0 +1,132 @@
+/* libvp_hip.so - C ABI of the MI355X-native voicepuppet hot path.
+ *
+ * The reference (taylorlu/voicepuppet) has no FFI boundary for its neural path: it is TF1.x graph
+ * construction behind Python classes.  Its one native precedent is utils/cython/mesh_core.h:53-77
+ * (free functions, raw pointers + explicit int sizes, caller owns every buffer).  This header keeps
+ * that convention for the path BASELINE.json names:
+ *
+ *   vp_pixrefer_*   replaces  voicepuppet/pixrefer/pixrefer.py:59-438   (PixReferNet.build_network,
+ *                             add_cost_function, build_train_op, build_inference_op) and
+ *                             voicepuppet/pixrefer/vgg_simple.py:96-162 (perceptual trunk)
+ *   vp_adam_tf      replaces  tf.train.AdamOptimizer                    (pixrefer.py:398,405)
+ *   vp_conv_* etc.  the single ops behind them (tf.layers.conv2d / conv2d_transpose /
+ *                             batch_normalization: pixrefer.py:61-101), exported for parity tests
+ *   vp_logmel_*     replaces  generator/generator.py:60-80              (DataGenerator.extract_mfcc)
+ *   vp_bfmnet_*     replaces  voicepuppet/bfmnet/bfmnet.py:189-213,325-333 + tinynet.py:159-212
+ *
+ * Conventions: every function returns 0 on success and a negative vp_status otherwise (never throws);
+ * all tensor pointers are DEVICE pointers owned by the caller (NHWC, row-major); nothing is allocated
+ * on the device by the library - workspace sizes are queried and the caller passes the buffer; every
+ * launch goes to the hipStream_t given (passed as void*), no call synchronises.
+ */
+#ifndef VP_HIP_H_
+#define VP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum vp_status { VP_OK = 0, VP_ERR_ARG = -1, VP_ERR_HIP = -2, VP_ERR_WORKSPACE = -3, VP_ERR_STATE = -4 };
+enum vp_dtype { VP_F32 = 0, VP_BF16 = 1 };
+enum vp_act { VP_ACT_NONE = 0, VP_ACT_LRELU = 1, VP_ACT_RELU = 2, VP_ACT_TANH = 3, VP_ACT_SIGMOID = 4 };
+
+int vp_version(void);
+const char* vp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * PixReferNet step (pixrefer.py:356-438)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vp_pixrefer_desc {
+  int batch;        /* per-device batch N */
+  int height;       /* square images, multiple of 256 */
+  int ngf, ndf;     /* pixrefer.py:28-29 (64, 64) */
+  int dtype;        /* vp_dtype of activations / MFMA operands; master weights, statistics, losses are f32 */
+  int training;     /* 1: build_train_op graph (G + 3xD + VGG + losses + grads); 0: build_inference_op */
+  float l1_weight;  /* pixrefer.py:30-31 */
+  float gan_weight;
+} vp_pixrefer_desc;
+
+typedef struct vp_pixrefer vp_pixrefer_t;
+
+/* Parameter manifest: TF variable names -> offset/shape in the flat f32 arenas.
+ * which: 0 = generator*, 1 = discriminator*, 2 = vgg_16 (conv1_1 .. conv3_3).
+ * vp_pixrefer_param_info returns VP_OK and fills the outputs, or VP_ERR_ARG when index is past the end. */
+size_t vp_pixrefer_param_count(const vp_pixrefer_desc* d, int which);
+int vp_pixrefer_param_info(const vp_pixrefer_desc* d, int which, int index, char* name, int name_cap,
+                           size_t* offset, int* ndim, int64_t shape[4]);
+
+size_t vp_pixrefer_workspace_bytes(const vp_pixrefer_desc* d);
+
+/* params_* / grads_*: flat f32 device arenas laid out as the manifest says (grads may be NULL when
+ * training == 0; params_d / params_vgg likewise). */
+int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t workspace_bytes,
+                       float* params_g, float* params_d, const float* params_vgg,
+                       float* grads_g, float* grads_d, void* stream, vp_pixrefer_t** out);
+void vp_pixrefer_destroy(vp_pixrefer_t* h);
+
+/* Call after the f32 master parameters changed (optimizer step, checkpoint load). */
+int vp_pixrefer_params_changed(vp_pixrefer_t* h);
+
+/* inputs [N,H,H,6], fg_inputs [N,H,H,6] (inference: only channels 0:3 are read), targets [N,H,H,3],
+ * masks [N,H,H,3] (training only) - float32 in [0,1] exactly as PixReferDataGenerator yields them
+ * (generator.py:1011-1019).  Runs the generator, the composite, and when training the three
+ * discriminator applications, the VGG trunk and all losses. */
+int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_inputs,
+                        const float* targets, const float* masks, void* stream);
+
+/* Both gradient sets from the forward just run: d(Discrim_loss)/d(discriminator*) -> grads_d,
+ * d(Gen_loss)/d(generator*) -> grads_g (pixrefer.py:396-407; pre-update weights for both). */
+int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream);
+
+/* Named device buffers ("nodes" of pixrefer.py:356-438 and every intermediate):
+ *   "Outputs_raw" [N,H,H,3] f32 in [-1,1], "Outputs_FG" [N,H,H,3] f32, "gen_out4" [N,H,H,4] f32,
+ *   "Predict" [2,N,h,h] f32 (real, fake), "losses" [8] f32 = {Discrim_loss, Gen_loss_GAN, Gen_loss_L1,
+ *   Gen_loss, Perceptual_loss}, "g/<scope>" raw conv outputs, "g/<scope>:dy" their gradients, ...
+ * dtype receives the vp_dtype of the buffer. */
+int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t shape[4], int* dtype);
+
+/* theta -= lr_t * m / (sqrt(v) + eps) with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) (TF formulation) */
+int vp_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, int step_t,
+               float lr, float beta1, float beta2, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single ops (parity tests; same kernels the step uses).  x: NHWC in `dtype`.
+ * in_scale/in_shift: optional per-channel deferred batch-norm affine of the producer, in_act applied
+ * after it (pixrefer.py:182-186: act -> conv -> BN).  workspace: vp_conv_workspace_bytes().
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vp_conv_desc {
+  int kind;          /* 0: conv2d HWIO (pixrefer.py:61-74, vgg_simple.py:138); 1: conv2d_transpose k4 s2 HWOI (pixrefer.py:85) */
+  int n, h, w;       /* input size */
+  int cin, cout;     /* cin % 8 == 0 and a power of two; any cout */
+  int ksize, stride, pad;
+  int dtype;
+  int in_act;
+  int out_act;       /* fwd only */
+} vp_conv_desc;
+
+size_t vp_conv_workspace_bytes(const vp_conv_desc* d);
+/* y = out_act(conv(in_act(in_scale*x+in_shift), w) + bias); y in `dtype`, [n,ho,wo,cout] */
+int vp_conv_fwd(const vp_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                const float* w, const float* bias, void* y, void* workspace, void* stream);
+/* dx = d/d(in_act(...) input)  (i.e. w.r.t. the activated tensor the conv reads), [n,h,w,cin] in `dtype` */
+int vp_conv_bwd_data(const vp_conv_desc* d, const void* dy, const float* w, void* dx, void* workspace, void* stream);
+/* dw in the TF layout of `kind`, f32 */
+int vp_conv_bwd_weight(const vp_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                       const void* dy, float* dw, void* workspace, void* stream);
+
+/* training-mode batch norm statistics (pixrefer.py:99-101): y [pixels, c] -> scale/shift (z = scale*y+shift),
+ * mean, rstd; biased variance, eps inside the sqrt.  workspace: vp_bn_workspace_bytes(). */
+size_t vp_bn_workspace_bytes(int pixels, int c, int dtype);
+int vp_bn_stats(const void* y, int pixels, int c, int dtype, const float* gamma, const float* beta, float eps,
+                float* scale, float* shift, float* mean, float* rstd, void* workspace, void* stream);
+/* dy = BN backward of dz (in place allowed), dgamma, dbeta */
+int vp_bn_bwd(const void* y, const void* dz, void* dy, int pixels, int c, int dtype, const float* gamma,
+              const float* mean, const float* rstd, float* dgamma, float* dbeta, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP_HIP_H_ */

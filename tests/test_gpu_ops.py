@@ -1,0 +1,139 @@
+"""-m gpu: single-op parity of the HIP kernels against the numpy oracle (oracle/nn_ops.py),
+called through the C ABI.  Tolerances: f32 path 1e-5 relative L2 (f32 MFMA == fmaf chain);
+bf16 path 1e-2 on bf16-rounded operands (bf16 storage of the result, f32 accumulate)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_ops as ops
+from voicepuppet_amd import _lib
+
+import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 2e-5, "bf16": 1e-2}
+ACTS = {0: lambda v: v, 1: lambda v: ops.lrelu(v, 0.2), 2: ops.relu, 3: np.tanh, 4: ops.sigmoid}
+
+# (kind, n, h, w, cin, cout, k, s, p, in_act, out_act, affine)
+FWD_CASES = [
+    (0, 2, 16, 16, 8, 64, 4, 2, 1, 0, 0, False),      # encoder_1-like (padded thin input)
+    (0, 2, 16, 16, 64, 128, 4, 2, 1, 1, 0, True),     # encoder_k: lrelu(bn(x)) -> conv
+    (0, 3, 9, 9, 32, 64, 4, 1, 1, 1, 0, True),        # D layer_4-like: stride 1, odd size
+    (0, 3, 9, 9, 64, 1, 4, 1, 1, 1, 0, True),         # D layer_5-like: one output channel
+    (0, 2, 12, 12, 8, 64, 3, 1, 1, 0, 2, False),      # VGG conv1_1-like (K = 72 is padded)
+    (0, 2, 12, 12, 64, 64, 3, 1, 1, 0, 2, False),     # VGG conv + relu
+    (0, 2, 2, 2, 512, 256, 4, 2, 1, 1, 0, True),      # bottleneck: 2 pixels, split-K
+    (0, 5, 4, 4, 256, 128, 4, 2, 1, 1, 0, True),      # 20 pixels: 32-pixel tile
+    (1, 2, 4, 4, 32, 16, 4, 2, 1, 2, 0, True),        # deconv
+    (1, 2, 8, 8, 128, 4, 4, 2, 1, 2, 3, True),        # decoder_1-like: 4 channels + tanh
+    (1, 2, 1, 1, 512, 512, 4, 2, 1, 2, 0, True),      # merged_decoder_5-like: 1x1 -> 2x2, split-K
+    (1, 3, 16, 16, 64, 64, 4, 2, 1, 2, 0, False),
+]
+
+
+def make_case(case, seed=0):
+  kind, n, h, w, cin, cout, k, s, p, in_act, out_act, affine = case
+  rng = np.random.default_rng(seed)
+  x = rng.normal(size=(n, h, w, cin))
+  wt = rng.normal(0, 0.05, (k, k, cin, cout) if kind == 0 else (4, 4, cout, cin))
+  b = rng.normal(0, 0.1, cout)
+  sc = rng.normal(1, 0.2, cin) if affine else None
+  sh = rng.normal(0, 0.2, cin) if affine else None
+  return x, wt, b, sc, sh
+
+
+def ref_input(x, sc, sh, in_act, dtype):
+  xr = gu.rounded(x, dtype)
+  if sc is not None:
+    xr = np.float32(sc) * xr + np.float32(sh)
+  xa = ACTS[in_act](xr)
+  return gu.rounded(xa, dtype) if dtype == "bf16" else xa
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_conv_fwd(case, dtype):
+  kind, n, h, w, cin, cout, k, s, p, in_act, out_act, affine = case
+  x, wt, b, sc, sh = make_case(case)
+  d = gu.conv_desc(kind, n, h, w, cin, cout, k, s, p, dtype, in_act, out_act)
+  y = gu.conv_fwd(d, x, sc, sh, wt, b, dtype)
+  xa = ref_input(x, sc, sh, in_act, dtype)
+  wr = gu.rounded(wt, dtype)
+  yr = ops.conv2d_fwd(xa, wr, np.float32(b).astype(np.float64), s, p) if kind == 0 else ops.deconv4s2_fwd(xa, wr, np.float32(b).astype(np.float64))
+  yr = ACTS[out_act](yr)
+  assert np.isfinite(y).all()
+  assert gu.rel_l2(y, yr) < TOL[dtype], gu.rel_l2(y, yr)
+
+
+BWD_CASES = [c for c in FWD_CASES if c[5] >= 8 and (c[5] & (c[5] - 1)) == 0]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_conv_bwd_data(case, dtype):
+  kind, n, h, w, cin, cout, k, s, p, in_act, out_act, affine = case
+  x, wt, b, sc, sh = make_case(case)
+  d = gu.conv_desc(kind, n, h, w, cin, cout, k, s, p, dtype)
+  ho, wo = gu.out_hw(d)
+  dy = np.random.default_rng(7).normal(size=(n, ho, wo, cout))
+  dx = gu.conv_bwd_data(d, dy, wt, dtype)
+  dyr, wr = gu.rounded(dy, dtype), gu.rounded(wt, dtype)
+  if kind == 0:
+    dxr, _, _ = ops.conv2d_bwd(np.zeros((n, h, w, cin)), wr, dyr, s, p, need_dw=False)
+  else:
+    dxr, _, _ = ops.deconv4s2_bwd(np.zeros((n, h, w, cin)), wr, dyr)
+  assert gu.rel_l2(dx, dxr) < TOL[dtype], gu.rel_l2(dx, dxr)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_conv_bwd_weight(case, dtype):
+  kind, n, h, w, cin, cout, k, s, p, in_act, out_act, affine = case
+  x, wt, b, sc, sh = make_case(case)
+  d = gu.conv_desc(kind, n, h, w, cin, cout, k, s, p, dtype, in_act)
+  ho, wo = gu.out_hw(d)
+  dy = np.random.default_rng(7).normal(size=(n, ho, wo, cout))
+  dw = gu.conv_bwd_weight(d, x, sc, sh, dy, wt.shape, dtype)
+  xa = ref_input(x, sc, sh, in_act, dtype)
+  dyr = gu.rounded(dy, dtype)
+  if kind == 0:
+    _, dwr, _ = ops.conv2d_bwd(xa, np.zeros_like(wt), dyr, s, p, need_dx=False)
+  else:
+    _, dwr, _ = ops.deconv4s2_bwd(xa, np.zeros_like(wt), dyr, need_dx=False)
+  assert gu.rel_l2(dw, dwr) < TOL[dtype], gu.rel_l2(dw, dwr)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("pixels,c", [(1, 64), (37, 8), (4096, 128), (3001, 512)])
+def test_batchnorm_stats_and_backward(pixels, c, dtype):
+  L = _lib.lib()
+  rng = np.random.default_rng(3)
+  y = rng.normal(0.3, 1.5, (pixels, c))
+  dz = rng.normal(size=(pixels, c))
+  gamma, beta = rng.normal(1, 0.1, c), rng.normal(0, 0.1, c)
+  yd, dzd = gu.to_dev(y, dtype), gu.to_dev(dz, dtype)
+  g, b = gu.dev_f32(gamma), gu.dev_f32(beta)
+  outs = [torch.zeros(c, device="cuda") for _ in range(6)]
+  ws = torch.zeros(L.vp_bn_workspace_bytes(pixels, c, gu.VP_BF16 if dtype == "bf16" else gu.VP_F32), dtype=torch.uint8, device="cuda")
+  dt = gu.VP_BF16 if dtype == "bf16" else gu.VP_F32
+  _lib.check(L.vp_bn_stats(gu.ptr(yd), pixels, c, dt, gu.ptr(g), gu.ptr(b), 1e-5, gu.ptr(outs[0]), gu.ptr(outs[1]),
+                           gu.ptr(outs[2]), gu.ptr(outs[3]), gu.ptr(ws), gu.stream()))
+  dyd = torch.empty_like(dzd)
+  _lib.check(L.vp_bn_bwd(gu.ptr(yd), gu.ptr(dzd), gu.ptr(dyd), pixels, c, dt, gu.ptr(g), gu.ptr(outs[2]), gu.ptr(outs[3]),
+                         gu.ptr(outs[4]), gu.ptr(outs[5]), gu.ptr(ws), gu.stream()))
+  torch.cuda.synchronize()
+  yr, dzr = gu.rounded(y, dtype).reshape(1, 1, pixels, c), gu.rounded(dz, dtype).reshape(1, 1, pixels, c)
+  g32, b32 = np.float32(gamma).astype(np.float64), np.float32(beta).astype(np.float64)
+  z, cache = ops.bn_train_fwd(yr, g32, b32)
+  scale, shift = outs[0].cpu().numpy(), outs[1].cpu().numpy()
+  zd = scale * yr + shift
+  if pixels == 1:   # zero variance: z == beta exactly (SURVEY 3.3 edge case)
+    np.testing.assert_array_equal(zd.reshape(-1), np.float32(beta))
+    return
+  assert gu.rel_l2(zd, z) < 1e-5
+  dyr, dgr, dbr = ops.bn_train_bwd(dzr, cache)
+  assert gu.rel_l2(dyd.float().cpu().numpy(), dyr.reshape(pixels, c)) < TOL[dtype]
+  assert gu.rel_l2(outs[4].cpu().numpy(), dgr) < 1e-4
+  assert gu.rel_l2(outs[5].cpu().numpy(), dbr) < 1e-4

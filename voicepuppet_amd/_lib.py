@@ -1,0 +1,77 @@
+"""ctypes binding of libvp_hip.so (include/vp_hip.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvp_hip.so")
+
+VP_F32, VP_BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+
+class PixReferDesc(ctypes.Structure):
+  _fields_ = [("batch", ctypes.c_int), ("height", ctypes.c_int), ("ngf", ctypes.c_int), ("ndf", ctypes.c_int),
+              ("dtype", ctypes.c_int), ("training", ctypes.c_int), ("l1_weight", ctypes.c_float),
+              ("gan_weight", ctypes.c_float)]
+
+
+class ConvDesc(ctypes.Structure):
+  _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int),
+              ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int),
+              ("pad", ctypes.c_int), ("dtype", ctypes.c_int), ("in_act", ctypes.c_int), ("out_act", ctypes.c_int)]
+
+
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    "vp_version": (ctypes.c_int, []),
+    "vp_last_error": (ctypes.c_char_p, []),
+    "vp_pixrefer_param_count": (ctypes.c_size_t, [ctypes.POINTER(PixReferDesc), ctypes.c_int]),
+    "vp_pixrefer_param_info": (ctypes.c_int, [ctypes.POINTER(PixReferDesc), ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                              ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int),
+                                              ctypes.POINTER(ctypes.c_int64)]),
+    "vp_pixrefer_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(PixReferDesc)]),
+    "vp_pixrefer_create": (ctypes.c_int, [ctypes.POINTER(PixReferDesc), _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P,
+                                          ctypes.POINTER(_P)]),
+    "vp_pixrefer_destroy": (None, [_P]),
+    "vp_pixrefer_params_changed": (ctypes.c_int, [_P]),
+    "vp_pixrefer_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
+    "vp_pixrefer_backward": (ctypes.c_int, [_P, _P]),
+    "vp_pixrefer_tensor": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_int)]),
+    "vp_adam_tf": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                  ctypes.c_float, ctypes.c_float, _P]),
+    "vp_conv_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "vp_conv_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vp_conv_bwd_data": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "vp_conv_bwd_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "vp_bn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vp_bn_stats": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P]),
+    "vp_bn_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+  """The loaded library; raises (never falls back) when it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise RuntimeError("libvp_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "or `make -C voicepuppet_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+      fn = getattr(l, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = l
+  return _lib
+
+
+def exported_symbols():
+  return sorted(_SIGNATURES)
+
+
+def check(rc, what=""):
+  if rc != 0:
+    raise RuntimeError("%s failed (%d): %s" % (what or "libvp_hip call", rc, lib().vp_last_error().decode()))

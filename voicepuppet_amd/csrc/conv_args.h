@@ -1,0 +1,73 @@
+// Argument blocks of the implicit-GEMM convolution kernels (host + device).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vp {
+
+struct TapTable {
+  int8_t dh[16];
+  int8_t dw[16];
+};
+
+// A pixel-major (NHWC) tensor, optionally the virtual concat of two tensors along C, read through
+// the deferred batch-norm affine of its producer (z = a*y + b per channel and BN group) followed by
+// the consumer's activation.  This is how "BN -> act -> conv" costs no extra pass over HBM.
+struct PixSrc {
+  const void* ptr[2];
+  int C[2];                 // channels per source (C[1] = 0: single source)
+  const float* aff_a[2];    // [groups][C] or null (identity)
+  const float* aff_b[2];
+  int act;                  // vp::Act applied after the affine
+  int group_n;              // samples per BN group
+};
+
+// Y[pixel, co] = epilogue( sum_{tap, ci} X~[pixel (+) tap, ci] * Wp[co][tap*Cin + ci] )
+// Covers conv fwd, conv bwd-data, transposed-conv fwd (4 output-parity classes) and its bwd-data.
+struct IgemmArgs {
+  PixSrc x;
+  int N, Hin, Win;
+  int Cin, log2Cin;         // total channels of x (power of two)
+  int Hg, Wg;               // GEMM pixel grid per class: pixel = (n, q, r)
+  int sh, sw;               // ih = q*sh + dh[tap], iw = r*sw + dw[tap]
+  int ntaps, nclass;
+  TapTable taps[4];
+  const void* Wp;           // [nclass][CoutPad][Kpad], element type T
+  int Kpad, CoutPad;        // CoutPad: rows rounded up to the channel tile (grid / slab stride)
+  int wp_rows;              // rows per class in Wp (>= CoutPad, zero padded)
+  void* Y;
+  int y_f32;                // store Y as float even when T is bf16
+  int Cout, ldY;            // real output channels (store mask), channel stride of one Y pixel
+  int Hof, Wof, os;         // Y pixel = (n, q*os + o0h[cls], r*os + o0w[cls]) in an Hof x Wof image
+  int o0h[4], o0w[4];
+  const float* bias;        // [Cout] or null
+  int out_act;
+  // backward-data epilogue: Y = [Y +] acc * act'(ref_a*ref + ref_b); ref has Y's geometry
+  const void* ref;
+  const float* ref_a;
+  const float* ref_b;
+  int ref_act, ref_group_n, accumulate;
+  int splitk;
+  float* partial;           // [nclass][splitk][P][CoutPad] when splitk > 1
+};
+
+// dW[tap][g][d] = sum_{pixels} G~[pixel (+) tap, g] * D~[pixel, d]
+//   conv  : G = layer input (ci), D = dY (co)       -> HWIO kernel gradient
+//   deconv: G = dY (co),          D = layer input    -> HWOI kernel gradient
+struct WgradArgs {
+  PixSrc g;
+  int Gc, log2Gc;           // padded channels of the gathered operand (power of two)
+  int Hgin, Wgin;           // spatial size of the gathered tensor
+  PixSrc d;
+  int Dc;                   // channels of the dense operand
+  int N, Hb, Wb;            // base grid: dense pixel (n,q,r); gathered pixel (n, q*s+dh, r*s+dw)
+  int s, ntaps;
+  TapTable taps;
+  int Mpad, Dpad;           // slab dims
+  int splitk;
+  float* partial;           // [splitk][Mpad][Dpad]
+  float* dW;                // [ntaps][Greal][Dreal]
+  int Greal, Dreal, accumulate;
+};
+
+}  // namespace vp

@@ -1,0 +1,516 @@
+// Implicit-GEMM convolution family for gfx950 (MI355X), hand-written MFMA kernels.
+//
+// One MFMA compute core (16x16 tiles, LDS "plane" layout, double-buffered register staging) is fed
+// by two loader kinds:
+//   * igemm_kernel : both operands are K-contiguous in memory (NHWC pixels gathered per tap, packed
+//                    weights [Cout][K]).  conv fwd, conv bwd-data, deconv fwd/bwd-data.
+//   * wgrad_kernel : the reduction runs over pixels, which is the strided dimension of NHWC, so each
+//                    thread transposes an ExE block in registers on the way into LDS.  bwd-weight.
+// LDS plane layout: a tile of ROWS rows x 64 bytes of K is stored as 4 planes (one per 16-byte
+// k-piece g), plane g = ROWS consecutive 16-byte slots.  MFMA lane (i = lane&15, g = lane>>4) reads
+// slot(row0+i) of plane g with one ds_read_b128: the 16 lanes of every b128 service group hit 16
+// distinct 16-byte slots of a 256-byte bank row, i.e. conflict-free reads; writers use 8-lane
+// contiguous (row loader) or XOR-swizzled (transposing loader) slots so writes are conflict-free too.
+#include "conv_args.h"
+#include "vp_common.h"
+
+namespace vp {
+
+// ------------------------------------------------------------------------------------------------
+// slot permutation inside a 16-row block (b = row >> 4)
+//   SWZ 0: identity (row loader)
+//   SWZ 1: transposing loader; a thread owns E consecutive rows and writes them in E instructions,
+//          so lanes of one ds_write_b128 group are E rows apart -> spread them over the 8 slots.
+// ------------------------------------------------------------------------------------------------
+template <int SWZ, int E> __device__ __forceinline__ int lds_slot(int row) {
+  if (SWZ == 0) return row;
+  int r = row & 15, b = row >> 4;
+  int s16;
+  if (E == 4) s16 = (((r & 3) << 2) | (r >> 2)) ^ ((b & 1) << 2);
+  else        s16 = (((r & 7) << 1) | (r >> 3)) ^ ((b & 3) << 1);
+  return (row & ~15) | s16;
+}
+
+// acc[tc][tp] += A(tile tc) x B(tile tp) for one 64-byte K chunk
+template <typename T, int TC, int TP, int BC, int BP, int SWZ>
+__device__ __forceinline__ void mma_chunk(const uint4* __restrict__ ldsA, const uint4* __restrict__ ldsB,
+                                          int rowA0, int rowB0, int lane, f32x4 (&acc)[TC][TP]) {
+  constexpr int E = Elem<T>::E;
+  const int i = lane & 15, g = lane >> 4;
+  uint4 fa[TC], fb[TP];
+#pragma unroll
+  for (int t = 0; t < TC; ++t) fa[t] = ldsA[g * BC + lds_slot<SWZ, E>(rowA0 + t * 16 + i)];
+#pragma unroll
+  for (int t = 0; t < TP; ++t) fb[t] = ldsB[g * BP + lds_slot<SWZ, E>(rowB0 + t * 16 + i)];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], fb[tp], acc[tc][tp]);
+}
+
+// deferred-BN affine + activation on one 16-byte piece (channels c .. c+E-1 of BN group grp)
+template <typename T>
+__device__ __forceinline__ uint4 prologue_piece(uint4 v, const float* __restrict__ pa, const float* __restrict__ pb, int act) {
+  constexpr int E = Elem<T>::E;
+  if (pa == nullptr && act == ACT_NONE) return v;
+  float f[E];
+  Elem<T>::unpack(v, f);
+  if (pa != nullptr) {
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(pa + e);
+      const float4 b4 = *reinterpret_cast<const float4*>(pb + e);
+      f[e + 0] = fmaf(a4.x, f[e + 0], b4.x); f[e + 1] = fmaf(a4.y, f[e + 1], b4.y);
+      f[e + 2] = fmaf(a4.z, f[e + 2], b4.z); f[e + 3] = fmaf(a4.w, f[e + 3], b4.w);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) f[e] = act_apply(act, f[e]);
+  return Elem<T>::pack(f);
+}
+
+// Load channels [c, c+E) of pixel (n, ih, iw) of a PixSrc (after affine + act); zeros outside.
+template <typename T>
+__device__ __forceinline__ uint4 load_pix_piece(const PixSrc& x, int n, int ih, int iw, int H, int W, int c, bool ok) {
+  if (!ok || (unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) return make_uint4(0, 0, 0, 0);
+  // explicit selects (no dynamic indexing of the by-value argument block: that would go to scratch)
+  const bool s = c >= x.C[0];
+  const int cl = s ? c - x.C[0] : c;
+  const int C = s ? x.C[1] : x.C[0];
+  const T* p = reinterpret_cast<const T*>(s ? x.ptr[1] : x.ptr[0]) + ((size_t)(n * H + ih) * W + iw) * C + cl;
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  const float* pa = s ? x.aff_a[1] : x.aff_a[0];
+  const float* pb = s ? x.aff_b[1] : x.aff_b[0];
+  if (pa != nullptr) {
+    const int off = (n / x.group_n) * C + cl;
+    pa += off; pb += off;
+  }
+  return prologue_piece<T>(v, pa, pb, x.act);
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogue shared by igemm_kernel and splitk_reduce_kernel: 4 consecutive output channels of one pixel
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int pidx, int c0, float v[4]) {
+  if (c0 >= a.Cout) return;
+  const int hw = a.Hg * a.Wg;
+  const int n = pidx / hw;
+  const int rem = pidx - n * hw;
+  const int q = rem / a.Wg;
+  const int r = rem - q * a.Wg;
+  const size_t pix = ((size_t)n * a.Hof + (q * a.os + a.o0h[cls])) * a.Wof + (r * a.os + a.o0w[cls]);
+  const size_t off = pix * a.ldY + c0;
+  const int nv = min(4, a.Cout - c0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < nv) {
+      if (a.bias) v[e] += a.bias[c0 + e];
+      v[e] = act_apply(a.out_act, v[e]);
+    }
+  }
+  if (a.ref) {
+    const T* rp = reinterpret_cast<const T*>(a.ref) + off;
+    const int goff = (n / a.ref_group_n) * a.Cout + c0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < nv) {
+        float z = Elem<T>::ld(rp + e);
+        if (a.ref_a) z = fmaf(a.ref_a[goff + e], z, a.ref_b[goff + e]);
+        v[e] *= act_grad(a.ref_act, z);
+      }
+    }
+  }
+  if (a.y_f32) {
+    float* yp = reinterpret_cast<float*>(a.Y) + off;
+    if (a.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) v[e] += yp[e];
+    }
+    if (nv == 4 && (a.ldY & 3) == 0) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) yp[e] = v[e];
+    }
+  } else {
+    T* yp = reinterpret_cast<T*>(a.Y) + off;
+    if (a.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) v[e] += Elem<T>::ld(yp + e);
+    }
+    if (nv == 4 && (a.ldY & 3) == 0) {
+      if (sizeof(T) == 4) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+      else *reinterpret_cast<uint2*>(yp) = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
+                                                     f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) Elem<T>::st(yp + e, v[e]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// igemm_kernel: grid = (pixel tiles, channel tiles, nclass * splitk), 256 threads = 4 waves (WC x WP)
+//   MFMA A operand = weights (rows -> output channels), B operand = pixels (cols), so one lane ends
+//   up with 4 consecutive channels of one pixel: a single 16-byte (f32) / 8-byte (bf16) NHWC store.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WC, int WP, int TC, int TP>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  constexpr int PA = (BC + 63) / 64, PB = (BP + 63) / 64;   // staging passes (64 rows per pass)
+  constexpr int BUF = 4 * (BC + BP);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  int* ltap = reinterpret_cast<int*>(lds + 2 * BUF);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cls = blockIdx.z / a.splitk, split = blockIdx.z - cls * a.splitk;
+  const int P = a.N * a.Hg * a.Wg;
+  const int p_base = blockIdx.x * BP, c_base = blockIdx.y * BC;
+
+  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
+
+  // staging thread -> (row within 16, k-piece g): 8 consecutive lanes = 8 consecutive rows of one plane
+  const int r16 = (lane & 7) + 8 * (lane >> 5);
+  const int g = (lane >> 3) & 3;
+
+  // per-thread pixel rows (fixed over the K loop)
+  int pn[PB], pbh[PB], pbw[PB];
+  bool pok[PB];
+#pragma unroll
+  for (int ps = 0; ps < PB; ++ps) {
+    const int row = ps * 64 + wave * 16 + r16;
+    const int pidx = p_base + row;
+    pok[ps] = (row < BP) && (pidx < P);
+    const int hw = a.Hg * a.Wg;
+    const int pc = pok[ps] ? pidx : 0;
+    const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
+    pn[ps] = n; pbh[ps] = q * a.sh; pbw[ps] = (rem - q * a.Wg) * a.sw;
+  }
+  const T* wp = reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad;
+
+  const int nchunk = a.Kpad / KC;
+  const int per = (nchunk + a.splitk - 1) / a.splitk;
+  const int kc0 = split * per, kc1 = min(nchunk, kc0 + per);
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging registers as named scalars (arrays captured by the lambdas below end up in scratch)
+  uint4 ra0, ra1, rb0, rb1;
+  ra0 = ra1 = rb0 = rb1 = make_uint4(0, 0, 0, 0);
+  __syncthreads();   // tap table visible
+
+  auto load_a = [&](int kc, int ps) -> uint4 {
+    const int row = ps * 64 + wave * 16 + r16;
+    if (BC % 64 == 0 || row < BC) return *reinterpret_cast<const uint4*>(wp + (size_t)(c_base + row) * a.Kpad + (kc * KC + g * E));
+    return make_uint4(0, 0, 0, 0);
+  };
+  auto load_b = [&](int kc, int ps, int n, int bh, int bw, bool ok) -> uint4 {
+    const int k0 = kc * KC + g * E;
+    const int tap = k0 >> a.log2Cin;
+    const int ci = k0 & (a.Cin - 1);
+    const bool tok = tap < a.ntaps;
+    const int tv = ltap[tok ? tap : 0];
+    const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
+    const int row = ps * 64 + wave * 16 + r16;
+    if (BP % 64 == 0 || row < BP) return load_pix_piece<T>(a.x, n, bh + dh, bw + dw, a.Hin, a.Win, ci, ok && tok);
+    return make_uint4(0, 0, 0, 0);
+  };
+  auto stage_load = [&](int kc) {
+    ra0 = load_a(kc, 0);
+    if (PA > 1) ra1 = load_a(kc, 1);
+    rb0 = load_b(kc, 0, pn[0], pbh[0], pbw[0], pok[0]);
+    if (PB > 1) rb1 = load_b(kc, 1, pn[PB - 1], pbh[PB - 1], pbw[PB - 1], pok[PB - 1]);
+  };
+  auto stage_store = [&](int buf) {
+    uint4* la = lds + buf * BUF;
+    uint4* lb = la + 4 * BC;
+    const int row = wave * 16 + r16;
+    if (BC % 64 == 0 || row < BC) la[g * BC + row] = ra0;
+    if (PA > 1) la[g * BC + 64 + row] = ra1;
+    if (BP % 64 == 0 || row < BP) lb[g * BP + row] = rb0;
+    if (PB > 1) lb[g * BP + 64 + row] = rb1;
+  };
+
+  const int wc = wave / WP, wpi = wave - wc * WP;
+  const int rowA0 = wc * TC * 16, rowB0 = wpi * TP * 16;
+
+  if (kc0 < kc1) {
+    stage_load(kc0);
+    stage_store(0);
+    __syncthreads();
+    for (int kc = kc0; kc < kc1; ++kc) {
+      const int buf = (kc - kc0) & 1;
+      const bool more = kc + 1 < kc1;
+      if (more) stage_load(kc + 1);
+      const uint4* la = lds + buf * BUF;
+      mma_chunk<T, TC, TP, BC, BP, 0>(la, la + 4 * BC, rowA0, rowB0, lane, acc);
+      if (more) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: lane holds pixel (lane&15), channels 4*(lane>>4) .. +3 of each 16x16 tile
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    const int pidx = p_base + rowB0 + tp * 16 + (lane & 15);
+    if (pidx >= P) continue;
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc) {
+      const int c0 = c_base + rowA0 + tc * 16 + 4 * (lane >> 4);
+      float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
+      if (a.splitk > 1) {
+        float* pp = a.partial + (((size_t)(cls * a.splitk + split) * P + pidx) * a.CoutPad + c0);
+        *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        igemm_epilogue<T>(a, cls, pidx, c0, v);
+      }
+    }
+  }
+}
+
+// sums the split-K slabs in a fixed order (deterministic) and applies the igemm epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArgs a) {
+  const int P = a.N * a.Hg * a.Wg;
+  const int cq = a.CoutPad >> 2;
+  const size_t total = (size_t)a.nclass * P * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c0 = (int)(i % cq) * 4;
+    const size_t t = i / cq;
+    const int pidx = (int)(t % P);
+    const int cls = (int)(t / P);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < a.splitk; ++s) {
+      const float4 x = *reinterpret_cast<const float4*>(a.partial + (((size_t)(cls * a.splitk + s) * P + pidx) * a.CoutPad + c0));
+      v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+    }
+    igemm_epilogue<T>(a, cls, pidx, c0, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad_kernel: grid = (M tiles over (tap, g), N tiles over d, splitk over pixels)
+//   A operand rows = (tap, g channel) of the gathered tensor, B operand cols = d channel of the
+//   dense tensor, K = pixels.  A loader task = E consecutive pixels x E consecutive channels,
+//   transposed in registers into E 16-byte pieces "one channel, E consecutive pixels".
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Transposer;
+template <> struct Transposer<float> {
+  __device__ static __forceinline__ void run(const uint4 (&in)[4], uint4 (&out)[4]) {
+    out[0] = make_uint4(in[0].x, in[1].x, in[2].x, in[3].x);
+    out[1] = make_uint4(in[0].y, in[1].y, in[2].y, in[3].y);
+    out[2] = make_uint4(in[0].z, in[1].z, in[2].z, in[3].z);
+    out[3] = make_uint4(in[0].w, in[1].w, in[2].w, in[3].w);
+  }
+};
+template <> struct Transposer<bf16> {
+  // in[p] = 8 channels of pixel p (dword d = channels 2d, 2d+1); out[c] = 8 pixels of channel c
+  __device__ static __forceinline__ uint32_t lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+  __device__ static __forceinline__ uint32_t hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+  __device__ static __forceinline__ void run(const uint4 (&in)[8], uint4 (&out)[8]) {
+#define VP_TR(dw, c0)                                                                                 \
+    out[c0]     = make_uint4(lo(in[0].dw, in[1].dw), lo(in[2].dw, in[3].dw), lo(in[4].dw, in[5].dw), lo(in[6].dw, in[7].dw)); \
+    out[c0 + 1] = make_uint4(hi(in[0].dw, in[1].dw), hi(in[2].dw, in[3].dw), hi(in[4].dw, in[5].dw), hi(in[6].dw, in[7].dw));
+    VP_TR(x, 0) VP_TR(y, 2) VP_TR(z, 4) VP_TR(w, 6)
+#undef VP_TR
+  }
+};
+
+template <typename T, int WC, int WP, int TC, int TP>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  constexpr int BUF = 4 * (BC + BP);
+  constexpr int TA = 4 * BC / E, TB = 4 * BP / E;     // loader tasks per chunk
+  static_assert(TA + TB <= 256, "one task per thread");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m_base = blockIdx.x * BC, d_base = blockIdx.y * BP, split = blockIdx.z;
+  const int P = a.N * a.Hb * a.Wb;
+  const int nchunk = (P + KC - 1) / KC;
+  const int per = (nchunk + a.splitk - 1) / a.splitk;
+  const int kc0 = split * per, kc1 = min(nchunk, kc0 + per);
+
+  // loader task of this thread
+  const bool isA = tid < TA;
+  const bool isB = !isA && tid < TA + TB;
+  const int tt = isA ? tid : tid - TA;
+  const int ncg = (isA ? BC : BP) / E;       // channel groups
+  const int cg = tt % ncg, kq = tt / ncg;    // channel group, k-quarter (plane)
+  int tdh = 0, tdw = 0, gch = 0;
+  bool rowok = false;
+  if (isA) {
+    const int m = m_base + cg * E;
+    const int tap = m >> a.log2Gc;
+    gch = m & (a.Gc - 1);
+    rowok = tap < a.ntaps;
+    if (rowok) { tdh = a.taps.dh[tap]; tdw = a.taps.dw[tap]; }
+  } else if (isB) {
+    gch = d_base + cg * E;
+    rowok = gch < a.Dc;
+  }
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 rin[E], rout[E];
+  auto stage_load = [&](int kc) {
+    if (!(isA || isB)) return;
+    int pidx = kc * KC + kq * E;
+    const int hw = a.Hb * a.Wb;
+    int n = pidx / hw;
+    int rem = pidx - n * hw;
+    int q = rem / a.Wb;
+    int r = rem - q * a.Wb;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const bool ok = rowok && (pidx + e < P);
+      if (isA) rin[e] = load_pix_piece<T>(a.g, n, q * a.s + tdh, r * a.s + tdw, a.Hgin, a.Wgin, gch, ok);
+      else     rin[e] = load_pix_piece<T>(a.d, n, q, r, a.Hb, a.Wb, gch, ok);
+      if (++r == a.Wb) { r = 0; if (++q == a.Hb) { q = 0; ++n; } }
+    }
+  };
+  auto stage_store = [&](int buf) {
+    if (!(isA || isB)) return;
+    Transposer<T>::run(rin, rout);
+    uint4* base = lds + buf * BUF + (isA ? 0 : 4 * BC) + kq * (isA ? BC : BP);
+#pragma unroll
+    for (int e = 0; e < E; ++e) base[lds_slot<1, E>(cg * E + e)] = rout[e];
+  };
+
+  const int wc = wave / WP, wpi = wave - wc * WP;
+  const int rowA0 = wc * TC * 16, rowB0 = wpi * TP * 16;
+
+  if (kc0 < kc1) {
+    stage_load(kc0);
+    stage_store(0);
+    __syncthreads();
+    for (int kc = kc0; kc < kc1; ++kc) {
+      const int buf = (kc - kc0) & 1;
+      const bool more = kc + 1 < kc1;
+      if (more) stage_load(kc + 1);
+      const uint4* la = lds + buf * BUF;
+      mma_chunk<T, TC, TP, BC, BP, 1>(la, la + 4 * BC, rowA0, rowB0, lane, acc);
+      if (more) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // slab store: lane holds d column (lane&15), rows 4*(lane>>4) .. +3
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {
+      const int m0 = m_base + rowA0 + tc * 16 + 4 * (lane >> 4);
+      const int d = d_base + rowB0 + tp * 16 + (lane & 15);
+      float* pp = a.partial + ((size_t)split * a.Mpad + m0) * a.Dpad + d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pp[(size_t)e * a.Dpad] = acc[tc][tp][e];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
+  const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int d = (int)(i % a.Dreal);
+    const size_t t = i / a.Dreal;
+    const int gc = (int)(t % a.Greal);
+    const int tap = (int)(t / a.Greal);
+    const size_t m = (size_t)tap * a.Gc + gc;
+    float s = 0.f;
+    for (int k = 0; k < a.splitk; ++k) s += a.partial[((size_t)k * a.Mpad + m) * a.Dpad + d];
+    if (a.accumulate) s += a.dW[i];
+    a.dW[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WC, int WP, int TC, int TP>
+static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  const int P = a.N * a.Hg * a.Wg;
+  dim3 grid((P + BP - 1) / BP, a.CoutPad / BC, a.nclass * a.splitk);
+  const size_t smem = 2 * 4 * (BC + BP) * 16 + 64;
+  hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
+  return hipGetLastError();
+}
+
+template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int cfg, hipStream_t st) {
+  hipError_t e;
+  switch (cfg) {
+    case 0: e = launch_igemm_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 ch x 128 px
+    case 1: e = launch_igemm_cfg<T, 1, 4, 4, 2>(a, st); break;   //  64 ch x 128 px
+    case 2: e = launch_igemm_cfg<T, 1, 4, 1, 2>(a, st); break;   //  16 ch x 128 px
+    case 3: e = launch_igemm_cfg<T, 4, 1, 2, 2>(a, st); break;   // 128 ch x  32 px
+    case 4: e = launch_igemm_cfg<T, 4, 1, 2, 1>(a, st); break;   // 128 ch x  16 px
+    case 5: e = launch_igemm_cfg<T, 2, 2, 2, 1>(a, st); break;   //  64 ch x  32 px
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  if (a.splitk > 1) {
+    const size_t total = (size_t)a.nclass * a.N * a.Hg * a.Wg * (a.CoutPad / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((igemm_splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, a);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st) {
+  return is_bf16 ? launch_igemm_t<bf16>(a, cfg, st) : launch_igemm_t<float>(a, cfg, st);
+}
+
+void igemm_tile(int cfg, int* bc, int* bp) {
+  static const int t[6][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}};
+  *bc = t[cfg][0]; *bp = t[cfg][1];
+}
+
+template <typename T, int WC, int WP, int TC, int TP>
+static hipError_t launch_wgrad_cfg(const WgradArgs& a, hipStream_t st) {
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  dim3 grid(a.Mpad / BC, a.Dpad / BP, a.splitk);
+  const size_t smem = 2 * 4 * (BC + BP) * 16;
+  hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
+  return hipGetLastError();
+}
+
+template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int cfg, hipStream_t st) {
+  hipError_t e;
+  switch (cfg) {
+    case 0: e = launch_wgrad_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 rows x 128 cols
+    case 1: e = launch_wgrad_cfg<T, 2, 2, 4, 2>(a, st); break;   // 128 rows x  64 cols
+    case 2: e = launch_wgrad_cfg<T, 4, 1, 2, 1>(a, st); break;   // 128 rows x  16 cols
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st) {
+  return is_bf16 ? launch_wgrad_t<bf16>(a, cfg, st) : launch_wgrad_t<float>(a, cfg, st);
+}
+
+void wgrad_tile(int cfg, int* bm, int* bn) {
+  static const int t[3][2] = {{128, 128}, {128, 64}, {128, 16}};
+  *bm = t[cfg][0]; *bn = t[cfg][1];
+}
+
+}  // namespace vp

@@ -1,0 +1,217 @@
+// Host-side construction of the implicit-GEMM argument blocks for one convolution layer:
+// forward, backward-data, backward-weight, and the weight-packing descriptors that go with them.
+// Geometry follows the TF ops the reference calls:
+//   conv   : tf.layers.conv2d, kernel HWIO [k,k,Cin,Cout], symmetric pad      (pixrefer.py:61-74)
+//   deconv : tf.layers.conv2d_transpose k4 s2 "same", kernel HWOI [4,4,Cout,Cin] (pixrefer.py:85)
+//            out[n,2i+kh-1,2j+kw-1,co] += in[n,i,j,ci] * W[kh,kw,co,ci]
+#pragma once
+#include <string.h>
+
+#include "launch.h"
+
+namespace vp {
+
+struct ConvGeomX : ConvGeom {
+  int CoutT;          // channel count of the output-side tensors (Cout, or 8 when Cout < 8)
+};
+
+inline ConvGeomX make_geom(int kind, int ks, int stride, int pad, int N, int Hin, int Win, int Cin, int Cin_real, int Cout) {
+  ConvGeomX g;
+  g.kind = kind; g.ks = ks; g.stride = stride; g.pad = pad;
+  g.N = N; g.Hin = Hin; g.Win = Win;
+  if (kind == 0) { g.Hout = (Hin + 2 * pad - ks) / stride + 1; g.Wout = (Win + 2 * pad - ks) / stride + 1; }
+  else { g.Hout = 2 * Hin; g.Wout = 2 * Win; }
+  g.Cin = Cin; g.Cin_real = Cin_real; g.Cout = Cout;
+  g.CoutT = Cout < 8 ? 8 : Cout;
+  return g;
+}
+
+inline int kc_elems(int is_bf16) { return is_bf16 ? 32 : 16; }
+
+// tile choice for an igemm producing `rows` channels over P pixels
+inline int pick_igemm_cfg(int rows, int P) {
+  if (P >= 96) {
+    if (rows % 128 == 0) return 0;
+    if (rows % 64 == 0) return 1;
+    if (rows <= 16) return 2;
+    return rows > 64 ? 0 : 1;
+  }
+  if (rows <= 64) return 5;
+  return P > 16 ? 3 : 4;
+}
+
+inline int pick_igemm_splitk(int blocks, int nchunk) {
+  if (blocks >= 256) return 1;
+  int s = (512 + blocks - 1) / blocks;
+  if (s > nchunk / 2) s = nchunk / 2;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+inline void set_single_src(PixSrc& x, const void* p, int C, const float* a, const float* b, int act, int group_n) {
+  x.ptr[0] = p; x.ptr[1] = nullptr; x.C[0] = C; x.C[1] = 0;
+  x.aff_a[0] = a; x.aff_b[0] = b; x.aff_a[1] = nullptr; x.aff_b[1] = nullptr;
+  x.act = act; x.group_n = group_n > 0 ? group_n : (1 << 30);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+struct IgemmPlan {
+  IgemmArgs a;
+  int cfg;
+  PackDesc pack;
+  size_t pack_elems;      // elements of the packed weight block
+  size_t partial_bytes;
+};
+
+inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
+  IgemmArgs& a = p.a;
+  const int P = a.N * a.Hg * a.Wg;
+  p.cfg = pick_igemm_cfg(rows, P);
+  int bc, bp;
+  igemm_tile(p.cfg, &bc, &bp);
+  a.CoutPad = round_up(rows, bc);
+  a.Kpad = round_up(a.ntaps * a.Cin, kc_elems(is_bf16));
+  a.log2Cin = ilog2(a.Cin);
+  const int blocks = ((P + bp - 1) / bp) * (a.CoutPad / bc) * a.nclass;
+  a.splitk = pick_igemm_splitk(blocks, a.Kpad / kc_elems(is_bf16));
+  p.partial_bytes = a.splitk > 1 ? (size_t)a.nclass * a.splitk * P * a.CoutPad * sizeof(float) : 0;
+  // packed rows are padded to the largest channel tile so the tile choice may vary with the batch
+  a.wp_rows = round_up(rows, 128);
+  p.pack.rows_pad = a.wp_rows;
+  p.pack.Kpad = a.Kpad;
+  p.pack_elems = (size_t)a.nclass * a.wp_rows * a.Kpad;
+}
+
+// x (PixSrc, total channels g.Cin) -> y [N,Hout,Wout,ldY]
+inline IgemmPlan plan_fwd(const ConvGeomX& g, size_t w_off, int is_bf16) {
+  IgemmPlan p;
+  memset(&p, 0, sizeof(p));
+  IgemmArgs& a = p.a;
+  a.N = g.N; a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin;
+  a.Cout = g.Cout; a.ldY = g.Cout; a.Hof = g.Hout; a.Wof = g.Wout;
+  a.ref_group_n = 1 << 30;
+  PackDesc& d = p.pack;
+  d.src_off = w_off; d.rows_real = g.Cout; d.C = g.Cin; d.C_real = g.Cin_real;
+  if (g.kind == 0) {
+    a.Hg = g.Hout; a.Wg = g.Wout; a.sh = a.sw = g.stride; a.os = 1;
+    a.ntaps = g.ks * g.ks; a.nclass = 1;
+    for (int t = 0; t < a.ntaps; ++t) {
+      a.taps[0].dh[t] = (int8_t)(t / g.ks - g.pad); a.taps[0].dw[t] = (int8_t)(t % g.ks - g.pad);
+      d.kh[0][t] = (int8_t)(t / g.ks); d.kw[0][t] = (int8_t)(t % g.ks);
+    }
+    d.s_kh = g.ks * g.Cin_real * g.Cout; d.s_kw = g.Cin_real * g.Cout; d.s_ch = g.Cout; d.s_row = 1;
+  } else {
+    a.Hg = g.Hin; a.Wg = g.Win; a.sh = a.sw = 1; a.os = 2;
+    a.ntaps = 4; a.nclass = 4;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int ph = cls >> 1, pw = cls & 1;
+      a.o0h[cls] = ph; a.o0w[cls] = pw;
+      for (int t = 0; t < 4; ++t) {
+        const int ta = t >> 1, tb = t & 1;
+        a.taps[cls].dh[t] = (int8_t)(ph - ta); a.taps[cls].dw[t] = (int8_t)(pw - tb);
+        d.kh[cls][t] = (int8_t)((1 - ph) + 2 * ta); d.kw[cls][t] = (int8_t)((1 - pw) + 2 * tb);
+      }
+    }
+    d.s_kh = 4 * g.Cout * g.Cin_real; d.s_kw = g.Cout * g.Cin_real; d.s_row = g.Cin_real; d.s_ch = 1;
+  }
+  d.nclass = a.nclass; d.ntaps = a.ntaps;
+  finish_igemm(p, g.Cout, is_bf16);
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward-data for input channels [row0, row0+rows): dY [N,Hout,Wout,CoutT] -> dX [N,Hin,Win,ldX]
+// ---------------------------------------------------------------------------------------------
+inline IgemmPlan plan_bwd_data(const ConvGeomX& g, size_t w_off, int row0, int rows, int rows_real, int ldX, int is_bf16) {
+  IgemmPlan p;
+  memset(&p, 0, sizeof(p));
+  IgemmArgs& a = p.a;
+  a.N = g.N; a.Hin = g.Hout; a.Win = g.Wout; a.Cin = g.CoutT;
+  a.Cout = rows; a.ldY = ldX; a.Hof = g.Hin; a.Wof = g.Win;
+  a.ref_group_n = 1 << 30;
+  PackDesc& d = p.pack;
+  d.rows_real = rows_real; d.C = g.CoutT; d.C_real = g.Cout;
+  if (g.kind == 0) {
+    d.s_kh = g.ks * g.Cin_real * g.Cout; d.s_kw = g.Cin_real * g.Cout; d.s_row = g.Cout; d.s_ch = 1;
+    if (g.stride == 1) {
+      a.Hg = g.Hin; a.Wg = g.Win; a.sh = a.sw = 1; a.os = 1;
+      a.ntaps = g.ks * g.ks; a.nclass = 1;
+      for (int t = 0; t < a.ntaps; ++t) {
+        const int kh = t / g.ks, kw = t % g.ks;
+        a.taps[0].dh[t] = (int8_t)(g.pad - kh); a.taps[0].dw[t] = (int8_t)(g.pad - kw);
+        d.kh[0][t] = (int8_t)kh; d.kw[0][t] = (int8_t)kw;
+      }
+    } else {   // k4 s2 p1: four input-parity classes with 2x2 taps each
+      a.Hg = g.Hout; a.Wg = g.Wout; a.sh = a.sw = 1; a.os = 2;
+      a.ntaps = 4; a.nclass = 4;
+      for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        a.o0h[cls] = ph; a.o0w[cls] = pw;
+        for (int t = 0; t < 4; ++t) {
+          const int ta = t >> 1, tb = t & 1;
+          a.taps[cls].dh[t] = (int8_t)(ph - ta); a.taps[cls].dw[t] = (int8_t)(pw - tb);
+          d.kh[cls][t] = (int8_t)((1 - ph) + 2 * ta); d.kw[cls][t] = (int8_t)((1 - pw) + 2 * tb);
+        }
+      }
+    }
+  } else {     // deconv: dX = conv k4 s2 p1 over dY with W[kh,kw,co,ci] read as [co -> K, ci -> rows]
+    d.s_kh = 4 * g.Cout * g.Cin_real; d.s_kw = g.Cout * g.Cin_real; d.s_row = 1; d.s_ch = g.Cin_real;
+    a.Hg = g.Hin; a.Wg = g.Win; a.sh = a.sw = 2; a.os = 1;
+    a.ntaps = 16; a.nclass = 1;
+    for (int t = 0; t < 16; ++t) {
+      a.taps[0].dh[t] = (int8_t)(t / 4 - 1); a.taps[0].dw[t] = (int8_t)(t % 4 - 1);
+      d.kh[0][t] = (int8_t)(t / 4); d.kw[0][t] = (int8_t)(t % 4);
+    }
+  }
+  d.src_off = w_off + (size_t)row0 * d.s_row;
+  d.nclass = a.nclass; d.ntaps = a.ntaps;
+  finish_igemm(p, rows, is_bf16);
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward-weight
+// ---------------------------------------------------------------------------------------------
+struct WgradPlan {
+  WgradArgs a;
+  int cfg;
+  size_t partial_bytes;
+};
+
+inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16) {
+  WgradPlan p;
+  memset(&p, 0, sizeof(p));
+  WgradArgs& a = p.a;
+  a.N = g.N;
+  a.ntaps = g.ks * g.ks;
+  for (int t = 0; t < a.ntaps; ++t) { a.taps.dh[t] = (int8_t)(t / g.ks - g.pad); a.taps.dw[t] = (int8_t)(t % g.ks - g.pad); }
+  if (g.kind == 0) {   // G = layer input, D = dY
+    a.Gc = g.Cin; a.Greal = g.Cin_real; a.Hgin = g.Hin; a.Wgin = g.Win;
+    a.Dc = g.CoutT; a.Dreal = g.Cout;
+    a.Hb = g.Hout; a.Wb = g.Wout; a.s = g.stride;
+  } else {             // G = dY, D = layer input
+    a.Gc = g.CoutT; a.Greal = g.Cout; a.Hgin = g.Hout; a.Wgin = g.Wout;
+    a.Dc = g.Cin; a.Dreal = g.Cin_real;
+    a.Hb = g.Hin; a.Wb = g.Win; a.s = 2;
+  }
+  a.log2Gc = ilog2(a.Gc);
+  p.cfg = (a.Dc % 128 == 0) ? 0 : (a.Dc % 64 == 0 ? 1 : 2);
+  int bm, bn;
+  wgrad_tile(p.cfg, &bm, &bn);
+  a.Mpad = round_up(a.ntaps * a.Gc, bm);
+  a.Dpad = round_up(a.Dc, bn);
+  const int P = a.N * a.Hb * a.Wb;
+  const int nchunk = (P + kc_elems(is_bf16) - 1) / kc_elems(is_bf16);
+  const int tiles = (a.Mpad / bm) * (a.Dpad / bn);
+  int s = (1024 + tiles - 1) / tiles;
+  if (s > nchunk / 4) s = nchunk / 4;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  a.splitk = s;
+  p.partial_bytes = (size_t)s * a.Mpad * a.Dpad * sizeof(float);
+  return p;
+}
+
+}  // namespace vp

@@ -1,0 +1,46 @@
+// Host-side launchers implemented in conv_kernels.hip / pointwise.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_args.h"
+#include "pointwise_args.h"
+
+namespace vp {
+
+hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st);
+void igemm_tile(int cfg, int* bc, int* bp);
+hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
+void wgrad_tile(int cfg, int* bm, int* bn);
+
+hipError_t launch_pack_weights(const PackDesc* d_descs, int ndesc, const float* master, void* packed, int is_bf16, hipStream_t st);
+hipError_t launch_pack_weights_one(const PackDesc& d, const float* master, void* packed, int is_bf16, hipStream_t st);
+int bn_nchunk(int Pg, int C, int G, int is_bf16);
+hipError_t launch_bn_stats(const BnArgs& a, int is_bf16, hipStream_t st);
+hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
+hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate, int is_bf16, hipStream_t st);
+hipError_t launch_pack_inputs(const PackInputsArgs& a, int is_bf16, hipStream_t st);
+int composite_nblocks(int N, int HW);
+hipError_t launch_composite_fwd(const CompositeArgs& a, int is_bf16, hipStream_t st);
+hipError_t launch_composite_bwd(const CompositeArgs& a, int is_bf16, hipStream_t st);
+hipError_t launch_gan_loss(const GanLossArgs& a, int is_bf16, hipStream_t st);
+int perceptual_nblocks(size_t half, int is_bf16);
+hipError_t launch_perceptual(const PerceptualArgs& a, int is_bf16, hipStream_t st);
+hipError_t launch_loss_final(const LossFinalArgs& a, hipStream_t st);
+hipError_t launch_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int is_bf16, hipStream_t st);
+hipError_t launch_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int is_bf16, hipStream_t st);
+hipError_t launch_relu_bwd(const void* y, void* d, size_t n, int is_bf16, hipStream_t st);
+hipError_t launch_adam(const AdamArgs& a, hipStream_t st);
+
+// ---- shape / tiling helpers shared by the plan and the single-op entry points ----
+struct ConvGeom {
+  int kind;           // 0 conv (HWIO), 1 deconv k4 s2 (HWOI)
+  int ks, stride, pad;
+  int N, Hin, Win, Hout, Wout;
+  int Cin, Cin_real;  // Cin: padded (multiple of 8, power of two); Cin_real: channels in the TF kernel
+  int Cout;           // real
+};
+
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace vp

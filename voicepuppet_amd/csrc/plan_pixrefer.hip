@@ -1,0 +1,764 @@
+// PixReferNet step executor: the whole G + 3xD + VGG + losses forward, and both backward passes, as a
+// fixed sequence of kernel launches on one HIP stream (no host sync, no allocation: hipGraph-capturable).
+//
+// Follows voicepuppet/pixrefer/pixrefer.py:59-438 and vgg_simple.py:96-162.
+// Design (MI355X-first, not the TF graph):
+//   * every conv output is stored ONCE, raw (pre-BN); its consumers apply the producer's batch-norm
+//     affine and their own activation while loading (deferred normalisation), so "BN -> act" never
+//     costs a pass over HBM and the skip concats are virtual (two source pointers);
+//   * the three discriminator applications run as ONE batch of 3N with three batch-norm groups;
+//   * the VGG trunk runs on the 2N batch [real | fake]; its backward only on the fake half;
+//   * weights live as f32 masters in flat arenas (also the all-reduce buffers) and are re-packed
+//     into MFMA-friendly [Cout][K] blocks of the compute dtype once per parameter update.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "conv_ops.h"
+#include "errors.h"
+#include "launch.h"
+#include "vp_common.h"
+
+namespace vp {
+
+thread_local char g_err[512] = "";
+void set_err(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct Arena {
+  char* base;
+  size_t off, cap;
+  void* alloc(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+struct BnBuf { float *a, *b, *mu, *rstd, *c1, *c2; };
+
+struct Tens {
+  std::string name;
+  void* y = nullptr;      // raw conv output (or packed network input)
+  void* dz = nullptr;     // gradient buffer (w.r.t. the normalised tensor, then in place w.r.t. y)
+  int N = 0, H = 0, W = 0, C = 0;
+  bool is_f32 = false;
+  bool has_bn = false;
+  bool is_input = false;
+  bool dz_written = false;
+  BnBuf bn{};
+  size_t elems() const { return (size_t)N * H * W * C; }
+};
+
+struct Layer {
+  std::string scope;       // TF variable scope
+  ConvGeomX g;
+  int src[2] = {-1, -1};
+  int nsrc = 1;
+  int in_act = ACT_NONE;
+  int out_act = ACT_NONE;  // VGG: relu in the epilogue
+  int out = -1;
+  bool has_bn = false;
+  size_t w_off = 0, b_off = 0, gamma_off = 0, beta_off = 0;
+  size_t pk_fwd = 0, pk_bwd[2] = {0, 0};
+  bool need_bwd[2] = {false, false};
+  IgemmPlan fwd, bwd[2], bwd_alt[2];   // bwd_alt: discriminator G-loss pass (batch N)
+  WgradPlan wg;
+};
+
+struct ParamInfo { std::string name; size_t off; int ndim; int64_t shape[4]; };
+
+struct Net {
+  std::vector<Tens> t;
+  std::vector<Layer> l;
+  std::vector<ParamInfo> manifest;
+  size_t nparams = 0;
+  int batch = 0, groups = 1;
+  float* params = nullptr;
+  float* grads = nullptr;
+  char* packed = nullptr;       // packed weights of this net (compute dtype)
+  size_t packed_elems = 0;
+  std::vector<PackDesc> descs;
+  PackDesc* d_descs = nullptr;
+};
+
+}  // namespace vp
+
+using namespace vp;
+
+struct vp_pixrefer {
+  vp_pixrefer_desc d;
+  int bf16, es;
+  Net G, D, V;
+  // shared device buffers
+  void *gin, *gfg, *din, *vin;
+  float *y4, *o4, *outputs, *outputs_fg, *logits, *predict, *losses;
+  void *dl_d, *dl_g, *d_din, *d_vin, *dy4, *df3;
+  void *vpool1, *vpool2, *d_vpool1, *d_vpool2;
+  double *comp_partial, *perc_partial, *bn_partial;
+  char* scratch;
+  size_t scratch_bytes;
+  int n_comp, n_perc;
+  bool params_dirty;
+  const float *in_targets, *in_masks;
+};
+
+namespace vp {
+
+// ------------------------------------------------------------------------------------------------
+// network construction
+// ------------------------------------------------------------------------------------------------
+static int add_tensor(Net& n, const std::string& name, int N, int H, int W, int C, bool has_bn, bool is_input) {
+  Tens t;
+  t.name = name; t.N = N; t.H = H; t.W = W; t.C = C; t.has_bn = has_bn; t.is_input = is_input;
+  n.t.push_back(t);
+  return (int)n.t.size() - 1;
+}
+
+static void add_param(Net& n, const std::string& name, std::initializer_list<int64_t> shape, size_t* off_out) {
+  ParamInfo p;
+  p.name = name; p.off = n.nparams; p.ndim = (int)shape.size();
+  size_t cnt = 1;
+  int i = 0;
+  for (auto s : shape) { p.shape[i++] = s; cnt *= (size_t)s; }
+  for (; i < 4; ++i) p.shape[i] = 1;
+  *off_out = n.nparams;
+  n.nparams += cnt;
+  n.manifest.push_back(p);
+}
+
+// conv/deconv layer reading tensors src[] and producing a new tensor
+static int add_layer(Net& n, const std::string& prefix, const std::string& scope, int kind, int ks, int stride, int pad,
+                     std::initializer_list<int> srcs, int cin_real, int cout, bool has_bn, int in_act, int out_act,
+                     const char* wname, const char* bname) {
+  Layer L;
+  L.scope = scope;
+  L.nsrc = 0;
+  int cin = 0;
+  for (int s : srcs) { L.src[L.nsrc++] = s; cin += n.t[s].C; }
+  const Tens& t0 = n.t[L.src[0]];
+  L.g = make_geom(kind, ks, stride, pad, n.batch, t0.H, t0.W, cin, cin_real, cout);
+  L.in_act = in_act; L.out_act = out_act; L.has_bn = has_bn;
+  const std::string base = prefix + scope + "/";
+  if (kind == 0) add_param(n, base + wname, {ks, ks, cin_real, cout}, &L.w_off);
+  else add_param(n, base + wname, {4, 4, cout, cin_real}, &L.w_off);
+  add_param(n, base + bname, {cout}, &L.b_off);
+  if (has_bn) {
+    add_param(n, base + "batch_normalization/gamma", {cout}, &L.gamma_off);
+    add_param(n, base + "batch_normalization/beta", {cout}, &L.beta_off);
+  }
+  L.out = add_tensor(n, scope, n.batch, L.g.Hout, L.g.Wout, L.g.CoutT, has_bn, false);
+  n.l.push_back(L);
+  return L.out;
+}
+
+static void build_generator(Net& n, int N, int H, int ngf) {
+  n.batch = N; n.groups = 1;
+  const int tin = add_tensor(n, "inputs", N, H, H, 8, false, true);
+  const int tfg = add_tensor(n, "fg_inputs", N, H, H, 8, false, true);
+  const char* CK = "conv2d/kernel"; const char* CB = "conv2d/bias";
+  const char* DK = "conv2d_transpose/kernel"; const char* DB = "conv2d_transpose/bias";
+  const std::string P = "generator/";
+  // encoders (pixrefer.py:169-213): act -> conv -> BN
+  int e1 = add_layer(n, P, "encoder_1", 0, 4, 2, 1, {tin}, 6, ngf, false, ACT_NONE, ACT_NONE, CK, CB);
+  int e2 = add_layer(n, P, "encoder_2", 0, 4, 2, 1, {e1}, ngf, ngf * 2, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int e3 = add_layer(n, P, "encoder_3", 0, 4, 2, 1, {e2}, ngf * 2, ngf * 2, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int e4 = add_layer(n, P, "encoder_4", 0, 4, 2, 1, {e3}, ngf * 2, ngf * 4, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int f1 = add_layer(n, P, "encoder_fg_1", 0, 4, 2, 1, {tfg}, 3, ngf, false, ACT_NONE, ACT_NONE, CK, CB);
+  int f2 = add_layer(n, P, "encoder_fg_2", 0, 4, 2, 1, {f1}, ngf, ngf * 2, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int f3 = add_layer(n, P, "encoder_fg_3", 0, 4, 2, 1, {f2}, ngf * 2, ngf * 2, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int f4 = add_layer(n, P, "encoder_fg_4", 0, 4, 2, 1, {f3}, ngf * 2, ngf * 4, true, ACT_LRELU, ACT_NONE, CK, CB);
+  // merged encoder on concat(e4, f4) (pixrefer.py:215-232)
+  int m2 = add_layer(n, P, "merged_encoder_2", 0, 4, 2, 1, {e4, f4}, ngf * 8, ngf * 4, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int m3 = add_layer(n, P, "merged_encoder_3", 0, 4, 2, 1, {m2}, ngf * 4, ngf * 8, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int m4 = add_layer(n, P, "merged_encoder_4", 0, 4, 2, 1, {m3}, ngf * 8, ngf * 8, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int m5 = add_layer(n, P, "merged_encoder_5", 0, 4, 2, 1, {m4}, ngf * 8, ngf * 8, true, ACT_LRELU, ACT_NONE, CK, CB);
+  // decoders (pixrefer.py:234-276): relu -> deconv -> BN, skip = virtual concat
+  int d5 = add_layer(n, P, "merged_decoder_5", 1, 4, 2, 1, {m5}, ngf * 8, ngf * 8, true, ACT_RELU, ACT_NONE, DK, DB);
+  int d4 = add_layer(n, P, "merged_decoder_4", 1, 4, 2, 1, {d5, m4}, ngf * 16, ngf * 8, true, ACT_RELU, ACT_NONE, DK, DB);
+  int d3 = add_layer(n, P, "merged_decoder_3", 1, 4, 2, 1, {d4, m3}, ngf * 16, ngf * 4, true, ACT_RELU, ACT_NONE, DK, DB);
+  int d2 = add_layer(n, P, "merged_decoder_2", 1, 4, 2, 1, {d3, m2}, ngf * 8, ngf * 4, true, ACT_RELU, ACT_NONE, DK, DB);
+  int c4 = add_layer(n, P, "merged2_decoder_4", 1, 4, 2, 1, {d2, e4}, ngf * 8, ngf * 2, true, ACT_RELU, ACT_NONE, DK, DB);
+  int c3 = add_layer(n, P, "merged2_decoder_3", 1, 4, 2, 1, {c4, e3}, ngf * 4, ngf * 2, true, ACT_RELU, ACT_NONE, DK, DB);
+  int c2 = add_layer(n, P, "merged2_decoder_2", 1, 4, 2, 1, {c3, e2}, ngf * 4, ngf, true, ACT_RELU, ACT_NONE, DK, DB);
+  add_layer(n, P, "decoder_1", 1, 4, 2, 1, {c2, e1}, ngf * 2, 4, false, ACT_RELU, ACT_NONE, DK, DB);
+}
+
+static void build_discriminator(Net& n, int N, int H, int ndf) {
+  n.batch = 3 * N; n.groups = 3;
+  const int tin = add_tensor(n, "d_inputs", 3 * N, H, H, 8, false, true);
+  const char* CK = "conv2d/kernel"; const char* CB = "conv2d/bias";
+  const std::string P = "discriminator/";
+  // pixrefer.py:103-134: conv -> BN -> lrelu; the lrelu is applied by the next layer's loader
+  int l1 = add_layer(n, P, "layer_1", 0, 4, 2, 1, {tin}, 6, ndf, false, ACT_NONE, ACT_NONE, CK, CB);
+  int l2 = add_layer(n, P, "layer_2", 0, 4, 2, 1, {l1}, ndf, ndf * 2, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int l3 = add_layer(n, P, "layer_3", 0, 4, 2, 1, {l2}, ndf * 2, ndf * 4, true, ACT_LRELU, ACT_NONE, CK, CB);
+  int l4 = add_layer(n, P, "layer_4", 0, 4, 1, 1, {l3}, ndf * 4, ndf * 8, true, ACT_LRELU, ACT_NONE, CK, CB);
+  add_layer(n, P, "layer_5", 0, 4, 1, 1, {l4}, ndf * 8, 1, false, ACT_LRELU, ACT_NONE, CK, CB);
+}
+
+static void build_vgg(Net& n, int N, int H) {
+  n.batch = 2 * N; n.groups = 1;
+  const int tin = add_tensor(n, "v_inputs", 2 * N, H, H, 8, false, true);
+  const std::string P = "vgg_16/";
+  // vgg_simple.py:138-151: conv3x3 s1 SAME + bias + relu; pools are separate ops between the blocks
+  int c11 = add_layer(n, P, "conv1/conv1_1", 0, 3, 1, 1, {tin}, 3, 64, false, ACT_NONE, ACT_RELU, "weights", "biases");
+  add_layer(n, P, "conv1/conv1_2", 0, 3, 1, 1, {c11}, 64, 64, false, ACT_NONE, ACT_RELU, "weights", "biases");
+  const int p1 = add_tensor(n, "pool1", 2 * N, H / 2, H / 2, 64, false, false);
+  int c21 = add_layer(n, P, "conv2/conv2_1", 0, 3, 1, 1, {p1}, 64, 128, false, ACT_NONE, ACT_RELU, "weights", "biases");
+  add_layer(n, P, "conv2/conv2_2", 0, 3, 1, 1, {c21}, 128, 128, false, ACT_NONE, ACT_RELU, "weights", "biases");
+  const int p2 = add_tensor(n, "pool2", 2 * N, H / 4, H / 4, 128, false, false);
+  int c31 = add_layer(n, P, "conv3/conv3_1", 0, 3, 1, 1, {p2}, 128, 256, false, ACT_NONE, ACT_RELU, "weights", "biases");
+  int c32 = add_layer(n, P, "conv3/conv3_2", 0, 3, 1, 1, {c31}, 256, 256, false, ACT_NONE, ACT_RELU, "weights", "biases");
+  add_layer(n, P, "conv3/conv3_3", 0, 3, 1, 1, {c32}, 256, 256, false, ACT_NONE, ACT_RELU, "weights", "biases");
+}
+
+// plans + packed-weight layout for one net.  alt_batch > 0: also plan bwd-data for that batch (D, G-loss pass)
+static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_batch, size_t* scratch_max) {
+  size_t pk = 0;
+  auto take = [&](IgemmPlan& p) {
+    p.pack.dst_off = pk;
+    pk += (p.pack_elems + 63) & ~(size_t)63;
+    n.descs.push_back(p.pack);
+    if (p.partial_bytes > *scratch_max) *scratch_max = p.partial_bytes;
+  };
+  for (Layer& L : n.l) {
+    L.fwd = plan_fwd(L.g, L.w_off, bf16);
+    take(L.fwd);
+    L.pk_fwd = L.fwd.pack.dst_off;
+    if (!training) continue;
+    int row0 = 0;
+    for (int s = 0; s < L.nsrc; ++s) {
+      const Tens& ts = n.t[L.src[s]];
+      const int rows = ts.C;
+      int rows_real = rows;
+      if (ts.is_input) rows_real = L.g.Cin_real;
+      // gradient w.r.t. network inputs is only needed for the discriminator (G loss) and VGG inputs
+      L.need_bwd[s] = !ts.is_input || (n.groups == 3) || (n.l[0].g.ks == 3);
+      if (L.need_bwd[s]) {
+        L.bwd[s] = plan_bwd_data(L.g, L.w_off, row0, rows, rows_real, ts.C, bf16);
+        take(L.bwd[s]);
+        L.pk_bwd[s] = L.bwd[s].pack.dst_off;
+        if (alt_batch > 0) {
+          ConvGeomX g2 = L.g;
+          g2.N = alt_batch;
+          L.bwd_alt[s] = plan_bwd_data(g2, L.w_off, row0, rows, rows_real, ts.C, bf16);
+          L.bwd_alt[s].pack.dst_off = L.pk_bwd[s];
+          if (L.bwd_alt[s].partial_bytes > *scratch_max) *scratch_max = L.bwd_alt[s].partial_bytes;
+        }
+      }
+      row0 += rows;
+    }
+    if (want_wgrad) {
+      L.wg = plan_wgrad(L.g, bf16);
+      if (L.wg.partial_bytes > *scratch_max) *scratch_max = L.wg.partial_bytes;
+    }
+  }
+  n.packed_elems = pk;
+}
+
+// carve device buffers of a net out of the workspace
+static void carve_net(Net& n, Arena& ar, int es, bool training) {
+  for (Tens& t : n.t) {
+    if (t.name == "decoder_1" || t.name == "layer_5") {   // thin f32 outputs live in the plan-level buffers
+      continue;
+    }
+    if (!t.is_input) t.y = ar.alloc(t.elems() * es);
+    if (t.has_bn) {
+      const size_t gc = (size_t)n.groups * t.C * sizeof(float);
+      t.bn.a = (float*)ar.alloc(gc); t.bn.b = (float*)ar.alloc(gc);
+      t.bn.mu = (float*)ar.alloc(gc); t.bn.rstd = (float*)ar.alloc(gc);
+      t.bn.c1 = (float*)ar.alloc(gc); t.bn.c2 = (float*)ar.alloc(gc);
+    }
+  }
+  n.packed = (char*)ar.alloc(n.packed_elems * es);
+  n.d_descs = (PackDesc*)ar.alloc(n.descs.size() * sizeof(PackDesc));
+  (void)training;
+}
+
+static size_t carve_all(vp_pixrefer* h, char* base, size_t cap) {
+  Arena ar{base, 0, cap};
+  const vp_pixrefer_desc& d = h->d;
+  const int N = d.batch, H = d.height, es = h->es;
+  const size_t px = (size_t)N * H * H;
+  h->gin = ar.alloc(px * 8 * es);
+  h->gfg = ar.alloc(px * 8 * es);
+  h->y4 = (float*)ar.alloc(px * 4 * sizeof(float));
+  h->o4 = (float*)ar.alloc(px * 4 * sizeof(float));
+  h->outputs = (float*)ar.alloc(px * 3 * sizeof(float));
+  h->outputs_fg = (float*)ar.alloc(px * 3 * sizeof(float));
+  h->losses = (float*)ar.alloc(8 * sizeof(float));
+  h->G.t[0].y = h->gin; h->G.t[1].y = h->gfg;
+  carve_net(h->G, ar, es, d.training);
+  if (d.training) {
+    const int hd = H / 8 - 2;
+    const size_t M = (size_t)N * hd * hd;
+    h->din = ar.alloc(3 * px * 8 * es);
+    h->vin = ar.alloc(2 * px * 8 * es);
+    h->logits = (float*)ar.alloc(3 * M * sizeof(float));
+    h->predict = (float*)ar.alloc(2 * M * sizeof(float));
+    h->dl_d = ar.alloc(3 * M * 8 * es);
+    h->dl_g = ar.alloc(M * 8 * es);
+    h->d_din = ar.alloc(px * 8 * es);
+    h->d_vin = ar.alloc(px * 8 * es);
+    h->dy4 = ar.alloc(px * 8 * es);
+    h->D.t[0].y = h->din; h->V.t[0].y = h->vin;
+    carve_net(h->D, ar, es, true);
+    carve_net(h->V, ar, es, true);
+    // gradient buffers.  generator + discriminator: one per non-input tensor.
+    for (Tens& t : h->G.t) if (!t.is_input && t.name != "decoder_1") t.dz = ar.alloc(t.elems() * es);
+    for (Tens& t : h->D.t) if (!t.is_input && t.name != "layer_5") t.dz = ar.alloc(t.elems() * es);
+    // VGG backward runs on the fake half only
+    for (Tens& t : h->V.t) if (!t.is_input) t.dz = ar.alloc(t.elems() / 2 * es);
+    h->n_comp = composite_nblocks(N, H * H);
+    h->n_perc = perceptual_nblocks((size_t)N * (H / 4) * (H / 4) * 256, h->bf16);
+    h->comp_partial = (double*)ar.alloc((size_t)h->n_comp * 2 * sizeof(double));
+    h->perc_partial = (double*)ar.alloc((size_t)h->n_perc * sizeof(double));
+  }
+  h->bn_partial = (double*)ar.alloc((size_t)1024 * 2 * 512 * sizeof(double));
+  h->scratch = (char*)ar.alloc(h->scratch_bytes);
+  return ar.off + 256;
+}
+
+static void init_handle(vp_pixrefer* h, const vp_pixrefer_desc* d) {
+  h->d = *d;
+  h->bf16 = d->dtype == VP_BF16;
+  h->es = h->bf16 ? 2 : 4;
+  build_generator(h->G, d->batch, d->height, d->ngf);
+  size_t smax = 0;
+  plan_net(h->G, h->bf16, d->training, d->training, 0, &smax);
+  if (d->training) {
+    build_discriminator(h->D, d->batch, d->height, d->ndf);
+    plan_net(h->D, h->bf16, true, true, d->batch, &smax);
+    build_vgg(h->V, d->batch, d->height);
+    // VGG backward (dX only) is planned for the fake half: batch N
+    for (Layer& L : h->V.l) L.g.N = 2 * d->batch;
+    plan_net(h->V, h->bf16, true, false, d->batch, &smax);
+  }
+  h->scratch_bytes = smax + 256;
+  h->params_dirty = true;
+}
+
+static bool valid_desc(const vp_pixrefer_desc* d) {
+  if (!d || d->batch < 1 || d->height < 256 || d->height % 256 != 0) return false;
+  if (d->ngf < 8 || (d->ngf & (d->ngf - 1)) || d->ndf < 8 || (d->ndf & (d->ndf - 1))) return false;
+  if (d->dtype != VP_F32 && d->dtype != VP_BF16) return false;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// execution helpers
+// ------------------------------------------------------------------------------------------------
+static void fill_src(const Net& n, const Layer& L, PixSrc& x, int group_n, int sample0, int group0, int es) {
+  for (int s = 0; s < 2; ++s) {
+    x.ptr[s] = nullptr; x.C[s] = 0; x.aff_a[s] = nullptr; x.aff_b[s] = nullptr;
+  }
+  for (int s = 0; s < L.nsrc; ++s) {
+    const Tens& t = n.t[L.src[s]];
+    x.ptr[s] = (const char*)t.y + (size_t)sample0 * t.H * t.W * t.C * es;
+    x.C[s] = t.C;
+    if (t.has_bn) { x.aff_a[s] = t.bn.a + (size_t)group0 * t.C; x.aff_b[s] = t.bn.b + (size_t)group0 * t.C; }
+  }
+  x.act = L.in_act;
+  x.group_n = group_n;
+}
+
+static int run_pack(vp_pixrefer* h, Net& n, hipStream_t st) {
+  if (n.descs.empty()) return VP_OK;
+  VP_HIP_CHECK(launch_pack_weights(n.d_descs, (int)n.descs.size(), n.params, n.packed, h->bf16, st));
+  return VP_OK;
+}
+
+static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
+  Tens& t = n.t[L.out];
+  BnArgs b;
+  memset(&b, 0, sizeof(b));
+  b.y = t.y; b.C = t.C; b.G = n.groups; b.Pg = (n.batch / n.groups) * t.H * t.W;
+  b.nchunk = bn_nchunk(b.Pg, b.C, b.G, h->bf16);
+  b.partial = h->bn_partial;
+  b.gamma = n.params + L.gamma_off; b.beta = n.params + L.beta_off;
+  b.aff_a = t.bn.a; b.aff_b = t.bn.b; b.mu = t.bn.mu; b.rstd = t.bn.rstd;
+  b.eps = 1e-5f;   // pixrefer.py:100
+  VP_HIP_CHECK(launch_bn_stats(b, h->bf16, st));
+  return VP_OK;
+}
+
+// forward of one conv layer (+ its batch statistics)
+static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
+  IgemmArgs a = L.fwd.a;
+  fill_src(n, L, a.x, n.batch / n.groups, 0, 0, h->es);
+  a.Wp = n.packed + L.pk_fwd * h->es;
+  Tens& to = n.t[L.out];
+  a.Y = to.y; a.ldY = to.C; a.y_f32 = 0;
+  if (to.is_f32) { a.y_f32 = 1; a.ldY = L.g.Cout; }
+  a.bias = L.has_bn ? nullptr : n.params + L.b_off;   // a bias in front of batch-norm cancels exactly
+  a.out_act = L.out_act;
+  a.partial = (float*)h->scratch;
+  VP_HIP_CHECK(launch_igemm(a, h->bf16, L.fwd.cfg, st));
+  if (L.has_bn) return run_bn_stats(h, n, L, st);
+  return VP_OK;
+}
+
+// backward of one layer given dL/dy in `dy` (dtype T, channel stride g.CoutT):
+//   weight/bias/BN gradients (when grads != null) and dz of every source tensor.
+// sample0/nb/group0/ng select a sub-batch (discriminator G-loss pass: the fake group only).
+static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool want_dw, bool alt,
+                         int sample0, int nb, int group0, hipStream_t st) {
+  const int es = h->es;
+  const int group_n = n.batch / n.groups;
+  if (want_dw) {
+    WgradArgs w = L.wg.a;
+    PixSrc xs;
+    fill_src(n, L, xs, group_n, sample0, group0, es);
+    PixSrc ds;
+    set_single_src(ds, dy, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
+    if (L.g.kind == 0) { w.g = xs; w.d = ds; } else { w.g = ds; w.d = xs; }
+    w.partial = (float*)h->scratch;
+    w.dW = n.grads + L.w_off;
+    w.accumulate = 0;
+    VP_HIP_CHECK(launch_wgrad(w, h->bf16, L.wg.cfg, st));
+    float* db = n.grads + L.b_off;
+    if (L.has_bn) {
+      VP_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)L.g.Cout * sizeof(float), st));   // analytically zero
+    } else {
+      BnArgs b;
+      memset(&b, 0, sizeof(b));
+      b.y = dy; b.C = L.g.CoutT; b.G = 1; b.Pg = nb * L.g.Hout * L.g.Wout;
+      b.nchunk = bn_nchunk(b.Pg, b.C, 1, h->bf16);
+      b.partial = h->bn_partial;
+      VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
+    }
+  }
+  for (int s = 0; s < L.nsrc; ++s) {
+    if (!L.need_bwd[s]) continue;
+    Tens& ts = n.t[L.src[s]];
+    IgemmArgs a = alt ? L.bwd_alt[s].a : L.bwd[s].a;
+    set_single_src(a.x, dy, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
+    a.Wp = n.packed + L.pk_bwd[s] * es;
+    a.partial = (float*)h->scratch;
+    if (ts.is_input) {
+      a.Y = (n.groups == 3) ? h->d_din : h->d_vin;
+      a.accumulate = 0;
+    } else {
+      a.Y = ts.dz;
+      a.accumulate = ts.dz_written ? 1 : 0;
+      ts.dz_written = true;
+      // chain rule through the consumer's activation and (for BN tensors) up to the normalised value
+      a.ref = (const char*)ts.y + (size_t)sample0 * ts.H * ts.W * ts.C * es;
+      a.ref_act = L.in_act;
+      if (ts.has_bn) { a.ref_a = ts.bn.a + (size_t)group0 * ts.C; a.ref_b = ts.bn.b + (size_t)group0 * ts.C; }
+      a.ref_group_n = group_n;
+    }
+    VP_HIP_CHECK(launch_igemm(a, h->bf16, alt ? L.bwd_alt[s].cfg : L.bwd[s].cfg, st));
+  }
+  return VP_OK;
+}
+
+// dz -> dy through the training-mode batch norm of tensor t (in place), + dgamma/dbeta
+static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample0, int nb, int group0, int ng, hipStream_t st) {
+  Tens& t = n.t[L.out];
+  BnArgs b;
+  memset(&b, 0, sizeof(b));
+  b.y = (const char*)t.y + (size_t)sample0 * t.H * t.W * t.C * h->es;
+  b.dz = t.dz; b.dy = t.dz;
+  b.C = t.C; b.G = ng; b.Pg = (nb / ng) * t.H * t.W;
+  b.nchunk = bn_nchunk(b.Pg, b.C, b.G, h->bf16);
+  b.partial = h->bn_partial;
+  b.gamma = n.params + L.gamma_off;
+  b.mu = t.bn.mu + (size_t)group0 * t.C; b.rstd = t.bn.rstd + (size_t)group0 * t.C;
+  b.c1 = t.bn.c1; b.c2 = t.bn.c2;
+  if (want_dw) { b.dgamma = n.grads + L.gamma_off; b.dbeta = n.grads + L.beta_off; }
+  VP_HIP_CHECK(launch_bn_bwd(b, h->bf16, st));
+  return VP_OK;
+}
+
+}  // namespace vp
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int vp_version(void) { return 100; }
+const char* vp_last_error(void) { return g_err; }
+
+static Net* manifest_net(const vp_pixrefer_desc* d, int which, vp_pixrefer* tmp) {
+  if (which == 0) { build_generator(tmp->G, d->batch, d->height, d->ngf); return &tmp->G; }
+  if (which == 1) { build_discriminator(tmp->D, d->batch, d->height, d->ndf); return &tmp->D; }
+  if (which == 2) { build_vgg(tmp->V, d->batch, d->height); return &tmp->V; }
+  return nullptr;
+}
+
+size_t vp_pixrefer_param_count(const vp_pixrefer_desc* d, int which) {
+  if (!valid_desc(d)) return 0;
+  vp_pixrefer tmp{};
+  Net* n = manifest_net(d, which, &tmp);
+  return n ? n->nparams : 0;
+}
+
+int vp_pixrefer_param_info(const vp_pixrefer_desc* d, int which, int index, char* name, int name_cap,
+                           size_t* offset, int* ndim, int64_t shape[4]) {
+  if (!valid_desc(d)) return VP_ERR_ARG;
+  vp_pixrefer tmp{};
+  Net* n = manifest_net(d, which, &tmp);
+  if (!n || index < 0 || index >= (int)n->manifest.size()) return VP_ERR_ARG;
+  const ParamInfo& p = n->manifest[index];
+  if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (offset) *offset = p.off;
+  if (ndim) *ndim = p.ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  return VP_OK;
+}
+
+size_t vp_pixrefer_workspace_bytes(const vp_pixrefer_desc* d) {
+  if (!valid_desc(d)) return 0;
+  vp_pixrefer* h = new vp_pixrefer{};
+  init_handle(h, d);
+  const size_t n = carve_all(h, nullptr, 0);
+  delete h;
+  return n;
+}
+
+int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t workspace_bytes,
+                       float* params_g, float* params_d, const float* params_vgg,
+                       float* grads_g, float* grads_d, void* stream, vp_pixrefer_t** out) {
+  if (!valid_desc(d) || !workspace || !params_g || !out) { set_err("vp_pixrefer_create: bad argument"); return VP_ERR_ARG; }
+  if (d->training && (!params_d || !params_vgg || !grads_g || !grads_d)) { set_err("training needs D/VGG params and grad arenas"); return VP_ERR_ARG; }
+  vp_pixrefer* h = new vp_pixrefer{};
+  init_handle(h, d);
+  const size_t need = carve_all(h, nullptr, 0);
+  if (workspace_bytes < need) { set_err("workspace too small: %zu < %zu", workspace_bytes, need); delete h; return VP_ERR_WORKSPACE; }
+  carve_all(h, (char*)workspace, workspace_bytes);
+  h->G.params = params_g; h->G.grads = grads_g;
+  h->D.params = params_d; h->D.grads = grads_d;
+  h->V.params = const_cast<float*>(params_vgg);
+  // thin f32 outputs
+  for (Tens& t : h->G.t) if (t.name == "decoder_1") { t.y = h->y4; t.is_f32 = true; t.dz = h->dy4; }
+  hipStream_t st = (hipStream_t)stream;
+  if (d->training) for (Tens& t : h->D.t) if (t.name == "layer_5") { t.y = h->logits; t.is_f32 = true; t.dz = h->dl_d; }
+  for (Net* n : {&h->G, &h->D, &h->V}) {
+    if (n->descs.empty()) continue;
+    VP_HIP_CHECK(hipMemcpyAsync(n->d_descs, n->descs.data(), n->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+  }
+  VP_HIP_CHECK(hipStreamSynchronize(st));   // descs are host vectors owned by the handle; copy is complete
+  *out = h;
+  return VP_OK;
+}
+
+void vp_pixrefer_destroy(vp_pixrefer_t* h) { delete h; }
+
+int vp_pixrefer_params_changed(vp_pixrefer_t* h) {
+  if (!h) return VP_ERR_ARG;
+  h->params_dirty = true;
+  return VP_OK;
+}
+
+int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_inputs,
+                        const float* targets, const float* masks, void* stream) {
+  if (!h || !inputs || !fg_inputs || !targets) { set_err("vp_pixrefer_forward: null argument"); return VP_ERR_ARG; }
+  const vp_pixrefer_desc& d = h->d;
+  if (d.training && !masks) { set_err("vp_pixrefer_forward: masks required when training"); return VP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const int N = d.batch, H = d.height, bf = h->bf16;
+  int rc;
+  if (h->params_dirty) {
+    if ((rc = run_pack(h, h->G, st))) return rc;
+    if (d.training) {
+      if ((rc = run_pack(h, h->D, st))) return rc;
+      if ((rc = run_pack(h, h->V, st))) return rc;
+    }
+    h->params_dirty = false;
+  }
+  h->in_targets = targets; h->in_masks = masks;
+  PackInputsArgs pi;
+  memset(&pi, 0, sizeof(pi));
+  pi.inputs = inputs; pi.fg_inputs = fg_inputs; pi.gin = h->gin; pi.gfg = h->gfg; pi.din = h->din; pi.vin = h->vin;
+  pi.N = N; pi.HW = H * H; pi.train = d.training;
+  VP_HIP_CHECK(launch_pack_inputs(pi, bf, st));
+
+  for (Layer& L : h->G.l) if ((rc = run_layer_fwd(h, h->G, L, st))) return rc;
+
+  CompositeArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.y4 = h->y4; ca.targets = targets; ca.masks = masks; ca.o4 = h->o4; ca.outputs = h->outputs; ca.outputs_fg = h->outputs_fg;
+  ca.din = h->din; ca.vin = h->vin; ca.partial = h->comp_partial; ca.N = N; ca.HW = H * H; ca.train = d.training;
+  VP_HIP_CHECK(launch_composite_fwd(ca, bf, st));
+  if (!d.training) return VP_OK;
+
+  // discriminator on [real1 | real2 | fake] (pixrefer.py:295-306)
+  for (Layer& L : h->D.l) if ((rc = run_layer_fwd(h, h->D, L, st))) return rc;
+  const int hd = H / 8 - 2;
+  GanLossArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.logits = h->logits; ga.dl_d = h->dl_d; ga.dl_g = h->dl_g; ga.predict = h->predict; ga.losses = h->losses;
+  ga.M = N * hd * hd; ga.gan_weight = d.gan_weight;
+  VP_HIP_CHECK(launch_gan_loss(ga, bf, st));
+
+  // VGG trunk on [real fg | Outputs_FG] (pixrefer.py:321)
+  Net& V = h->V;
+  for (size_t i = 0; i < V.l.size(); ++i) {
+    Layer& L = V.l[i];
+    if ((rc = run_layer_fwd(h, V, L, st))) return rc;
+    if (L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2") {
+      const Tens& ti = V.t[L.out];
+      Tens& tp = V.t[L.out + 1];   // pool tensor follows in creation order
+      VP_HIP_CHECK(launch_maxpool_fwd(ti.y, tp.y, ti.N, ti.H, ti.W, ti.C, bf, st));
+    }
+  }
+  const Tens& f3 = V.t.back();
+  PerceptualArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.f3 = f3.y; pa.df3 = f3.dz; pa.partial = h->perc_partial; pa.half = f3.elems() / 2; pa.l1_weight = d.l1_weight;
+  VP_HIP_CHECK(launch_perceptual(pa, bf, st));
+
+  LossFinalArgs lf;
+  memset(&lf, 0, sizeof(lf));
+  lf.comp_partial = h->comp_partial; lf.n_comp = h->n_comp; lf.perc_partial = h->perc_partial; lf.n_perc = h->n_perc;
+  lf.n_out = (double)N * H * H * 3; lf.n_feat = (double)pa.half; lf.losses = h->losses;
+  lf.l1_weight = d.l1_weight; lf.gan_weight = d.gan_weight;
+  VP_HIP_CHECK(launch_loss_final(lf, st));
+  return VP_OK;
+}
+
+int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
+  if (!h || !h->d.training) { set_err("vp_pixrefer_backward: needs a training plan"); return VP_ERR_STATE; }
+  hipStream_t st = (hipStream_t)stream;
+  const vp_pixrefer_desc& d = h->d;
+  const int N = d.batch, H = d.height, bf = h->bf16, es = h->es;
+  int rc;
+  Net &G = h->G, &D = h->D, &V = h->V;
+
+  // ---- Discrim_loss -> discriminator* (pixrefer.py:396-400), all three applications at once ----
+  for (Tens& t : D.t) t.dz_written = false;
+  for (int i = (int)D.l.size() - 1; i >= 0; --i) {
+    Layer& L = D.l[i];
+    Tens& to = D.t[L.out];
+    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, true, 0, 3 * N, 0, 3, st))) return rc;
+    const bool save = L.need_bwd[0];
+    if (i == 0) L.need_bwd[0] = false;          // no gradient w.r.t. the images for the D loss
+    rc = run_layer_bwd(h, D, L, to.dz, true, false, 0, 3 * N, 0, st);
+    L.need_bwd[0] = save;
+    if (rc) return rc;
+  }
+
+  // ---- Gen_loss -> generator* (pixrefer.py:402-407) ----
+  // (a) GAN term through the fake application of the discriminator (dX only, pre-update weights)
+  for (Tens& t : D.t) t.dz_written = false;
+  for (int i = (int)D.l.size() - 1; i >= 0; --i) {
+    Layer& L = D.l[i];
+    Tens& to = D.t[L.out];
+    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, false, 2 * N, N, 2, 1, st))) return rc;
+    const void* dy = (i == (int)D.l.size() - 1) ? h->dl_g : to.dz;
+    if ((rc = run_layer_bwd(h, D, L, dy, false, true, 2 * N, N, 2, st))) return rc;
+  }
+  // (b) perceptual term through the VGG trunk, fake half only (dX only: VGG is frozen)
+  for (Tens& t : V.t) t.dz_written = false;
+  for (int i = (int)V.l.size() - 1; i >= 0; --i) {
+    Layer& L = V.l[i];
+    Tens& to = V.t[L.out];
+    Tens& ti = V.t[L.src[0]];
+    // dz of a conv output here is already w.r.t. the pre-relu value (perceptual seed / epilogue / pool bwd)
+    IgemmArgs a = L.bwd_alt[0].a;
+    set_single_src(a.x, to.dz, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
+    a.Wp = V.packed + L.pk_bwd[0] * es;
+    a.partial = (float*)h->scratch;
+    const bool from_pool = (ti.name == "pool1" || ti.name == "pool2");
+    if (ti.is_input) {
+      a.Y = h->d_vin;
+    } else {
+      a.Y = ti.dz;
+      if (!from_pool) {   // producer is a conv+relu: multiply by relu'(stored output of the fake half)
+        a.ref = (const char*)ti.y + ti.elems() / 2 * es;
+        a.ref_act = ACT_RELU;
+      }
+    }
+    VP_HIP_CHECK(launch_igemm(a, bf, L.bwd_alt[0].cfg, st));
+    if (from_pool) {
+      // ti = pool output; its input is the conv tensor created just before it
+      const int ci = L.src[0] - 1;
+      Tens& tc = V.t[ci];
+      const char* xin = (const char*)tc.y + tc.elems() / 2 * es;
+      VP_HIP_CHECK(launch_maxpool_bwd(xin, ti.dz, tc.dz, N, tc.H, tc.W, tc.C, bf, st));
+    }
+  }
+  // (c) composite + L1 / matte terms -> gradient w.r.t. the pre-tanh generator output
+  CompositeArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.targets = h->in_targets; ca.masks = h->in_masks; ca.o4 = h->o4; ca.outputs = h->outputs;
+  ca.d_din = h->d_din; ca.d_vin = h->d_vin; ca.dy4 = h->dy4; ca.N = N; ca.HW = H * H; ca.l1_weight = d.l1_weight;
+  VP_HIP_CHECK(launch_composite_bwd(ca, bf, st));
+  // (d) generator, last layer first
+  for (Tens& t : G.t) t.dz_written = false;
+  for (int i = (int)G.l.size() - 1; i >= 0; --i) {
+    Layer& L = G.l[i];
+    Tens& to = G.t[L.out];
+    if (L.has_bn) if ((rc = run_bn_bwd(h, G, L, true, 0, N, 0, 1, st))) return rc;
+    if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st))) return rc;
+  }
+  return VP_OK;
+}
+
+int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t shape[4], int* dtype) {
+  if (!h || !name || !ptr) return VP_ERR_ARG;
+  const int N = h->d.batch, H = h->d.height;
+  auto ret = [&](void* p, int64_t a, int64_t b, int64_t c, int64_t e, int dt) {
+    *ptr = p;
+    if (shape) { shape[0] = a; shape[1] = b; shape[2] = c; shape[3] = e; }
+    if (dtype) *dtype = dt;
+    return p ? VP_OK : VP_ERR_STATE;
+  };
+  const std::string s(name);
+  const int cd = h->bf16 ? VP_BF16 : VP_F32;
+  if (s == "Outputs_raw") return ret(h->outputs, N, H, H, 3, VP_F32);
+  if (s == "Outputs_FG") return ret(h->outputs_fg, N, H, H, 3, VP_F32);
+  if (s == "gen_out4") return ret(h->o4, N, H, H, 4, VP_F32);
+  if (s == "losses") return ret(h->losses, 8, 1, 1, 1, VP_F32);
+  const int hd = H / 8 - 2;
+  if (s == "Predict") return ret(h->predict, 2, N, hd, hd, VP_F32);
+  if (s == "logits") return ret(h->logits, 3 * N, hd, hd, 1, VP_F32);
+  if (s == "d_gen_out4") return ret(h->dy4, N, H, H, 8, cd);
+  if (s == "d_din") return ret(h->d_din, N, H, H, 8, cd);
+  if (s == "d_vin") return ret(h->d_vin, N, H, H, 8, cd);
+  const size_t c = s.find('/');
+  if (c == std::string::npos) return VP_ERR_ARG;
+  const std::string net = s.substr(0, c);
+  std::string rest = s.substr(c + 1);
+  Net* n = net == "g" ? &h->G : net == "d" ? &h->D : net == "v" ? &h->V : nullptr;
+  if (!n) return VP_ERR_ARG;
+  std::string field;
+  const size_t k = rest.find(':');
+  if (k != std::string::npos) { field = rest.substr(k + 1); rest = rest.substr(0, k); }
+  for (Tens& t : n->t) {
+    if (t.name != rest) continue;
+    if (field.empty()) return ret(t.y, t.N, t.H, t.W, t.is_f32 ? (t.name == "decoder_1" ? 4 : 1) : t.C, t.is_f32 ? VP_F32 : cd);
+    if (field == "dy") return ret(t.dz, n == &h->V ? t.N / 2 : t.N, t.H, t.W, t.C, cd);
+    if (!t.has_bn) return VP_ERR_ARG;
+    if (field == "scale") return ret(t.bn.a, n->groups, t.C, 1, 1, VP_F32);
+    if (field == "shift") return ret(t.bn.b, n->groups, t.C, 1, 1, VP_F32);
+    if (field == "mean") return ret(t.bn.mu, n->groups, t.C, 1, 1, VP_F32);
+    if (field == "rstd") return ret(t.bn.rstd, n->groups, t.C, 1, 1, VP_F32);
+    return VP_ERR_ARG;
+  }
+  return VP_ERR_ARG;
+}
+
+int vp_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, int step_t,
+               float lr, float beta1, float beta2, float eps, void* stream) {
+  if (!params || !grads || !m || !v || step_t < 1) { set_err("vp_adam_tf: bad argument"); return VP_ERR_ARG; }
+  AdamArgs a;
+  a.p = params; a.g = grads; a.m = m; a.v = v; a.n = n;
+  a.lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, step_t)) / (1.0 - pow((double)beta1, step_t)));
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  VP_HIP_CHECK(launch_adam(a, (hipStream_t)stream));
+  return VP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,598 @@
+// HBM-bound kernels of the PixReferNet step: weight packing, training-mode batch-norm statistics
+// (fwd and bwd), input packing, alpha compositing (fwd/bwd), GAN / L1 / perceptual losses, 2x2
+// max-pool, TF-style Adam.  All reductions are two-stage with a fixed summation order, so a step
+// is bit-reproducible.
+#include "pointwise_args.h"
+#include "vp_common.h"
+
+namespace vp {
+
+// block-wide sum of NV doubles per thread; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sm /* >= NV*4 doubles */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sm[i * 16 + wave] = v[i];
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double s = 0;
+      for (int w = 0; w < nw; ++w) s += sm[i * 16 + w];
+      v[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (fp32 master, TF layouts HWIO / HWOI) -> [class][row][tap*C + c] in T
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ master, T* __restrict__ packed) {
+  const PackDesc& d = descs[blockIdx.y];
+  const size_t total = (size_t)d.nclass * d.rows_pad * d.Kpad;
+  T* dst = packed + d.dst_off;
+  const float* src = master + d.src_off;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % d.Kpad);
+    const size_t t = i / d.Kpad;
+    const int row = (int)(t % d.rows_pad);
+    const int cls = (int)(t / d.rows_pad);
+    const int tap = k / d.C, c = k - tap * d.C;
+    float v = 0.f;
+    if (row < d.rows_real && tap < d.ntaps && c < d.C_real)
+      v = src[(size_t)d.kh[cls][tap] * d.s_kh + (size_t)d.kw[cls][tap] * d.s_kw + (size_t)row * d.s_row + (size_t)c * d.s_ch];
+    Elem<T>::st(dst + i, v);
+  }
+}
+
+// single-descriptor variant (descriptor passed by value) for the stand-alone op entry points
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_one_kernel(const PackDesc d, const float* __restrict__ master, T* __restrict__ packed) {
+  const size_t total = (size_t)d.nclass * d.rows_pad * d.Kpad;
+  T* dst = packed + d.dst_off;
+  const float* src = master + d.src_off;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % d.Kpad);
+    const size_t t = i / d.Kpad;
+    const int row = (int)(t % d.rows_pad);
+    const int cls = (int)(t / d.rows_pad);
+    const int tap = k / d.C, c = k - tap * d.C;
+    float v = 0.f;
+    if (row < d.rows_real && tap < d.ntaps && c < d.C_real) {
+      // select the tap entry without dynamically indexing the by-value argument block
+      int kh = 0, kw = 0;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt)
+          if (cc == cls && tt == tap) { kh = d.kh[cc][tt]; kw = d.kw[cc][tt]; }
+      v = src[(size_t)kh * d.s_kh + (size_t)kw * d.s_kw + (size_t)row * d.s_row + (size_t)c * d.s_ch];
+    }
+    Elem<T>::st(dst + i, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch-norm statistics.  MODE 0: sum y, sum y^2.  MODE 1: sum dz, sum dz*zhat.
+// grid = (nchunk, G); thread -> (pixel lane, E-channel group); double accumulation.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs a) {
+  constexpr int E = Elem<T>::E;
+  const int ncg = a.C / E;                       // channel groups (divides 256)
+  const int cgi = threadIdx.x % ncg, prow = threadIdx.x / ncg, nprow = 256 / ncg;
+  const int grp = blockIdx.y;
+  const int per = (a.Pg + a.nchunk - 1) / a.nchunk;
+  const int p0 = blockIdx.x * per, p1 = min(a.Pg, p0 + per);
+  double s0[E], s1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { s0[e] = 0; s1[e] = 0; }
+  float mu[E], rs[E];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) { mu[e] = a.mu[grp * a.C + cgi * E + e]; rs[e] = a.rstd[grp * a.C + cgi * E + e]; }
+  }
+  const T* y = reinterpret_cast<const T*>(a.y) + (size_t)grp * a.Pg * a.C + cgi * E;
+  const T* dz = reinterpret_cast<const T*>(a.dz) + (size_t)grp * a.Pg * a.C + cgi * E;
+  for (int p = p0 + prow; p < p1; p += nprow) {
+    float fy[E];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + (size_t)p * a.C), fy);
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) { s0[e] += fy[e]; s1[e] += (double)fy[e] * fy[e]; }
+    } else {
+      float fd[E];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(dz + (size_t)p * a.C), fd);
+#pragma unroll
+      for (int e = 0; e < E; ++e) { s0[e] += fd[e]; s1[e] += (double)fd[e] * ((fy[e] - mu[e]) * rs[e]); }
+    }
+  }
+  // reduce over the pixel lanes that share a channel group
+  __shared__ double sm[256 * 2];
+  double* out = a.partial + ((size_t)(grp * a.nchunk + blockIdx.x) * 2) * a.C;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    __syncthreads();
+    sm[threadIdx.x] = s0[e]; sm[256 + threadIdx.x] = s1[e];
+    __syncthreads();
+    if (prow == 0) {
+      double t0 = 0, t1 = 0;
+      for (int r = 0; r < nprow; ++r) { t0 += sm[r * ncg + cgi]; t1 += sm[256 + r * ncg + cgi]; }
+      out[cgi * E + e] = t0; out[a.C + cgi * E + e] = t1;
+    }
+  }
+}
+
+// one thread per (group, channel): mean / biased variance -> affine (pixrefer.py:99-101, eps in sqrt)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.G * a.C) return;
+  const int grp = i / a.C, c = i - grp * a.C;
+  double s0 = 0, s1 = 0;
+  for (int k = 0; k < a.nchunk; ++k) {
+    const double* p = a.partial + ((size_t)(grp * a.nchunk + k) * 2) * a.C;
+    s0 += p[c]; s1 += p[a.C + c];
+  }
+  const double mean = s0 / a.Pg;
+  double var = s1 / a.Pg - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float g = a.gamma[c], b = a.beta[c];
+  // zero variance (N=1 at the 1x1 bottleneck): y - mean == 0 exactly, so z == beta exactly
+  const float sc = (var == 0.0) ? 0.f : g * rstd;
+  a.aff_a[i] = sc;
+  a.aff_b[i] = (var == 0.0) ? b : (float)((double)b - mean * (double)sc);
+  a.mu[i] = (float)mean;
+  a.rstd[i] = rstd;
+}
+
+// bwd: c1 = mean(dz), c2 = mean(dz*zhat) per group; dgamma/dbeta summed over groups
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.C) return;
+  double dg = 0, db = 0;
+  for (int grp = 0; grp < a.G; ++grp) {
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < a.nchunk; ++k) {
+      const double* p = a.partial + ((size_t)(grp * a.nchunk + k) * 2) * a.C;
+      s0 += p[c]; s1 += p[a.C + c];
+    }
+    a.c1[grp * a.C + c] = (float)(s0 / a.Pg);
+    a.c2[grp * a.C + c] = (float)(s1 / a.Pg);
+    db += s0; dg += s1;
+  }
+  if (a.dgamma) {
+    a.dgamma[c] = (float)dg + (a.accumulate ? a.dgamma[c] : 0.f);
+    a.dbeta[c] = (float)db + (a.accumulate ? a.dbeta[c] : 0.f);
+  }
+}
+
+// dy = gamma*rstd*(dz - c1 - zhat*c2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
+  constexpr int E = Elem<T>::E;
+  const int ncg = a.C / E;
+  const size_t total = (size_t)a.G * a.Pg * ncg;
+  const T* y = reinterpret_cast<const T*>(a.y);
+  const T* dz = reinterpret_cast<const T*>(a.dz);
+  T* dy = reinterpret_cast<T*>(a.dy);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cgi = (int)(i % ncg);
+    const size_t pix = i / ncg;
+    const int grp = (int)(pix / a.Pg);
+    const int c0 = cgi * E;
+    float fy[E], fd[E];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + pix * a.C + c0), fy);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(dz + pix * a.C + c0), fd);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int gi = grp * a.C + c0 + e;
+      const float rs = a.rstd[gi];
+      const float zh = (fy[e] - a.mu[gi]) * rs;
+      fd[e] = a.gamma[c0 + e] * rs * (fd[e] - a.c1[gi] - zh * a.c2[gi]);
+    }
+    *reinterpret_cast<uint4*>(dy + pix * a.C + c0) = Elem<T>::pack(fd);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// input packing: [0,1] -> [-1,1] (pixrefer.py:373-375), channel padding to 8, the real halves of the
+// discriminator and VGG batches (pixrefer.py:295-306, 321)
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&f)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&f)[8]) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&f)[8]) {
+  *reinterpret_cast<uint4*>(p) = Elem<bf16>::pack(f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_inputs_kernel(const PackInputsArgs a) {
+  const size_t total = (size_t)a.N * a.HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float in[6], fg[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { in[c] = a.inputs[i * 6 + c] * 2.f - 1.f; fg[c] = a.fg_inputs[i * 6 + c] * 2.f - 1.f; }
+    { const float f[8] = {in[0], in[1], in[2], in[3], in[4], in[5], 0.f, 0.f}; store8<T>(reinterpret_cast<T*>(a.gin) + i * 8, f); }
+    { const float f[8] = {fg[0], fg[1], fg[2], 0.f, 0.f, 0.f, 0.f, 0.f}; store8<T>(reinterpret_cast<T*>(a.gfg) + i * 8, f); }
+    if (a.train) {
+      T* din = reinterpret_cast<T*>(a.din);
+      { const float f[8] = {in[3], in[4], in[5], fg[3], fg[4], fg[5], 0.f, 0.f}; store8<T>(din + i * 8, f); }
+      { const float f[8] = {in[0], in[1], in[2], fg[0], fg[1], fg[2], 0.f, 0.f}; store8<T>(din + (total + i) * 8, f); }
+      { const float f[8] = {in[3], in[4], in[5], 0.f, 0.f, 0.f, 0.f, 0.f}; store8<T>(din + (2 * total + i) * 8, f); }
+      { const float f[8] = {fg[3], fg[4], fg[5], 0.f, 0.f, 0.f, 0.f, 0.f}; store8<T>(reinterpret_cast<T*>(a.vin) + i * 8, f); }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// alpha composite (pixrefer.py:281-286) fused with tanh, the L1 / matte loss partial sums and the
+// hand-over of Outputs_FG to the discriminator and VGG batches
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeArgs a) {
+  const size_t total = (size_t)a.N * a.HW;
+  double acc[2] = {0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const float4 y = reinterpret_cast<const float4*>(a.y4)[i];
+    const float o[4] = {tanhf(y.x), tanhf(y.y), tanhf(y.z), tanhf(y.w)};
+    reinterpret_cast<float4*>(a.o4)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    const float al = (o[3] + 1.f) * 0.5f;
+    float ofg[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float tg = a.targets[i * 3 + c] * 2.f - 1.f;
+      const float out = o[c] * al + tg * (1.f - al);
+      ofg[c] = o[c] * al + al - 1.f;
+      a.outputs[i * 3 + c] = out;
+      a.outputs_fg[i * 3 + c] = ofg[c];
+      if (a.train) {
+        acc[0] += fabsf(tg - out);
+        acc[1] += fabsf(a.masks[i * 3 + c] - al);
+      }
+    }
+    if (a.train) {
+      T* d = reinterpret_cast<T*>(a.din) + (2 * total + i) * 8 + 3;
+      T* v = reinterpret_cast<T*>(a.vin) + (total + i) * 8;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { Elem<T>::st(d + c, ofg[c]); Elem<T>::st(v + c, ofg[c]); }
+#pragma unroll
+      for (int c = 3; c < 8; ++c) Elem<T>::st(v + c, 0.f);
+    }
+  }
+  if (a.train) {
+    __shared__ double sm[64];
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) { a.partial[blockIdx.x * 2] = acc[0]; a.partial[blockIdx.x * 2 + 1] = acc[1]; }
+  }
+}
+
+// gradient of Gen_loss w.r.t. the pre-tanh generator output
+template <typename T>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeArgs a) {
+  const size_t total = (size_t)a.N * a.HW;
+  const float s = a.l1_weight / (float)((double)total * 3.0);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const float4 o4 = reinterpret_cast<const float4*>(a.o4)[i];
+    const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+    const float al = (o[3] + 1.f) * 0.5f;
+    const T* dd = reinterpret_cast<const T*>(a.d_din) + i * 8 + 3;
+    const T* dv = reinterpret_cast<const T*>(a.d_vin) + i * 8;
+    float dout[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float dal = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float tg = a.targets[i * 3 + c] * 2.f - 1.f;
+      const float out = a.outputs[i * 3 + c];
+      const float df = tg - out, dm = a.masks[i * 3 + c] - al;
+      const float d_out = -s * ((df > 0.f) - (df < 0.f));
+      const float d_al = -s * ((dm > 0.f) - (dm < 0.f));
+      const float d_fg = Elem<T>::ld(dd + c) + Elem<T>::ld(dv + c);
+      dout[c] = (d_out + d_fg) * al;
+      dal += d_out * (o[c] - tg) + d_fg * (o[c] + 1.f) + d_al;
+    }
+    dout[3] = dal * 0.5f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dout[c] *= (1.f - o[c] * o[c]);
+    store8<T>(reinterpret_cast<T*>(a.dy4) + i * 8, dout);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GAN losses and their seeds (pixrefer.py:334-347).  One block; M = N*30*30 at 256x256.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void gan_loss_kernel(const GanLossArgs a) {
+  const float eps = 1e-12f;
+  double acc[2] = {0, 0};
+  const float invM = 1.f / (float)a.M;
+  T* dld = reinterpret_cast<T*>(a.dl_d);
+  T* dlg = reinterpret_cast<T*>(a.dl_g);
+  for (int i = threadIdx.x; i < a.M; i += 1024) {
+    const float p0 = 1.f / (1.f + expf(-a.logits[i]));
+    const float p1 = 1.f / (1.f + expf(-a.logits[a.M + i]));
+    const float pf = 1.f / (1.f + expf(-a.logits[2 * a.M + i]));
+    const float pr = (p0 + p1) * 0.5f;
+    a.predict[i] = pr; a.predict[a.M + i] = pf;
+    acc[0] += -(logf(pr + eps) * 2.f + logf(1.f - pf + eps));
+    acc[1] += -logf(pf + eps);
+    const float dpr = -2.f / (pr + eps) * invM * 0.5f;
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f[0] = dpr * p0 * (1.f - p0); store8<T>(dld + (size_t)i * 8, f);
+    f[0] = dpr * p1 * (1.f - p1); store8<T>(dld + (size_t)(a.M + i) * 8, f);
+    f[0] = 1.f / (1.f - pf + eps) * invM * pf * (1.f - pf); store8<T>(dld + (size_t)(2 * a.M + i) * 8, f);
+    f[0] = a.gan_weight * (-1.f / (pf + eps)) * invM * pf * (1.f - pf); store8<T>(dlg + (size_t)i * 8, f);
+  }
+  __shared__ double sm[64];
+  block_sum<2>(acc, sm);
+  if (threadIdx.x == 0) { a.losses[0] = (float)(acc[0] / a.M); a.losses[1] = (float)(acc[1] / a.M); }
+}
+
+// perceptual loss on conv3_3 (pixrefer.py:321-323) + seed for the fake half (through its relu)
+template <typename T>
+__global__ __launch_bounds__(256) void perceptual_kernel(const PerceptualArgs a) {
+  constexpr int E = Elem<T>::E;
+  const T* f = reinterpret_cast<const T*>(a.f3);
+  T* df = reinterpret_cast<T*>(a.df3);
+  const float s = a.l1_weight / (float)a.half;
+  double acc[1] = {0};
+  const size_t nv = a.half / E;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    float fa[E], fb[E], d[E];
+    Elem<T>::unpack(reinterpret_cast<const uint4*>(f)[i], fa);
+    Elem<T>::unpack(reinterpret_cast<const uint4*>(f + a.half)[i], fb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float x = fa[e] - fb[e];
+      acc[0] += (double)x * x;
+      d[e] = (fb[e] > 0.f) ? -s * x : 0.f;
+    }
+    reinterpret_cast<uint4*>(df)[i] = Elem<T>::pack(d);
+  }
+  __shared__ double sm[64];
+  block_sum<1>(acc, sm);
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = acc[0];
+}
+
+__global__ void loss_final_kernel(const LossFinalArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double l1 = 0, mt = 0, pc = 0;
+  for (int i = 0; i < a.n_comp; ++i) { l1 += a.comp_partial[2 * i]; mt += a.comp_partial[2 * i + 1]; }
+  for (int i = 0; i < a.n_perc; ++i) pc += a.perc_partial[i];
+  const double content = pc / 2.0 / a.n_feat;
+  const double gl1 = l1 / a.n_out + mt / a.n_out + content;
+  a.losses[2] = (float)gl1;
+  a.losses[3] = (float)((double)a.losses[1] * a.gan_weight + gl1 * a.l1_weight);
+  a.losses[4] = (float)content;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2/s2 max-pool (vgg_simple.py:143,150) fwd, and bwd fused with the relu' of the producing conv
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  constexpr int E = Elem<T>::E;
+  const int ncg = C / E, Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)B * Ho * Wo * ncg;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    size_t t = i / ncg;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const T* p = x + (((size_t)n * H + 2 * oh) * W + 2 * ow) * C + cg * E;
+    float m[E], v[E];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(p), m);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(p + C), v);
+#pragma unroll
+    for (int e = 0; e < E; ++e) m[e] = fmaxf(m[e], v[e]);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(p + (size_t)W * C), v);
+#pragma unroll
+    for (int e = 0; e < E; ++e) m[e] = fmaxf(m[e], v[e]);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(p + (size_t)W * C + C), v);
+#pragma unroll
+    for (int e = 0; e < E; ++e) m[e] = fmaxf(m[e], v[e]);
+    *reinterpret_cast<uint4*>(y + i * E) = Elem<T>::pack(m);
+  }
+}
+
+// dx = (first arg-max of the window) ? dy : 0, times relu'(x) of the conv that produced x (x is post-relu)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C) {
+  constexpr int E = Elem<T>::E;
+  const int ncg = C / E, Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)B * Ho * Wo * ncg;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    size_t t = i / ncg;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const size_t base = (((size_t)n * H + 2 * oh) * W + 2 * ow) * C + cg * E;
+    const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    float v[4][E], g[E];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + base + offs[k]), v[k]);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + i * E), g);
+    float o[4][E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      int best = 0;
+      float m = v[0][e];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) if (v[k][e] > m) { m = v[k][e]; best = k; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][e] = (k == best && m > 0.f) ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(dx + base + offs[k]) = Elem<T>::pack(o[k]);
+  }
+}
+
+// relu' on a stored post-relu tensor: d *= (y > 0)   (used where no bwd-data epilogue can do it)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ y, T* __restrict__ d, size_t nvec) {
+  constexpr int E = Elem<T>::E;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    float fy[E], fd[E];
+    Elem<T>::unpack(reinterpret_cast<const uint4*>(y)[i], fy);
+    Elem<T>::unpack(reinterpret_cast<const uint4*>(d)[i], fd);
+#pragma unroll
+    for (int e = 0; e < E; ++e) fd[e] = fy[e] > 0.f ? fd[e] : 0.f;
+    reinterpret_cast<uint4*>(d)[i] = Elem<T>::pack(fd);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.train.AdamOptimizer over a flat arena (pixrefer.py:398,405): theta -= lr_t * m / (sqrt(v) + eps)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_tf_kernel(const AdamArgs a) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+    const float g = a.g[i];
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m; a.v[i] = v;
+    a.p[i] -= a.lr_t * m / (sqrtf(v) + a.eps);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+static inline int nblocks(size_t work, int cap = 2048) {
+  size_t b = (work + 255) / 256;
+  if (b < 1) b = 1;
+  return (int)(b > (size_t)cap ? cap : b);
+}
+
+#define VP_DISPATCH(is_bf16, KERNEL, grid, block, stream, ...)                         \
+  do {                                                                                 \
+    if (is_bf16) hipLaunchKernelGGL((KERNEL<bf16>), grid, block, 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<float>), grid, block, 0, stream, __VA_ARGS__);       \
+  } while (0)
+
+hipError_t launch_pack_weights(const PackDesc* d_descs, int ndesc, const float* master, void* packed, int is_bf16, hipStream_t st) {
+  dim3 grid(512, ndesc);
+  if (is_bf16) hipLaunchKernelGGL((pack_weights_kernel<bf16>), grid, dim3(256), 0, st, d_descs, master, (bf16*)packed);
+  else hipLaunchKernelGGL((pack_weights_kernel<float>), grid, dim3(256), 0, st, d_descs, master, (float*)packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_weights_one(const PackDesc& d, const float* master, void* packed, int is_bf16, hipStream_t st) {
+  if (is_bf16) hipLaunchKernelGGL((pack_weights_one_kernel<bf16>), dim3(512), dim3(256), 0, st, d, master, (bf16*)packed);
+  else hipLaunchKernelGGL((pack_weights_one_kernel<float>), dim3(512), dim3(256), 0, st, d, master, (float*)packed);
+  return hipGetLastError();
+}
+
+int bn_nchunk(int Pg, int C, int G, int is_bf16) {
+  const int E = is_bf16 ? 8 : 4;
+  const int nprow = 256 / (C / E);
+  int n = (Pg + nprow * 8 - 1) / (nprow * 8);       // >= 8 pixel rows per thread
+  const int cap = 1024 / G;
+  if (n > cap) n = cap;
+  return n < 1 ? 1 : n;
+}
+
+hipError_t launch_bn_stats(const BnArgs& a, int is_bf16, hipStream_t st) {
+  dim3 grid(a.nchunk, a.G);
+  if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 0>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.G * a.C + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st) {
+  dim3 grid(a.nchunk, a.G);
+  if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 1>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 255) / 256), dim3(256), 0, st, a);
+  const size_t work = (size_t)a.G * a.Pg * (a.C / (is_bf16 ? 8 : 4));
+  VP_DISPATCH(is_bf16, bn_bwd_apply_kernel, dim3(nblocks(work)), dim3(256), st, a);
+  return hipGetLastError();
+}
+
+// out[c] (+)= sum over pixels of x[p][c], c < creal  (bias gradients of the BN-free layers)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const BnArgs a, int creal, float* out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= creal) return;
+  double s = 0;
+  for (int grp = 0; grp < a.G; ++grp)
+    for (int k = 0; k < a.nchunk; ++k) s += a.partial[((size_t)(grp * a.nchunk + k) * 2) * a.C + c];
+  out[c] = (float)s + (accumulate ? out[c] : 0.f);
+}
+
+hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate, int is_bf16, hipStream_t st) {
+  dim3 grid(a.nchunk, a.G);
+  if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 0>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((creal + 255) / 256), dim3(256), 0, st, a, creal, out, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_inputs(const PackInputsArgs& a, int is_bf16, hipStream_t st) {
+  VP_DISPATCH(is_bf16, pack_inputs_kernel, dim3(nblocks((size_t)a.N * a.HW)), dim3(256), st, a);
+  return hipGetLastError();
+}
+
+int composite_nblocks(int N, int HW) { return nblocks((size_t)N * HW, 1024); }
+
+hipError_t launch_composite_fwd(const CompositeArgs& a, int is_bf16, hipStream_t st) {
+  VP_DISPATCH(is_bf16, composite_fwd_kernel, dim3(composite_nblocks(a.N, a.HW)), dim3(256), st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_composite_bwd(const CompositeArgs& a, int is_bf16, hipStream_t st) {
+  VP_DISPATCH(is_bf16, composite_bwd_kernel, dim3(nblocks((size_t)a.N * a.HW)), dim3(256), st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_gan_loss(const GanLossArgs& a, int is_bf16, hipStream_t st) {
+  VP_DISPATCH(is_bf16, gan_loss_kernel, dim3(1), dim3(1024), st, a);
+  return hipGetLastError();
+}
+
+int perceptual_nblocks(size_t half, int is_bf16) { return nblocks(half / (is_bf16 ? 8 : 4), 1024); }
+
+hipError_t launch_perceptual(const PerceptualArgs& a, int is_bf16, hipStream_t st) {
+  VP_DISPATCH(is_bf16, perceptual_kernel, dim3(perceptual_nblocks(a.half, is_bf16)), dim3(256), st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_loss_final(const LossFinalArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int is_bf16, hipStream_t st) {
+  const size_t work = (size_t)B * (H / 2) * (W / 2) * (C / (is_bf16 ? 8 : 4));
+  if (is_bf16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16>), dim3(nblocks(work)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, B, H, W, C);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(nblocks(work)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int is_bf16, hipStream_t st) {
+  const size_t work = (size_t)B * (H / 2) * (W / 2) * (C / (is_bf16 ? 8 : 4));
+  if (is_bf16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16>), dim3(nblocks(work)), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, B, H, W, C);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(nblocks(work)), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_relu_bwd(const void* y, void* d, size_t n, int is_bf16, hipStream_t st) {
+  const size_t nvec = n / (is_bf16 ? 8 : 4);
+  if (is_bf16) hipLaunchKernelGGL((relu_bwd_kernel<bf16>), dim3(nblocks(nvec)), dim3(256), 0, st, (const bf16*)y, (bf16*)d, nvec);
+  else hipLaunchKernelGGL((relu_bwd_kernel<float>), dim3(nblocks(nvec)), dim3(256), 0, st, (const float*)y, (float*)d, nvec);
+  return hipGetLastError();
+}
+
+hipError_t launch_adam(const AdamArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(adam_tf_kernel, dim3(nblocks(a.n, 4096)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace vp

@@ -1,0 +1,100 @@
+// Argument blocks of the HBM-bound kernels (weight packing, BN statistics, compositing, losses, Adam).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vp {
+
+// dst[cls][row][tap*C + c] = src[kh*s_kh + kw*s_kw + row*s_row + c*s_ch]   (0 in the padding)
+struct PackDesc {
+  size_t src_off;           // floats into the fp32 master arena
+  size_t dst_off;           // elements into the packed arena
+  int nclass, rows_real, rows_pad, ntaps, C, C_real, Kpad;
+  int s_kh, s_kw, s_row, s_ch;
+  int8_t kh[4][16];
+  int8_t kw[4][16];
+};
+
+struct BnArgs {
+  const void* y;            // [G*Pg][C] raw conv output
+  const void* dz;           // bwd: gradient w.r.t. the normalised tensor
+  void* dy;                 // bwd apply: output (may alias dz)
+  int C, G, Pg;             // channels, BN groups, pixels per group
+  int nchunk;               // pixel chunks per group (partials)
+  double* partial;          // [G][nchunk][2][C]
+  const float* gamma;
+  const float* beta;
+  float* aff_a;             // [G][C]  z = a*y + b
+  float* aff_b;
+  float* mu;                // [G][C]
+  float* rstd;
+  float* c1;                // [G][C] mean(dz), mean(dz*zhat)
+  float* c2;
+  float* dgamma;            // [C]
+  float* dbeta;
+  int accumulate;           // dgamma/dbeta +=
+  float eps;
+};
+
+struct PackInputsArgs {
+  const float* inputs;      // [N,H,W,6] in [0,1]
+  const float* fg_inputs;   // [N,H,W,6]
+  void* gin;                // [N,H,W,8]   generator input  (inputs*2-1, 0, 0)
+  void* gfg;                // [N,H,W,8]   fg branch input  (fg[...,:3]*2-1, 0 x5)
+  void* din;                // [3N,H,W,8]  discriminator batch: real1 | real2 | fake(cond only)
+  void* vin;                // [2N,H,W,8]  VGG batch: real fg | (fake, written by composite)
+  int N, HW, train;
+};
+
+struct CompositeArgs {
+  const float* y4;          // [N,H,W,4] decoder_1 output (pre-tanh, bias included)
+  const float* targets;     // [N,H,W,3] in [0,1]
+  const float* masks;       // [N,H,W,3] in [0,1] (train only)
+  float* o4;                // [N,H,W,4] tanh(y4)
+  float* outputs;           // [N,H,W,3] in [-1,1]
+  float* outputs_fg;        // [N,H,W,3]
+  void* din;                // fake group image channels 3:6 (train)
+  void* vin;                // fake half channels 0:3 (train)
+  double* partial;          // [nblocks][2]  sum|tgt-out|, sum|mask-alpha|
+  int N, HW, train;
+  // backward
+  const void* d_din;        // [N,H,W,8] grad of D layer_1 input (G loss), channels 3:6
+  const void* d_vin;        // [N,H,W,8] grad of VGG input (fake half), channels 0:3
+  void* dy4;                // [N,H,W,8] grad w.r.t. y4 (pre-tanh), channels 4:8 zero
+  float l1_weight;
+};
+
+struct GanLossArgs {
+  const float* logits;      // [3][M] D layer_5 output (bias included): real1 | real2 | fake
+  void* dl_d;               // [3][M][8] seed of the D loss w.r.t. logits (channel 0)
+  void* dl_g;               // [M][8]    seed of the G loss w.r.t. the fake logits
+  float* predict;           // [2][M] predict_real, predict_fake
+  float* losses;            // [0] Discrim_loss [1] Gen_loss_GAN
+  int M;
+  float gan_weight;
+};
+
+struct PerceptualArgs {
+  const void* f3;           // [2N*hw][C] conv3_3 output (post-relu): real half | fake half
+  void* df3;                // [N*hw][C] grad w.r.t. the pre-relu conv3_3 output of the fake half
+  double* partial;          // [nblocks]
+  size_t half;              // N*hw*C
+  float l1_weight;
+};
+
+struct LossFinalArgs {
+  const double* comp_partial; int n_comp;     // composite partials [n][2]
+  const double* perc_partial; int n_perc;
+  double n_out;             // N*H*W*3
+  double n_feat;            // N*hw*C
+  float* losses;            // [0] D [1] G_GAN -> writes [2] G_L1 [3] G_loss [4] perceptual
+  float l1_weight, gan_weight;
+};
+
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v;
+  size_t n;
+  float lr_t, beta1, beta2, eps;
+};
+
+}  // namespace vp

@@ -1,0 +1,154 @@
+"""Host-side driver of the PixReferNet step executor (libvp_hip.so: vp_pixrefer_*).
+
+torch is used for device memory, the current HIP stream and (optionally) torch.distributed; all
+arithmetic happens in the HIP kernels behind the C ABI.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import VP_BF16, VP_F32, PixReferDesc
+
+
+def _ptr(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def manifest(desc, which):
+  """[(tf_variable_name, offset, shape)] of arena `which` (0 generator, 1 discriminator, 2 vgg_16)."""
+  L = _lib.lib()
+  out = []
+  name = ctypes.create_string_buffer(256)
+  off = ctypes.c_size_t()
+  nd = ctypes.c_int()
+  shp = (ctypes.c_int64 * 4)()
+  i = 0
+  while L.vp_pixrefer_param_info(ctypes.byref(desc), which, i, name, 256, ctypes.byref(off), ctypes.byref(nd), shp) == 0:
+    out.append((name.value.decode(), int(off.value), tuple(int(shp[k]) for k in range(nd.value))))
+    i += 1
+  return out
+
+
+class PixReferEngine:
+  """One replica of the PixReferNet graph (pixrefer.py:356-438) on the current device."""
+
+  def __init__(self, batch, height, ngf=64, ndf=64, dtype="bf16", training=True, l1_weight=500.0, gan_weight=1.0,
+               device=None):
+    if not torch.cuda.is_available():
+      raise RuntimeError("PixReferEngine needs an MI355X (no CPU fallback)")
+    self.L = _lib.lib()
+    self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    self.desc = PixReferDesc(batch, height, ngf, ndf, VP_BF16 if dtype == "bf16" else VP_F32, 1 if training else 0,
+                             l1_weight, gan_weight)
+    self.training = training
+    self.compute_dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+    d = ctypes.byref(self.desc)
+    self.manifests = [manifest(self.desc, w) for w in range(3)]
+    counts = [self.L.vp_pixrefer_param_count(d, w) for w in range(3)]
+    z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
+    self.params_g = z(counts[0])
+    self.params_d = z(counts[1]) if training else None
+    self.params_vgg = z(counts[2]) if training else None
+    self.grads_g = z(counts[0]) if training else None
+    self.grads_d = z(counts[1]) if training else None
+    if training:
+      self.adam = {"g": [z(counts[0]), z(counts[0])], "d": [z(counts[1]), z(counts[1])]}
+    self.t_g = self.t_d = 0
+    ws = self.L.vp_pixrefer_workspace_bytes(d)
+    if ws == 0:
+      raise ValueError("invalid PixReferNet descriptor: %s" % self.L.vp_last_error().decode())
+    self.workspace = torch.zeros(ws, dtype=torch.uint8, device=self.device)
+    h = ctypes.c_void_p()
+    _lib.check(self.L.vp_pixrefer_create(d, _ptr(self.workspace), ws, _ptr(self.params_g), _ptr(self.params_d),
+                                         _ptr(self.params_vgg), _ptr(self.grads_g), _ptr(self.grads_d), _stream(),
+                                         ctypes.byref(h)), "vp_pixrefer_create")
+    self.h = h
+    self._keep = None
+
+  def __del__(self):
+    try:
+      if getattr(self, "h", None):
+        self.L.vp_pixrefer_destroy(self.h)
+        self.h = None
+    except Exception:
+      pass
+
+  # ---- parameters -------------------------------------------------------------------------------
+  def arena(self, which):
+    return [self.params_g, self.params_d, self.params_vgg][which]
+
+  def load_params(self, params):
+    """params: {tf_variable_name: numpy array}; missing names keep their current value."""
+    for which in range(3):
+      a = self.arena(which)
+      if a is None:
+        continue
+      host = a.cpu().numpy()
+      for name, off, shape in self.manifests[which]:
+        if name in params:
+          v = np.asarray(params[name], dtype=np.float32)
+          assert v.shape == shape, (name, v.shape, shape)
+          host[off:off + v.size] = v.reshape(-1)
+      a.copy_(torch.from_numpy(host))
+    self.params_changed()
+
+  def get_params(self, which, src=None):
+    a = (self.arena(which) if src is None else src).cpu().numpy()
+    return {name: a[off:off + int(np.prod(shape))].reshape(shape).copy() for name, off, shape in self.manifests[which]}
+
+  def params_changed(self):
+    _lib.check(self.L.vp_pixrefer_params_changed(self.h))
+
+  # ---- execution --------------------------------------------------------------------------------
+  def forward(self, inputs, fg_inputs, targets, masks=None):
+    """float32 NHWC device tensors in [0,1] (generator.py:1011-1019 layout)."""
+    N, H = self.desc.batch, self.desc.height
+    assert inputs.shape == (N, H, H, 6) and targets.shape == (N, H, H, 3)
+    if fg_inputs.shape[-1] == 3:   # infer_bfmvid.py feeds a 3-channel foreground reference
+      fg_inputs = torch.cat([fg_inputs, torch.zeros_like(fg_inputs)], dim=-1)
+    ts = [t.contiguous() for t in (inputs, fg_inputs, targets)]
+    m = masks.contiguous() if masks is not None else None
+    for t in ts + ([m] if m is not None else []):
+      assert t.dtype == torch.float32 and t.is_cuda
+    self._keep = (ts, m)   # the backward reads targets/masks again
+    _lib.check(self.L.vp_pixrefer_forward(self.h, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(m), _stream()),
+               "vp_pixrefer_forward")
+
+  def backward(self):
+    _lib.check(self.L.vp_pixrefer_backward(self.h, _stream()), "vp_pixrefer_backward")
+
+  def adam_step(self, lr, beta1=0.5, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer on discriminator* then generator* (pixrefer.py:396-407)."""
+    self.t_d += 1
+    self.t_g += 1
+    for key, p, g, t in (("d", self.params_d, self.grads_d, self.t_d), ("g", self.params_g, self.grads_g, self.t_g)):
+      m, v = self.adam[key]
+      _lib.check(self.L.vp_adam_tf(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), t, lr, beta1, beta2, eps, _stream()),
+                 "vp_adam_tf")
+    self.params_changed()
+
+  # ---- named device buffers -----------------------------------------------------------------------
+  def tensor(self, name):
+    """View of a named buffer inside the workspace (no copy)."""
+    p = ctypes.c_void_p()
+    shp = (ctypes.c_int64 * 4)()
+    dt = ctypes.c_int()
+    _lib.check(self.L.vp_pixrefer_tensor(self.h, name.encode(), ctypes.byref(p), shp, ctypes.byref(dt)),
+               "vp_pixrefer_tensor(%s)" % name)
+    shape = tuple(int(s) for s in shp)
+    tdt = torch.bfloat16 if dt.value == VP_BF16 else torch.float32
+    nbytes = int(np.prod(shape)) * (2 if dt.value == VP_BF16 else 4)
+    off = p.value - self.workspace.data_ptr()
+    assert 0 <= off and off + nbytes <= self.workspace.numel(), name
+    return self.workspace[off:off + nbytes].view(tdt).view(shape)
+
+  def losses(self):
+    l = self.tensor("losses").view(-1).float().cpu().numpy()
+    return {"Discrim_loss": float(l[0]), "Gen_loss_GAN": float(l[1]), "Gen_loss_L1": float(l[2]),
+            "Gen_loss": float(l[3]), "Perceptual_loss": float(l[4])}
