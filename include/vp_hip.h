@@ -80,6 +80,10 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
 /* Both gradient sets from the forward just run: d(Discrim_loss)/d(discriminator*) -> grads_d,
  * d(Gen_loss)/d(generator*) -> grads_g (pixrefer.py:396-407; pre-update weights for both). */
 int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream);
+/* The two halves of vp_pixrefer_backward, so a data-parallel host can start the all-reduce of the
+ * discriminator gradients while the generator backward runs. */
+int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream);
+int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream);
 
 /* Named device buffers ("nodes" of pixrefer.py:356-438 and every intermediate):
  *   "Outputs_raw" [N,H,H,3] f32 in [-1,1], "Outputs_FG" [N,H,H,3] f32, "gen_out4" [N,H,H,4] f32,
@@ -87,6 +91,12 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream);
  *   Gen_loss, Perceptual_loss}, "g/<scope>" raw conv outputs, "g/<scope>:dy" their gradients, ...
  * dtype receives the vp_dtype of the buffer. */
 int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t shape[4], int* dtype);
+
+/* Per-launch timing of the conv kernels with HIP events on the launch stream (bench.py roofline).
+ * vp_profile_collect: JSON array [{name, calls, ms, flops, bytes}] since the last collect; call after
+ * synchronising the stream; returns the bytes needed (including the terminator). */
+int vp_profile_enable(int on);
+size_t vp_profile_collect(char* json, size_t cap);
 
 /* theta -= lr_t * m / (sqrt(v) + eps) with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) (TF formulation) */
 int vp_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, int step_t,

@@ -376,7 +376,8 @@ def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64,
   d_alphas = l1_weight * (-np.sign(masks - alphas)) / alphas.size
   dout4 = composite_bwd(out4, tgt, d_outputs, d_alphas, d_outputs_fg)
   ggr, g_dacts = generator_bwd(p, gcache, dout4, ngf)
-  nodes.update(Discrim_grads=dgr, Gen_grads=ggr, d_gen_out4=dout4, d_outputs_fg=d_outputs_fg, g_dacts=g_dacts)
+  nodes.update(Discrim_grads=dgr, Gen_grads=ggr, d_gen_out4=dout4, d_outputs_fg=d_outputs_fg, g_dacts=g_dacts,
+               d_dinput=d_dinput, d_vin=d_vin)
   return nodes
 
 

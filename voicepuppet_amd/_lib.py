@@ -36,6 +36,10 @@ _SIGNATURES = {
     "vp_pixrefer_params_changed": (ctypes.c_int, [_P]),
     "vp_pixrefer_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "vp_pixrefer_backward": (ctypes.c_int, [_P, _P]),
+    "vp_pixrefer_backward_d": (ctypes.c_int, [_P, _P]),
+    "vp_pixrefer_backward_g": (ctypes.c_int, [_P, _P]),
+    "vp_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "vp_profile_collect": (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
     "vp_pixrefer_tensor": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_int)]),
     "vp_adam_tf": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_float,

@@ -28,6 +28,7 @@ struct IgemmArgs {
   PixSrc x;
   int N, Hin, Win;
   int Cin, log2Cin;         // total channels of x (power of two)
+  int cin_real;             // channels that carry data (accounting only)
   int Hg, Wg;               // GEMM pixel grid per class: pixel = (n, q, r)
   int sh, sw;               // ih = q*sh + dh[tap], iw = r*sw + dw[tap]
   int ntaps, nclass;

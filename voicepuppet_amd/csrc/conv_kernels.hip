@@ -11,6 +11,12 @@
 // slot(row0+i) of plane g with one ds_read_b128: the 16 lanes of every b128 service group hit 16
 // distinct 16-byte slots of a 256-byte bank row, i.e. conflict-free reads; writers use 8-lane
 // contiguous (row loader) or XOR-swizzled (transposing loader) slots so writes are conflict-free too.
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
 #include "conv_args.h"
 #include "vp_common.h"
 
@@ -436,6 +442,78 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// optional per-launch timing (HIP events on the launch stream) for bench.py's roofline line
+// ------------------------------------------------------------------------------------------------
+void igemm_tile(int cfg, int* bc, int* bp);
+void wgrad_tile(int cfg, int* bm, int* bn);
+
+struct ProfRec { hipEvent_t e0, e1; std::string name; double flops, bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_ev_pool;
+
+static hipEvent_t prof_event() {
+  hipEvent_t e;
+  if (!g_ev_pool.empty()) { e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+  hipEventCreate(&e);
+  return e;
+}
+
+void profile_enable(int on) { g_prof_on = on != 0; }
+
+struct ProfScope {
+  bool on;
+  ProfRec r;
+  hipStream_t st;
+  ProfScope(const char* kind, int is_bf16, int bc, int bp, double flops, double bytes, hipStream_t s) : on(g_prof_on), st(s) {
+    if (!on) return;
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%s_%s_%dx%d", kind, is_bf16 ? "bf16" : "f32", bc, bp);
+    r.name = buf; r.flops = flops; r.bytes = bytes;
+    r.e0 = prof_event(); r.e1 = prof_event();
+    hipEventRecord(r.e0, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(r.e1, st);
+    g_prof.push_back(r);
+  }
+};
+
+// JSON array of {name, calls, ms, flops, bytes}; call after the stream has been synchronised
+size_t profile_collect(char* out, size_t cap) {
+  struct Agg { std::string name; int calls; double ms, flops, bytes; };
+  static std::string cache = "[]";
+  if (g_prof.empty()) {   // second call of the (size query, copy) pair
+    if (out && cap > 0) { strncpy(out, cache.c_str(), cap - 1); out[cap - 1] = 0; }
+    return cache.size() + 1;
+  }
+  std::vector<Agg> agg;
+  for (ProfRec& r : g_prof) {
+    float ms = 0.f;
+    hipEventSynchronize(r.e1);
+    hipEventElapsedTime(&ms, r.e0, r.e1);
+    g_ev_pool.push_back(r.e0); g_ev_pool.push_back(r.e1);
+    Agg* a = nullptr;
+    for (Agg& x : agg) if (x.name == r.name) a = &x;
+    if (!a) { agg.push_back({r.name, 0, 0, 0, 0}); a = &agg.back(); }
+    a->calls++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes;
+  }
+  g_prof.clear();
+  std::string js = "[";
+  for (size_t i = 0; i < agg.size(); ++i) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s{\"name\":\"%s\",\"calls\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}", i ? "," : "",
+             agg[i].name.c_str(), agg[i].calls, agg[i].ms, agg[i].flops, agg[i].bytes);
+    js += buf;
+  }
+  js += "]";
+  cache = js;
+  if (out && cap > 0) { strncpy(out, js.c_str(), cap - 1); out[cap - 1] = 0; }
+  return js.size() + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
 template <typename T, int WC, int WP, int TC, int TP>
@@ -450,6 +528,14 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
 
 template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int cfg, hipStream_t st) {
   hipError_t e;
+  int pbc, pbp;
+  igemm_tile(cfg, &pbc, &pbp);
+  // algorithmic cost: 2*MACs over real channels; bytes = X + W + Y each touched once
+  const double Pn = (double)a.N * a.Hg * a.Wg * a.nclass;
+  const double kreal = (double)a.ntaps * a.cin_real;
+  const double es = sizeof(T);
+  ProfScope prof("igemm", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
+                 es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
   switch (cfg) {
     case 0: e = launch_igemm_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 ch x 128 px
     case 1: e = launch_igemm_cfg<T, 1, 4, 4, 2>(a, st); break;   //  64 ch x 128 px
@@ -490,6 +576,11 @@ static hipError_t launch_wgrad_cfg(const WgradArgs& a, hipStream_t st) {
 
 template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int cfg, hipStream_t st) {
   hipError_t e;
+  int pbm, pbn;
+  wgrad_tile(cfg, &pbm, &pbn);
+  const double Pn = (double)a.N * a.Hb * a.Wb;
+  ProfScope prof("wgrad", sizeof(T) == 2, pbm, pbn, 2.0 * Pn * a.ntaps * a.Greal * a.Dreal,
+                 sizeof(T) * ((double)a.N * a.Hgin * a.Wgin * a.Greal + Pn * a.Dreal) + 4.0 * a.ntaps * a.Greal * a.Dreal, st);
   switch (cfg) {
     case 0: e = launch_wgrad_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 rows x 128 cols
     case 1: e = launch_wgrad_cfg<T, 2, 2, 4, 2>(a, st); break;   // 128 rows x  64 cols

@@ -89,7 +89,7 @@ inline IgemmPlan plan_fwd(const ConvGeomX& g, size_t w_off, int is_bf16) {
   IgemmPlan p;
   memset(&p, 0, sizeof(p));
   IgemmArgs& a = p.a;
-  a.N = g.N; a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin;
+  a.N = g.N; a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.cin_real = g.Cin_real;
   a.Cout = g.Cout; a.ldY = g.Cout; a.Hof = g.Hout; a.Wof = g.Wout;
   a.ref_group_n = 1 << 30;
   PackDesc& d = p.pack;
@@ -128,7 +128,7 @@ inline IgemmPlan plan_bwd_data(const ConvGeomX& g, size_t w_off, int row0, int r
   IgemmPlan p;
   memset(&p, 0, sizeof(p));
   IgemmArgs& a = p.a;
-  a.N = g.N; a.Hin = g.Hout; a.Win = g.Wout; a.Cin = g.CoutT;
+  a.N = g.N; a.Hin = g.Hout; a.Win = g.Wout; a.Cin = g.CoutT; a.cin_real = g.Cout;
   a.Cout = rows; a.ldY = ldX; a.Hof = g.Hin; a.Wof = g.Win;
   a.ref_group_n = 1 << 30;
   PackDesc& d = p.pack;

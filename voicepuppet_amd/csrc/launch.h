@@ -12,6 +12,9 @@ void igemm_tile(int cfg, int* bc, int* bp);
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
 void wgrad_tile(int cfg, int* bm, int* bn);
 
+void profile_enable(int on);
+size_t profile_collect(char* out, size_t cap);
+
 hipError_t launch_pack_weights(const PackDesc* d_descs, int ndesc, const float* master, void* packed, int is_bf16, hipStream_t st);
 hipError_t launch_pack_weights_one(const PackDesc& d, const float* master, void* packed, int is_bf16, hipStream_t st);
 int bn_nchunk(int Pg, int C, int G, int is_bf16);

@@ -629,12 +629,17 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
 }
 
 int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
-  if (!h || !h->d.training) { set_err("vp_pixrefer_backward: needs a training plan"); return VP_ERR_STATE; }
+  int rc = vp_pixrefer_backward_d(h, stream);
+  if (rc) return rc;
+  return vp_pixrefer_backward_g(h, stream);
+}
+
+int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream) {
+  if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d: needs a training plan"); return VP_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
-  const vp_pixrefer_desc& d = h->d;
-  const int N = d.batch, H = d.height, bf = h->bf16, es = h->es;
+  const int N = h->d.batch;
   int rc;
-  Net &G = h->G, &D = h->D, &V = h->V;
+  Net& D = h->D;
 
   // ---- Discrim_loss -> discriminator* (pixrefer.py:396-400), all three applications at once ----
   for (Tens& t : D.t) t.dz_written = false;
@@ -649,6 +654,16 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
     if (rc) return rc;
   }
 
+  return VP_OK;
+}
+
+int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream) {
+  if (!h || !h->d.training) { set_err("vp_pixrefer_backward_g: needs a training plan"); return VP_ERR_STATE; }
+  hipStream_t st = (hipStream_t)stream;
+  const vp_pixrefer_desc& d = h->d;
+  const int N = d.batch, H = d.height, bf = h->bf16, es = h->es;
+  int rc;
+  Net &G = h->G, &D = h->D, &V = h->V;
   // ---- Gen_loss -> generator* (pixrefer.py:402-407) ----
   // (a) GAN term through the fake application of the discriminator (dX only, pre-update weights)
   for (Tens& t : D.t) t.dz_written = false;
@@ -705,6 +720,9 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
   }
   return VP_OK;
 }
+
+int vp_profile_enable(int on) { profile_enable(on); return VP_OK; }
+size_t vp_profile_collect(char* json, size_t cap) { return profile_collect(json, cap); }
 
 int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t shape[4], int* dtype) {
   if (!h || !name || !ptr) return VP_ERR_ARG;

@@ -123,6 +123,29 @@ class PixReferEngine:
   def backward(self):
     _lib.check(self.L.vp_pixrefer_backward(self.h, _stream()), "vp_pixrefer_backward")
 
+  def backward_d(self):
+    _lib.check(self.L.vp_pixrefer_backward_d(self.h, _stream()), "vp_pixrefer_backward_d")
+
+  def backward_g(self):
+    _lib.check(self.L.vp_pixrefer_backward_g(self.h, _stream()), "vp_pixrefer_backward_g")
+
+  def train_step(self, inputs, fg_inputs, targets, masks, lr, beta1=0.5, group=None):
+    """One iteration of train_pixrefer.py:136-143 on this replica: forward, both backward passes,
+    (data parallel: RCCL all-reduce-mean of the two gradient arenas, the discriminator's overlapped
+    with the generator backward), Adam(D) then Adam(G)."""
+    import torch.distributed as dist
+    self.forward(inputs, fg_inputs, targets, masks)
+    self.backward_d()
+    wd = None
+    if group is not None and dist.get_world_size(group) > 1:
+      wd = dist.all_reduce(self.grads_d, op=dist.ReduceOp.AVG, group=group, async_op=True)
+    self.backward_g()
+    if wd is not None:
+      wg = dist.all_reduce(self.grads_g, op=dist.ReduceOp.AVG, group=group, async_op=True)
+      wd.wait()
+      wg.wait()
+    self.adam_step(lr, beta1)
+
   def adam_step(self, lr, beta1=0.5, beta2=0.999, eps=1e-8):
     """tf.train.AdamOptimizer on discriminator* then generator* (pixrefer.py:396-407)."""
     self.t_d += 1
@@ -147,6 +170,16 @@ class PixReferEngine:
     off = p.value - self.workspace.data_ptr()
     assert 0 <= off and off + nbytes <= self.workspace.numel(), name
     return self.workspace[off:off + nbytes].view(tdt).view(shape)
+
+  def profile(self, on):
+    self.L.vp_profile_enable(1 if on else 0)
+
+  def profile_collect(self):
+    import json
+    n = self.L.vp_profile_collect(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 16)
+    self.L.vp_profile_collect(buf, len(buf))
+    return json.loads(buf.value.decode())
 
   def losses(self):
     l = self.tensor("losses").view(-1).float().cpu().numpy()
