@@ -50,6 +50,7 @@ struct IgemmArgs {
   int ref_act, ref_group_n, accumulate;
   int splitk;
   float* partial;           // [nclass][splitk][P][CoutPad] when splitk > 1
+  const void* zeros;        // >= 16 bytes of zeros (padding source of the LDS-DMA loader); null: register loader
 };
 
 // dW[tap][g][d] = sum_{pixels} G~[pixel (+) tap, g] * D~[pixel, d]

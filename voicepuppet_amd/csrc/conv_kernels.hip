@@ -280,6 +280,144 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// igemm_dma_kernel: same GEMM, operands that need no prologue (materialised activations, gradients,
+// packed weights) go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no
+// ds_write pass).  One wave instruction moves a 16-row block x 4 k-pieces = 64 consecutive 16-byte
+// slots, so the LDS image is [row block][k-piece g][16 rows]; reads stay conflict-free (the 16 lanes of
+// a ds_read_b128 group still touch 16 distinct slots of one 256-byte bank row).  Padding / ragged
+// pixels read a 16-byte zero page instead (LDS-DMA cannot zero-fill).  One barrier per K chunk.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TC, int TP, int BC, int BP>
+__device__ __forceinline__ void mma_chunk_rb(const uint4* __restrict__ ldsA, const uint4* __restrict__ ldsB,
+                                             int blkA0, int blkB0, int lane, f32x4 (&acc)[TC][TP]) {
+  const int i = lane & 15, g = lane >> 4;
+  uint4 fa[TC], fb[TP];
+#pragma unroll
+  for (int t = 0; t < TC; ++t) fa[t] = ldsA[((blkA0 + t) * 4 + g) * 16 + i];
+#pragma unroll
+  for (int t = 0; t < TP; ++t) fb[t] = ldsB[((blkB0 + t) * 4 + g) * 16 + i];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], fb[tp], acc[tc][tp]);
+}
+
+__device__ __forceinline__ void dma16(const void* src, uint4* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+template <typename T, int WC, int WP, int TC, int TP>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
+  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  constexpr int NBA = BC / 16, NBB = BP / 16;          // 16-row blocks per operand tile
+  constexpr int JA = (NBA + 3) / 4, JB = (NBB + 3) / 4; // DMA instructions per wave per chunk
+  constexpr int BUF = 4 * (BC + BP);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  int* ltap = reinterpret_cast<int*>(lds + 2 * BUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cls = blockIdx.z / a.splitk, split = blockIdx.z - cls * a.splitk;
+  const int P = a.N * a.Hg * a.Wg;
+  const int p_base = blockIdx.x * BP, c_base = blockIdx.y * BC;
+  const int r = lane & 15, g = lane >> 4;
+
+  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
+
+  // fixed per-thread rows
+  const T* wrow[JA];
+#pragma unroll
+  for (int j = 0; j < JA; ++j)
+    wrow[j] = reinterpret_cast<const T*>(a.Wp) + ((size_t)cls * a.wp_rows + c_base + (wave + 4 * j) * 16 + r) * a.Kpad + g * E;
+  int pn[JB], pbh[JB], pbw[JB];
+  bool pok[JB];
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int pidx = p_base + (wave + 4 * j) * 16 + r;
+    pok[j] = (wave + 4 * j < NBB) && (pidx < P);
+    const int hw = a.Hg * a.Wg;
+    const int pc = pok[j] ? pidx : 0;
+    const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
+    pn[j] = n * a.Hin; pbh[j] = q * a.sh; pbw[j] = (rem - q * a.Wg) * a.sw;
+  }
+  const T* x0 = reinterpret_cast<const T*>(a.x.ptr[0]);
+  const T* x1 = reinterpret_cast<const T*>(a.x.ptr[1]);
+  const int C0 = a.x.C[0], C1 = a.x.C[1];
+
+  const int nchunk = a.Kpad / KC;
+  const int per = (nchunk + a.splitk - 1) / a.splitk;
+  const int kc0 = split * per, kc1 = min(nchunk, kc0 + per);
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int kc, int buf) {
+    uint4* la = lds + buf * BUF;
+    uint4* lb = la + 4 * BC;
+#pragma unroll
+    for (int j = 0; j < JA; ++j)
+      if (NBA % 4 == 0 || wave + 4 * j < NBA) dma16(wrow[j] + (size_t)kc * KC, la + (wave + 4 * j) * 64);
+    const int k0 = kc * KC + g * E;
+    const int tap = k0 >> a.log2Cin;
+    const int ci = k0 & (a.Cin - 1);
+    const bool tok = tap < a.ntaps;
+    const int tv = ltap[tok ? tap : 0];
+    const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
+    const bool s1 = ci >= C0;
+    const T* xb = s1 ? x1 : x0;
+    const int Cs = s1 ? C1 : C0;
+    const int cl = s1 ? ci - C0 : ci;
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      if (NBB % 4 == 0 || wave + 4 * j < NBB) {
+        const int ih = pbh[j] + dh, iw = pbw[j] + dw;
+        const bool ok = pok[j] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+        const void* src = ok ? (const void*)(xb + ((size_t)(pn[j] + ih) * a.Win + iw) * Cs + cl) : a.zeros;
+        dma16(src, lb + (wave + 4 * j) * 64);
+      }
+    }
+  };
+
+  const int wc = wave / WP, wpi = wave - wc * WP;
+  const int blkA0 = wc * TC, blkB0 = wpi * TP;
+
+  __syncthreads();   // tap table visible
+  if (kc0 < kc1) {
+    issue(kc0, 0);
+    for (int kc = kc0; kc < kc1; ++kc) {
+      const int buf = (kc - kc0) & 1;
+      __syncthreads();   // waits for this wave's DMA (vmcnt) and for every wave's reads of the other buffer
+      if (kc + 1 < kc1) issue(kc + 1, buf ^ 1);
+      const uint4* la = lds + buf * BUF;
+      mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
+    }
+  }
+
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    const int pidx = p_base + (blkB0 + tp) * 16 + (lane & 15);
+    if (pidx >= P) continue;
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc) {
+      const int c0 = c_base + (blkA0 + tc) * 16 + 4 * (lane >> 4);
+      float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
+      if (a.splitk > 1) {
+        float* pp = a.partial + (((size_t)(cls * a.splitk + split) * P + pidx) * a.CoutPad + c0);
+        *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        igemm_epilogue<T>(a, cls, pidx, c0, v);
+      }
+    }
+  }
+}
+
 // sums the split-K slabs in a fixed order (deterministic) and applies the igemm epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArgs a) {
@@ -328,12 +466,13 @@ template <> struct Transposer<bf16> {
   }
 };
 
-template <typename T, int WC, int WP, int TC, int TP>
+template <typename T, int WC, int WP, int TC, int TP, int KCH>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int E = Elem<T>::E, KC = 4 * E;           // KC pixels per 64-byte chunk; KCH chunks per iteration
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
-  constexpr int BUF = 4 * (BC + BP);
-  constexpr int TA = 4 * BC / E, TB = 4 * BP / E;     // loader tasks per chunk
+  constexpr int CH = 4 * (BC + BP);                   // slots of one chunk (A planes then B planes)
+  constexpr int BUF = KCH * CH;
+  constexpr int TA = KCH * 4 * BC / E, TB = KCH * 4 * BP / E;   // loader tasks per iteration
   static_assert(TA + TB <= 256, "one task per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
@@ -341,16 +480,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m_base = blockIdx.x * BC, d_base = blockIdx.y * BP, split = blockIdx.z;
   const int P = a.N * a.Hb * a.Wb;
-  const int nchunk = (P + KC - 1) / KC;
-  const int per = (nchunk + a.splitk - 1) / a.splitk;
-  const int kc0 = split * per, kc1 = min(nchunk, kc0 + per);
+  const int niter = (P + KC * KCH - 1) / (KC * KCH);
+  const int per = (niter + a.splitk - 1) / a.splitk;
+  const int it0 = split * per, it1 = min(niter, it0 + per);
 
-  // loader task of this thread
+  // loader task of this thread: E consecutive pixels x E consecutive channels
   const bool isA = tid < TA;
   const bool isB = !isA && tid < TA + TB;
   const int tt = isA ? tid : tid - TA;
   const int ncg = (isA ? BC : BP) / E;       // channel groups
-  const int cg = tt % ncg, kq = tt / ncg;    // channel group, k-quarter (plane)
+  const int cg = tt % ncg, kq = tt / ncg;    // channel group, pixel group (kq / 4 = chunk, kq % 4 = plane)
   int tdh = 0, tdw = 0, gch = 0;
   bool rowok = false;
   if (isA) {
@@ -358,7 +497,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int tap = m >> a.log2Gc;
     gch = m & (a.Gc - 1);
     rowok = tap < a.ntaps;
-    if (rowok) { tdh = a.taps.dh[tap]; tdw = a.taps.dw[tap]; }
+    if (rowok) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) if (t == tap) { tdh = a.taps.dh[t]; tdw = a.taps.dw[t]; }
+    }
   } else if (isB) {
     gch = d_base + cg * E;
     rowok = gch < a.Dc;
@@ -371,9 +513,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   uint4 rin[E], rout[E];
-  auto stage_load = [&](int kc) {
+  auto stage_load = [&](int it) {
     if (!(isA || isB)) return;
-    int pidx = kc * KC + kq * E;
+    int pidx = it * (KC * KCH) + kq * E;
     const int hw = a.Hb * a.Wb;
     int n = pidx / hw;
     int rem = pidx - n * hw;
@@ -390,7 +532,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   auto stage_store = [&](int buf) {
     if (!(isA || isB)) return;
     Transposer<T>::run(rin, rout);
-    uint4* base = lds + buf * BUF + (isA ? 0 : 4 * BC) + kq * (isA ? BC : BP);
+    uint4* base = lds + buf * BUF + (kq >> 2) * CH + (isA ? 0 : 4 * BC) + (kq & 3) * (isA ? BC : BP);
 #pragma unroll
     for (int e = 0; e < E; ++e) base[lds_slot<1, E>(cg * E + e)] = rout[e];
   };
@@ -398,16 +540,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int wc = wave / WP, wpi = wave - wc * WP;
   const int rowA0 = wc * TC * 16, rowB0 = wpi * TP * 16;
 
-  if (kc0 < kc1) {
-    stage_load(kc0);
+  if (it0 < it1) {
+    stage_load(it0);
     stage_store(0);
     __syncthreads();
-    for (int kc = kc0; kc < kc1; ++kc) {
-      const int buf = (kc - kc0) & 1;
-      const bool more = kc + 1 < kc1;
-      if (more) stage_load(kc + 1);
-      const uint4* la = lds + buf * BUF;
-      mma_chunk<T, TC, TP, BC, BP, 1>(la, la + 4 * BC, rowA0, rowB0, lane, acc);
+    for (int it = it0; it < it1; ++it) {
+      const int buf = (it - it0) & 1;
+      const bool more = it + 1 < it1;
+      if (more) stage_load(it + 1);
+#pragma unroll
+      for (int c = 0; c < KCH; ++c) {
+        const uint4* la = lds + buf * BUF + c * CH;
+        mma_chunk<T, TC, TP, BC, BP, 1>(la, la + 4 * BC, rowA0, rowB0, lane, acc);
+      }
       if (more) stage_store(buf ^ 1);
       __syncthreads();
     }
@@ -522,7 +667,9 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   const int P = a.N * a.Hg * a.Wg;
   dim3 grid((P + BP - 1) / BP, a.CoutPad / BC, a.nclass * a.splitk);
   const size_t smem = 2 * 4 * (BC + BP) * 16 + 64;
-  hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
+  const bool plain = a.zeros && !a.x.aff_a[0] && !a.x.aff_a[1] && a.x.act == ACT_NONE;
+  if (plain) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
   return hipGetLastError();
 }
 
@@ -569,8 +716,10 @@ template <typename T, int WC, int WP, int TC, int TP>
 static hipError_t launch_wgrad_cfg(const WgradArgs& a, hipStream_t st) {
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
   dim3 grid(a.Mpad / BC, a.Dpad / BP, a.splitk);
-  const size_t smem = 2 * 4 * (BC + BP) * 16;
-  hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
+  // bf16 tasks are 8x8 blocks: two chunks per iteration keep all 256 threads loading
+  constexpr int KCH = (sizeof(T) == 2) ? 2 : 1;
+  const size_t smem = 2 * KCH * 4 * (BC + BP) * 16;
+  hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP, KCH>), grid, dim3(256), smem, st, a);
   return hipGetLastError();
 }
 

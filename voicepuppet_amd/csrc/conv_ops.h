@@ -203,11 +203,12 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16) {
   a.Mpad = round_up(a.ntaps * a.Gc, bm);
   a.Dpad = round_up(a.Dc, bn);
   const int P = a.N * a.Hb * a.Wb;
-  const int nchunk = (P + kc_elems(is_bf16) - 1) / kc_elems(is_bf16);
+  const int kiter = kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of wgrad_kernel
+  const int nchunk = (P + kiter - 1) / kiter;
   const int tiles = (a.Mpad / bm) * (a.Dpad / bn);
   int s = (1024 + tiles - 1) / tiles;
   if (s > nchunk / 4) s = nchunk / 4;
-  if (s > 64) s = 64;
+  if (s > 512) s = 512;
   if (s < 1) s = 1;
   a.splitk = s;
   p.partial_bytes = (size_t)s * a.Mpad * a.Dpad * sizeof(float);

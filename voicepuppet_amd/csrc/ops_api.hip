@@ -26,6 +26,13 @@ ConvGeomX geom_of(const vp_conv_desc* d) {
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// 256 zero bytes behind the op's workspace use (padding source of the LDS-DMA loader)
+const void* zero_page(char* ws, size_t used, hipStream_t st) {
+  char* z = ws + align256(used);
+  (void)hipMemsetAsync(z, 0, 256, st);
+  return z;
+}
+
 }  // namespace
 
 extern "C" {
@@ -46,7 +53,7 @@ size_t vp_conv_workspace_bytes(const vp_conv_desc* d) {
     WgradPlan w = plan_wgrad(g, bf);
     if (w.partial_bytes > best) best = w.partial_bytes;
   }
-  return best + 512;
+  return best + 1024;
 }
 
 int vp_conv_fwd(const vp_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
@@ -63,6 +70,7 @@ int vp_conv_fwd(const vp_conv_desc* d, const void* x, const float* in_scale, con
   a.Wp = ws;
   a.partial = (float*)(ws + align256(p.pack_elems * es));
   a.Y = y; a.ldY = d->cout; a.bias = bias; a.out_act = d->out_act;
+  a.zeros = zero_page(ws, align256(p.pack_elems * es) + p.partial_bytes, st);
   VP_HIP_CHECK(launch_igemm(a, bf, p.cfg, st));
   return VP_OK;
 }
@@ -81,6 +89,7 @@ int vp_conv_bwd_data(const vp_conv_desc* d, const void* dy, const float* w, void
   a.Wp = ws;
   a.partial = (float*)(ws + align256(p.pack_elems * es));
   a.Y = dx;
+  a.zeros = zero_page(ws, align256(p.pack_elems * es) + p.partial_bytes, st);
   VP_HIP_CHECK(launch_igemm(a, bf, p.cfg, st));
   return VP_OK;
 }

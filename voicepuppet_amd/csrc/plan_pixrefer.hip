@@ -54,6 +54,8 @@ struct Tens {
   bool has_bn = false;
   bool is_input = false;
   bool dz_written = false;
+  void* xa[3] = {nullptr, nullptr, nullptr};   // materialised act(bn(y)) per vp::Act (lrelu, relu) for the consumers
+  bool need_act[3] = {false, false, false};
   BnBuf bn{};
   size_t elems() const { return (size_t)N * H * W * C; }
 };
@@ -105,6 +107,7 @@ struct vp_pixrefer {
   void *vpool1, *vpool2, *d_vpool1, *d_vpool2;
   double *comp_partial, *perc_partial, *bn_partial;
   char* scratch;
+  void* zeros;
   size_t scratch_bytes;
   int n_comp, n_perc;
   bool params_dirty;
@@ -143,7 +146,10 @@ static int add_layer(Net& n, const std::string& prefix, const std::string& scope
   L.scope = scope;
   L.nsrc = 0;
   int cin = 0;
-  for (int s : srcs) { L.src[L.nsrc++] = s; cin += n.t[s].C; }
+  for (int s : srcs) {
+    L.src[L.nsrc++] = s; cin += n.t[s].C;
+    if (in_act != ACT_NONE) n.t[s].need_act[in_act] = true;
+  }
   const Tens& t0 = n.t[L.src[0]];
   L.g = make_geom(kind, ks, stride, pad, n.batch, t0.H, t0.W, cin, cin_real, cout);
   L.in_act = in_act; L.out_act = out_act; L.has_bn = has_bn;
@@ -272,6 +278,7 @@ static void carve_net(Net& n, Arena& ar, int es, bool training) {
       continue;
     }
     if (!t.is_input) t.y = ar.alloc(t.elems() * es);
+    for (int k = 1; k < 3; ++k) if (t.need_act[k]) t.xa[k] = ar.alloc(t.elems() * es);
     if (t.has_bn) {
       const size_t gc = (size_t)n.groups * t.C * sizeof(float);
       t.bn.a = (float*)ar.alloc(gc); t.bn.b = (float*)ar.alloc(gc);
@@ -323,6 +330,7 @@ static size_t carve_all(vp_pixrefer* h, char* base, size_t cap) {
     h->comp_partial = (double*)ar.alloc((size_t)h->n_comp * 2 * sizeof(double));
     h->perc_partial = (double*)ar.alloc((size_t)h->n_perc * sizeof(double));
   }
+  h->zeros = ar.alloc(256);
   h->bn_partial = (double*)ar.alloc((size_t)1024 * 2 * 512 * sizeof(double));
   h->scratch = (char*)ar.alloc(h->scratch_bytes);
   return ar.off + 256;
@@ -363,12 +371,13 @@ static void fill_src(const Net& n, const Layer& L, PixSrc& x, int group_n, int s
   }
   for (int s = 0; s < L.nsrc; ++s) {
     const Tens& t = n.t[L.src[s]];
-    x.ptr[s] = (const char*)t.y + (size_t)sample0 * t.H * t.W * t.C * es;
+    const void* base = (L.in_act != ACT_NONE) ? t.xa[L.in_act] : t.y;   // act(bn(y)) was materialised by the producer
+    x.ptr[s] = (const char*)base + (size_t)sample0 * t.H * t.W * t.C * es;
     x.C[s] = t.C;
-    if (t.has_bn) { x.aff_a[s] = t.bn.a + (size_t)group0 * t.C; x.aff_b[s] = t.bn.b + (size_t)group0 * t.C; }
   }
-  x.act = L.in_act;
+  x.act = ACT_NONE;
   x.group_n = group_n;
+  (void)group0;
 }
 
 static int run_pack(vp_pixrefer* h, Net& n, hipStream_t st) {
@@ -402,8 +411,14 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
   a.bias = L.has_bn ? nullptr : n.params + L.b_off;   // a bias in front of batch-norm cancels exactly
   a.out_act = L.out_act;
   a.partial = (float*)h->scratch;
+  a.zeros = h->zeros;
   VP_HIP_CHECK(launch_igemm(a, h->bf16, L.fwd.cfg, st));
-  if (L.has_bn) return run_bn_stats(h, n, L, st);
+  if (L.has_bn) { const int rc = run_bn_stats(h, n, L, st); if (rc) return rc; }
+  if (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) {
+    VP_HIP_CHECK(launch_act_apply(to.y, L.has_bn ? to.bn.a : nullptr, L.has_bn ? to.bn.b : nullptr, to.C,
+                                  (n.batch / n.groups) * to.H * to.W, (size_t)to.N * to.H * to.W,
+                                  to.xa[ACT_LRELU], to.xa[ACT_RELU], h->bf16, st));
+  }
   return VP_OK;
 }
 
@@ -452,11 +467,12 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       a.accumulate = ts.dz_written ? 1 : 0;
       ts.dz_written = true;
       // chain rule through the consumer's activation and (for BN tensors) up to the normalised value
-      a.ref = (const char*)ts.y + (size_t)sample0 * ts.H * ts.W * ts.C * es;
+      // lrelu'/relu' only depend on the sign of the pre-activation == the sign of the materialised x~
+      a.ref = (const char*)ts.xa[L.in_act] + (size_t)sample0 * ts.H * ts.W * ts.C * es;
       a.ref_act = L.in_act;
-      if (ts.has_bn) { a.ref_a = ts.bn.a + (size_t)group0 * ts.C; a.ref_b = ts.bn.b + (size_t)group0 * ts.C; }
       a.ref_group_n = group_n;
     }
+    a.zeros = h->zeros;
     VP_HIP_CHECK(launch_igemm(a, h->bf16, alt ? L.bwd_alt[s].cfg : L.bwd[s].cfg, st));
   }
   return VP_OK;
@@ -543,6 +559,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
   // thin f32 outputs
   for (Tens& t : h->G.t) if (t.name == "decoder_1") { t.y = h->y4; t.is_f32 = true; t.dz = h->dy4; }
   hipStream_t st = (hipStream_t)stream;
+  VP_HIP_CHECK(hipMemsetAsync(h->zeros, 0, 256, st));
   if (d->training) for (Tens& t : h->D.t) if (t.name == "layer_5") { t.y = h->logits; t.is_f32 = true; t.dz = h->dl_d; }
   for (Net* n : {&h->G, &h->D, &h->V}) {
     if (n->descs.empty()) continue;
@@ -695,6 +712,7 @@ int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream) {
         a.ref_act = ACT_RELU;
       }
     }
+    a.zeros = h->zeros;
     VP_HIP_CHECK(launch_igemm(a, bf, L.bwd_alt[0].cfg, st));
     if (from_pool) {
       // ti = pool output; its input is the conv tensor created just before it

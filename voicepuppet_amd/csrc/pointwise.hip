@@ -127,16 +127,24 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs a) {
   }
 }
 
-// one thread per (group, channel): mean / biased variance -> affine (pixrefer.py:99-101, eps in sqrt)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.G * a.C) return;
-  const int grp = i / a.C, c = i - grp * a.C;
-  double s0 = 0, s1 = 0;
-  for (int k = 0; k < a.nchunk; ++k) {
+// sum of the (s0, s1) partials of (grp, c) over the pixel chunks: one wave, lanes stride over chunks
+__device__ __forceinline__ void chunk_sum(const BnArgs& a, int grp, int c, int lane, double& s0, double& s1) {
+  s0 = 0; s1 = 0;
+  for (int k = lane; k < a.nchunk; k += 64) {
     const double* p = a.partial + ((size_t)(grp * a.nchunk + k) * 2) * a.C;
     s0 += p[c]; s1 += p[a.C + c];
   }
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+}
+
+// one wave per (group, channel): mean / biased variance -> affine (pixrefer.py:99-101, eps in sqrt)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnArgs a) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= a.G * a.C) return;
+  const int grp = i / a.C, c = i - grp * a.C;
+  double s0, s1;
+  chunk_sum(a, grp, c, lane, s0, s1);
+  if (lane != 0) return;
   const double mean = s0 / a.Pg;
   double var = s1 / a.Pg - mean * mean;
   if (var < 0) var = 0;
@@ -150,22 +158,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnArgs a) {
   a.rstd[i] = rstd;
 }
 
-// bwd: c1 = mean(dz), c2 = mean(dz*zhat) per group; dgamma/dbeta summed over groups
+// bwd, one wave per channel: c1 = mean(dz), c2 = mean(dz*zhat) per group; dgamma/dbeta summed over groups
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnArgs a) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= a.C) return;
   double dg = 0, db = 0;
   for (int grp = 0; grp < a.G; ++grp) {
-    double s0 = 0, s1 = 0;
-    for (int k = 0; k < a.nchunk; ++k) {
-      const double* p = a.partial + ((size_t)(grp * a.nchunk + k) * 2) * a.C;
-      s0 += p[c]; s1 += p[a.C + c];
+    double s0, s1;
+    chunk_sum(a, grp, c, lane, s0, s1);
+    if (lane == 0) {
+      a.c1[grp * a.C + c] = (float)(s0 / a.Pg);
+      a.c2[grp * a.C + c] = (float)(s1 / a.Pg);
     }
-    a.c1[grp * a.C + c] = (float)(s0 / a.Pg);
-    a.c2[grp * a.C + c] = (float)(s1 / a.Pg);
     db += s0; dg += s1;
   }
-  if (a.dgamma) {
+  if (lane == 0 && a.dgamma) {
     a.dgamma[c] = (float)dg + (a.accumulate ? a.dgamma[c] : 0.f);
     a.dbeta[c] = (float)db + (a.accumulate ? a.dbeta[c] : 0.f);
   }
@@ -196,6 +203,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
       fd[e] = a.gamma[c0 + e] * rs * (fd[e] - a.c1[gi] - zh * a.c2[gi]);
     }
     *reinterpret_cast<uint4*>(dy + pix * a.C + c0) = Elem<T>::pack(fd);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// materialise the activated tensors the consumers read: x~ = act(scale*y + shift) (batch-norm affine of
+// the producer, per BN group).  One read of y, one write per needed activation.  The MFMA kernels then
+// move plain bytes (LDS-DMA) instead of re-doing this per tap and per consumer.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void act_apply_kernel(const T* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                        int C, int Pg, size_t npix, T* __restrict__ out_lrelu, T* __restrict__ out_relu) {
+  constexpr int E = Elem<T>::E;
+  const int ncg = C / E;
+  const size_t total = npix * ncg;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    const size_t pix = i / ncg;
+    float f[E], o[E];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + pix * C + cg * E), f);
+    if (sc) {
+      const int go = (int)(pix / Pg) * C + cg * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) f[e] = fmaf(sc[go + e], f[e], sh[go + e]);
+    }
+    if (out_lrelu) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = act_apply(ACT_LRELU, f[e]);
+      *reinterpret_cast<uint4*>(out_lrelu + pix * C + cg * E) = Elem<T>::pack(o);
+    }
+    if (out_relu) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = act_apply(ACT_RELU, f[e]);
+      *reinterpret_cast<uint4*>(out_relu + pix * C + cg * E) = Elem<T>::pack(o);
+    }
   }
 }
 
@@ -503,7 +544,7 @@ hipError_t launch_bn_stats(const BnArgs& a, int is_bf16, hipStream_t st) {
   dim3 grid(a.nchunk, a.G);
   if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 0>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), grid, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.G * a.C + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.G * a.C + 3) / 4), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -511,7 +552,7 @@ hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st) {
   dim3 grid(a.nchunk, a.G);
   if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 1>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), grid, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 3) / 4), dim3(256), 0, st, a);
   const size_t work = (size_t)a.G * a.Pg * (a.C / (is_bf16 ? 8 : 4));
   VP_DISPATCH(is_bf16, bn_bwd_apply_kernel, dim3(nblocks(work)), dim3(256), st, a);
   return hipGetLastError();
@@ -519,19 +560,30 @@ hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st) {
 
 // out[c] (+)= sum over pixels of x[p][c], c < creal  (bias gradients of the BN-free layers)
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const BnArgs a, int creal, float* out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= creal) return;
   double s = 0;
-  for (int grp = 0; grp < a.G; ++grp)
-    for (int k = 0; k < a.nchunk; ++k) s += a.partial[((size_t)(grp * a.nchunk + k) * 2) * a.C + c];
-  out[c] = (float)s + (accumulate ? out[c] : 0.f);
+  for (int grp = 0; grp < a.G; ++grp) {
+    double s0, s1;
+    chunk_sum(a, grp, c, lane, s0, s1);
+    s += s0;
+  }
+  if (lane == 0) out[c] = (float)s + (accumulate ? out[c] : 0.f);
 }
 
 hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate, int is_bf16, hipStream_t st) {
   dim3 grid(a.nchunk, a.G);
   if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 0>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), grid, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((creal + 255) / 256), dim3(256), 0, st, a, creal, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((creal + 3) / 4), dim3(256), 0, st, a, creal, out, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int C, int Pg, size_t npix,
+                            void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st) {
+  const size_t work = npix * (C / (is_bf16 ? 8 : 4));
+  if (is_bf16) hipLaunchKernelGGL((act_apply_kernel<bf16>), dim3(nblocks(work)), dim3(256), 0, st, (const bf16*)y, sc, sh, C, Pg, npix, (bf16*)out_lrelu, (bf16*)out_relu);
+  else hipLaunchKernelGGL((act_apply_kernel<float>), dim3(nblocks(work)), dim3(256), 0, st, (const float*)y, sc, sh, C, Pg, npix, (float*)out_lrelu, (float*)out_relu);
   return hipGetLastError();
 }
 
