@@ -284,19 +284,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 // igemm_dma_kernel: same GEMM, operands that need no prologue (materialised activations, gradients,
 // packed weights) go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no
 // ds_write pass).  One wave instruction moves a 16-row block x 4 k-pieces = 64 consecutive 16-byte
-// slots, so the LDS image is [row block][k-piece g][16 rows]; reads stay conflict-free (the 16 lanes of
-// a ds_read_b128 group still touch 16 distinct slots of one 256-byte bank row).  Padding / ragged
+// slots; the LDS image is [row block][16 rows][4 k-pieces] with the pieces of each row XOR-permuted
+// (rb_swz) so that global reads are coalesced AND ds_read_b128 stays conflict-free.  Padding / ragged
 // pixels read a 16-byte zero page instead (LDS-DMA cannot zero-fill).  One barrier per K chunk.
 // ------------------------------------------------------------------------------------------------
+// piece permutation of row i inside a 16-row block: LDS slot = i*4 + (g ^ rb_swz(i)).  The DMA writes
+// slot = lane, so lane (i = lane>>2, p = lane&3) fetches global piece p ^ rb_swz(i): four adjacent lanes
+// read one contiguous 64-byte segment (coalesced), and with h = (0,2,3,1) every ds_read_b128 service
+// group {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... lands on 16 distinct slots mod 16 (conflict-free).
+__device__ __forceinline__ int rb_swz(int i) { return (0x78 >> ((i >> 1) & 6)) & 3; }
+
 template <typename T, int TC, int TP, int BC, int BP>
 __device__ __forceinline__ void mma_chunk_rb(const uint4* __restrict__ ldsA, const uint4* __restrict__ ldsB,
                                              int blkA0, int blkB0, int lane, f32x4 (&acc)[TC][TP]) {
   const int i = lane & 15, g = lane >> 4;
+  const int so = i * 4 + (g ^ rb_swz(i));
   uint4 fa[TC], fb[TP];
 #pragma unroll
-  for (int t = 0; t < TC; ++t) fa[t] = ldsA[((blkA0 + t) * 4 + g) * 16 + i];
+  for (int t = 0; t < TC; ++t) fa[t] = ldsA[(blkA0 + t) * 64 + so];
 #pragma unroll
-  for (int t = 0; t < TP; ++t) fb[t] = ldsB[((blkB0 + t) * 4 + g) * 16 + i];
+  for (int t = 0; t < TP; ++t) fb[t] = ldsB[(blkB0 + t) * 64 + so];
 #pragma unroll
   for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
@@ -315,16 +322,20 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
   constexpr int NBA = BC / 16, NBB = BP / 16;          // 16-row blocks per operand tile
   constexpr int JA = (NBA + 3) / 4, JB = (NBB + 3) / 4; // DMA instructions per wave per chunk
   constexpr int BUF = 4 * (BC + BP);
+  // every wave issues the same number of DMAs per chunk -> a counted vmcnt can keep one chunk in flight
+  // across the barrier (3-deep LDS ring); otherwise 2 buffers and a full drain per chunk
+  constexpr bool RING = (NBA % 4 == 0) && (NBB % 4 == 0);
+  constexpr int NST = RING ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
-  int* ltap = reinterpret_cast<int*>(lds + 2 * BUF);
+  int* ltap = reinterpret_cast<int*>(lds + NST * BUF);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cls = blockIdx.z / a.splitk, split = blockIdx.z - cls * a.splitk;
   const int P = a.N * a.Hg * a.Wg;
   const int p_base = blockIdx.x * BP, c_base = blockIdx.y * BC;
-  const int r = lane & 15, g = lane >> 4;
+  const int r = lane >> 2, g = (lane & 3) ^ rb_swz(lane >> 2);   // row in the 16-row block, k-piece fetched
 
   if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
 
@@ -390,13 +401,31 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
 
   __syncthreads();   // tap table visible
   if (kc0 < kc1) {
-    issue(kc0, 0);
-    for (int kc = kc0; kc < kc1; ++kc) {
-      const int buf = (kc - kc0) & 1;
-      __syncthreads();   // waits for this wave's DMA (vmcnt) and for every wave's reads of the other buffer
-      if (kc + 1 < kc1) issue(kc + 1, buf ^ 1);
-      const uint4* la = lds + buf * BUF;
-      mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
+    if (RING) {
+      issue(kc0, 0);
+      if (kc0 + 1 < kc1) issue(kc0 + 1, 1);
+      int st = 0;
+      for (int kc = kc0; kc < kc1; ++kc) {
+        // chunk kc has landed once at most the newest batch (chunk kc+1) is still outstanding
+        if (kc + 1 < kc1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave's DMA of chunk kc landed; every wave is done reading chunk kc-1
+        asm volatile("" ::: "memory");
+        const int st2 = st == 0 ? 2 : st - 1;   // == (st + 2) % 3, the buffer chunk kc-1 used
+        if (kc + 2 < kc1) issue(kc + 2, st2);
+        const uint4* la = lds + st * BUF;
+        mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
+        st = st == 2 ? 0 : st + 1;
+      }
+    } else {
+      issue(kc0, 0);
+      for (int kc = kc0; kc < kc1; ++kc) {
+        const int buf = (kc - kc0) & 1;
+        __syncthreads();   // waits for this wave's DMA (vmcnt) and for every wave's reads of the other buffer
+        if (kc + 1 < kc1) issue(kc + 1, buf ^ 1);
+        const uint4* la = lds + buf * BUF;
+        mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
+      }
     }
   }
 
@@ -604,7 +633,10 @@ static hipEvent_t prof_event() {
   return e;
 }
 
-void profile_enable(int on) { g_prof_on = on != 0; }
+static std::string g_prof_tag;
+static bool g_prof_detail = false;
+void profile_enable(int on) { g_prof_on = on != 0; g_prof_detail = on > 1; }
+void profile_tag(const char* tag) { if (g_prof_on && g_prof_detail) g_prof_tag = tag ? tag : ""; }
 
 struct ProfScope {
   bool on;
@@ -615,6 +647,7 @@ struct ProfScope {
     char buf[96];
     snprintf(buf, sizeof(buf), "%s_%s_%dx%d", kind, is_bf16 ? "bf16" : "f32", bc, bp);
     r.name = buf; r.flops = flops; r.bytes = bytes;
+    if (g_prof_detail && !g_prof_tag.empty()) r.name = g_prof_tag + " " + r.name;
     r.e0 = prof_event(); r.e1 = prof_event();
     hipEventRecord(r.e0, st);
   }
@@ -666,7 +699,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
   const int P = a.N * a.Hg * a.Wg;
   dim3 grid((P + BP - 1) / BP, a.CoutPad / BC, a.nclass * a.splitk);
-  const size_t smem = 2 * 4 * (BC + BP) * 16 + 64;
+  const size_t smem = 3 * 4 * (BC + BP) * 16 + 64;
   const bool plain = a.zeros && !a.x.aff_a[0] && !a.x.aff_a[1] && a.x.act == ACT_NONE;
   if (plain) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
   else hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);

@@ -12,7 +12,8 @@ void igemm_tile(int cfg, int* bc, int* bp);
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
 void wgrad_tile(int cfg, int* bm, int* bn);
 
-void profile_enable(int on);
+void profile_enable(int on);          // 1: per kernel kind, 2: per layer tag
+void profile_tag(const char* tag);
 size_t profile_collect(char* out, size_t cap);
 
 hipError_t launch_pack_weights(const PackDesc* d_descs, int ndesc, const float* master, void* packed, int is_bf16, hipStream_t st);

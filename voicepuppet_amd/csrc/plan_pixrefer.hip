@@ -412,6 +412,7 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
   a.out_act = L.out_act;
   a.partial = (float*)h->scratch;
   a.zeros = h->zeros;
+  profile_tag((L.scope + ":fwd").c_str());
   VP_HIP_CHECK(launch_igemm(a, h->bf16, L.fwd.cfg, st));
   if (L.has_bn) { const int rc = run_bn_stats(h, n, L, st); if (rc) return rc; }
   if (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) {
@@ -439,6 +440,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     w.partial = (float*)h->scratch;
     w.dW = n.grads + L.w_off;
     w.accumulate = 0;
+    profile_tag((L.scope + ":wgrad").c_str());
     VP_HIP_CHECK(launch_wgrad(w, h->bf16, L.wg.cfg, st));
     float* db = n.grads + L.b_off;
     if (L.has_bn) {
@@ -473,6 +475,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       a.ref_group_n = group_n;
     }
     a.zeros = h->zeros;
+    profile_tag((L.scope + (alt ? ":bwdG" : ":bwd")).c_str());
     VP_HIP_CHECK(launch_igemm(a, h->bf16, alt ? L.bwd_alt[s].cfg : L.bwd[s].cfg, st));
   }
   return VP_OK;
@@ -713,6 +716,7 @@ int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream) {
       }
     }
     a.zeros = h->zeros;
+    profile_tag((L.scope + ":bwd").c_str());
     VP_HIP_CHECK(launch_igemm(a, bf, L.bwd_alt[0].cfg, st));
     if (from_pool) {
       // ti = pool output; its input is the conv tensor created just before it

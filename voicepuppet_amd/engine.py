@@ -172,7 +172,7 @@ class PixReferEngine:
     return self.workspace[off:off + nbytes].view(tdt).view(shape)
 
   def profile(self, on):
-    self.L.vp_profile_enable(1 if on else 0)
+    self.L.vp_profile_enable(int(on))
 
   def profile_collect(self):
     import json
