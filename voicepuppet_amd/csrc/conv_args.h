@@ -50,6 +50,8 @@ struct IgemmArgs {
   int ref_act, ref_group_n, accumulate;
   int splitk;
   float* partial;           // [nclass][splitk][P][CoutPad] when splitk > 1
+  int vec_epi;              // staged (LDS) epilogue with 16-byte row stores (set by the launcher)
+  int dbg;                  // ablation switches (VP_DBG): 1 = skip MFMA, 2 = skip DMA after the prologue
   const void* zeros;        // >= 16 bytes of zeros (padding source of the LDS-DMA loader); null: register loader
 };
 

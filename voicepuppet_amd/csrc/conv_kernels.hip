@@ -12,6 +12,7 @@
 // distinct 16-byte slots of a 256-byte bank row, i.e. conflict-free reads; writers use 8-lane
 // contiguous (row loader) or XOR-swizzled (transposing loader) slots so writes are conflict-free too.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -315,6 +316,105 @@ __device__ __forceinline__ void dma16(const void* src, uint4* lds_dst_wave_unifo
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Staged epilogue: the accumulators go through LDS as an f32 [pixel][channel] tile, then every thread
+// finishes 8 consecutive channels of one pixel (bias, activation, act'(ref) product, accumulate) and
+// issues ONE 16-byte store; 16 adjacent lanes cover 256 contiguous bytes of an NHWC row.  (The direct
+// MFMA-layout store writes 8 bytes per lane at a 32-byte granularity and ran at ~0.4 TB/s.)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TC, int TP, int BC, int BP, int NPASS>
+__device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, int cls, int p_base, int c_base, int blkA0, int blkB0,
+                                                f32x4 (&acc)[TC][TP], char* smem) {
+  constexpr int PITCH = BC * 4 + 16;                 // bytes per pixel row (+16: conflict-free b128 writes)
+  constexpr int CG = BC / 8;                         // 8-channel groups per row
+  constexpr int RP = BP / NPASS;                     // pixel rows staged per pass (keeps the tile inside the ring's LDS)
+  static_assert(RP % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int P = a.N * a.Hg * a.Wg;
+  long long* otab = reinterpret_cast<long long*>(smem + RP * PITCH);
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();                                 // ring (pass 0) / previous pass's tile no longer needed
+    if (tid < RP) {
+      const int pidx = p_base + ps * RP + tid;
+      long long off = -1;
+      if (pidx < P) {
+        const int hw = a.Hg * a.Wg;
+        const int n = pidx / hw, rem = pidx - n * hw, q = rem / a.Wg, r = rem - q * a.Wg;
+        off = (((long long)n * a.Hof + (q * a.os + a.o0h[cls])) * a.Wof + (r * a.os + a.o0w[cls])) * a.ldY;
+        off = (off << 8) | (long long)(n / a.ref_group_n);   // BN group of the pixel in the low byte
+      }
+      otab[tid] = off;
+    }
+    if (blkB0 * 16 >= ps * RP && blkB0 * 16 < (ps + 1) * RP) {
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+          const int row = (blkB0 + tp) * 16 + (lane & 15) - ps * RP;
+          const int ch = (blkA0 + tc) * 16 + 4 * (lane >> 4);
+          *reinterpret_cast<f32x4*>(smem + row * PITCH + ch * 4) = acc[tc][tp];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RP * CG; idx += 256) {
+      const int p = idx / CG, cgp = idx - p * CG;
+      const long long ot = otab[p];
+      const int c0 = c_base + cgp * 8;
+      if (ot < 0 || c0 >= a.Cout) continue;
+      const size_t off = (size_t)(ot >> 8) + c0;
+      float v[8];
+      {
+        const float4 v0 = *reinterpret_cast<const float4*>(smem + p * PITCH + cgp * 32);
+        const float4 v1 = *reinterpret_cast<const float4*>(smem + p * PITCH + cgp * 32 + 16);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      }
+      if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += a.bias[c0 + e];
+      }
+      if (a.out_act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act_apply(a.out_act, v[e]);
+      }
+      if (a.ref) {
+        float z[8];
+        const T* rp = reinterpret_cast<const T*>(a.ref) + off;
+        if (sizeof(T) == 2) Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(rp), z);
+        else {
+          Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[0], z);
+          Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[1], z + 4);
+        }
+        if (a.ref_a) {
+          const int goff = (int)(ot & 255) * a.Cout + c0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) z[e] = fmaf(a.ref_a[goff + e], z[e], a.ref_b[goff + e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= act_grad(a.ref_act, z[e]);
+      }
+      if (a.y_f32 || sizeof(T) == 4) {
+        float* yp = reinterpret_cast<float*>(a.Y) + off;
+        if (a.accumulate) {
+          const float4 e0 = reinterpret_cast<const float4*>(yp)[0], e1 = reinterpret_cast<const float4*>(yp)[1];
+          v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w; v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
+        }
+        reinterpret_cast<float4*>(yp)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(yp)[1] = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        bf16* yp = reinterpret_cast<bf16*>(a.Y) + off;
+        if (a.accumulate) {
+          float e[8];
+          Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(yp), e);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += e[k];
+        }
+        *reinterpret_cast<uint4*>(yp) = Elem<bf16>::pack(v);
+      }
+    }
+  }
+}
+
 template <typename T, int WC, int WP, int TC, int TP>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
@@ -412,9 +512,9 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
         __builtin_amdgcn_s_barrier();   // every wave's DMA of chunk kc landed; every wave is done reading chunk kc-1
         asm volatile("" ::: "memory");
         const int st2 = st == 0 ? 2 : st - 1;   // == (st + 2) % 3, the buffer chunk kc-1 used
-        if (kc + 2 < kc1) issue(kc + 2, st2);
+        if (kc + 2 < kc1 && !(a.dbg & 2)) issue(kc + 2, st2);
         const uint4* la = lds + st * BUF;
-        mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
+        if (!(a.dbg & 1)) mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
         st = st == 2 ? 0 : st + 1;
       }
     } else {
@@ -429,6 +529,12 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
     }
   }
 
+  if (a.vec_epi) {
+    constexpr int RINGB = NST * BUF * 16;
+    constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : ((WP >= 2 && BP / 2 * (BC * 4 + 16) + BP * 4 <= RINGB) ? 2 : (WP >= 4 ? 4 : 2));
+    staged_epilogue<T, TC, TP, BC, BP, NPASS>(a, cls, p_base, c_base, blkA0, blkB0, acc, smem);
+    return;
+  }
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) {
     const int pidx = p_base + (blkB0 + tp) * 16 + (lane & 15);
@@ -699,9 +805,22 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
   const int P = a.N * a.Hg * a.Wg;
   dim3 grid((P + BP - 1) / BP, a.CoutPad / BC, a.nclass * a.splitk);
-  const size_t smem = 3 * 4 * (BC + BP) * 16 + 64;
+  constexpr bool RING = ((BC / 16) % 4 == 0) && ((BP / 16) % 4 == 0);
+  constexpr int RINGB = (RING ? 3 : 2) * 4 * (BC + BP) * 16;
+  constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : ((WP >= 2 && BP / 2 * (BC * 4 + 16) + BP * 4 <= RINGB) ? 2 : (WP >= 4 ? 4 : 2));
+  size_t smem = RINGB + 64;
+  const size_t smem_epi = (size_t)(BP / NPASS) * (BC * 4 + 16) + (BP / NPASS) * 8;
+  if (smem_epi > smem) smem = smem_epi;
   const bool plain = a.zeros && !a.x.aff_a[0] && !a.x.aff_a[1] && a.x.act == ACT_NONE;
-  if (plain) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
+  static const int dbg = getenv("VP_DBG") ? atoi(getenv("VP_DBG")) : 0;
+  if (plain) {
+    IgemmArgs b = a;
+    b.dbg = dbg & 3;
+    b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
+    hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, b);
+    return hipGetLastError();
+  }
+  if (false) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
   else hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
   return hipGetLastError();
 }
