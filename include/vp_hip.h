@@ -31,7 +31,7 @@ extern "C" {
 
 enum vp_status { VP_OK = 0, VP_ERR_ARG = -1, VP_ERR_HIP = -2, VP_ERR_WORKSPACE = -3, VP_ERR_STATE = -4 };
 enum vp_dtype { VP_F32 = 0, VP_BF16 = 1 };
-enum vp_act { VP_ACT_NONE = 0, VP_ACT_LRELU = 1, VP_ACT_RELU = 2, VP_ACT_TANH = 3, VP_ACT_SIGMOID = 4 };
+enum vp_act { VP_ACT_NONE = 0, VP_ACT_LRELU = 1, VP_ACT_RELU = 2, VP_ACT_TANH = 3, VP_ACT_SIGMOID = 4, VP_ACT_RELU6 = 5, VP_ACT_LEAKY = 6 };
 
 int vp_version(void);
 const char* vp_last_error(void);
@@ -135,6 +135,43 @@ int vp_bn_stats(const void* y, int pixels, int c, int dtype, const float* gamma,
 /* dy = BN backward of dz (in place allowed), dgamma, dbeta */
 int vp_bn_bwd(const void* y, const void* dz, void* dy, int pixels, int c, int dtype, const float* gamma,
               const float* mean, const float* rstd, float* dgamma, float* dbeta, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Audio front-end (f32).
+ * vp_logmel_*  : DataGenerator.extract_mfcc (generator/generator.py:60-80): Hann STFT -> |.| -> HTK mel -> log(.+1e-6)
+ * vp_bfmnet_*  : BFMNet.build_inference_op (voicepuppet/bfmnet/bfmnet.py:325-333 -> 189-213) with MfccNet
+ *                (tinynet.py:159-212) in inference mode; parameters by TF variable name (vp_bfmnet_param_info).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vp_logmel_desc {
+  int sample_rate, num_mel_bins, win_length, hop_step, fft_length;   /* config/params.yml:16-21; win == fft */
+  float lower_hz, upper_hz;                                          /* 80, 7600 (generator.py:68) */
+  int batch, samples;                                                /* pcm [batch, samples] */
+} vp_logmel_desc;
+typedef struct vp_logmel vp_logmel_t;
+size_t vp_logmel_workspace_bytes(const vp_logmel_desc* d);
+int vp_logmel_frames(const vp_logmel_desc* d);                       /* 1 + (samples - win)/hop */
+int vp_logmel_create(const vp_logmel_desc* d, void* workspace, size_t workspace_bytes, void* stream, vp_logmel_t** out);
+void vp_logmel_destroy(vp_logmel_t* h);
+/* pcm [batch, samples] f32 in [-1,1] -> out [batch, frames, num_mel_bins] f32 */
+int vp_logmel_forward(vp_logmel_t* h, const float* pcm, float* out, void* stream);
+
+typedef struct vp_bfmnet_desc {
+  int batch;          /* clips */
+  int frames;         /* T video frames per clip; the mel input has 5*T frames (frame_mfcc_scale, generator.py:46-52) */
+  int num_mel_bins;   /* 80 */
+} vp_bfmnet_desc;
+typedef struct vp_bfmnet vp_bfmnet_t;
+size_t vp_bfmnet_param_count(void);
+int vp_bfmnet_param_info(int index, char* name, int name_cap, size_t* offset, int* ndim, int64_t shape[4]);
+size_t vp_bfmnet_workspace_bytes(const vp_bfmnet_desc* d);
+int vp_bfmnet_create(const vp_bfmnet_desc* d, void* workspace, size_t workspace_bytes, const float* params,
+                     void* stream, vp_bfmnet_t** out);
+void vp_bfmnet_destroy(vp_bfmnet_t* h);
+int vp_bfmnet_params_changed(vp_bfmnet_t* h);
+/* ears [B,T,1], mfccs [B,5T,80], seq_len [B] (int32) -> BFMCoeffDecoder [B,T,64]; all device pointers */
+int vp_bfmnet_forward(vp_bfmnet_t* h, const float* ears, const float* mfccs, const int* seq_len, float* out, void* stream);
+/* "MfccEncoder" [B,T,256], "RNNModule" [B,T,256] of the last forward */
+int vp_bfmnet_tensor(vp_bfmnet_t* h, const char* name, void** ptr, int64_t shape[4]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,62 @@
+"""-m gpu: log-mel and BFMNet inference (vp_logmel_*, vp_bfmnet_*) against oracle/audio_ref.py.
+f32 path; tolerance 1e-4 relative L2 on the log-mel features (f32 DFT of 512 terms), 1e-3 on the coefficients."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_ref as ar
+from voicepuppet_amd.audio import BFMNetEngine, LogMel, bfmnet_manifest
+
+import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_pcm(b, n, seed=0):
+  rng = np.random.default_rng(seed)
+  t = np.arange(n) / 16000.0
+  sweep = 0.3 * np.sin(2 * np.pi * (100 + (4000 - 100) * t / t[-1] / 2) * t)
+  return np.clip(0.1 * rng.normal(size=(b, n)) + sweep, -1, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("b,n", [(1, 512), (3, 4096), (4, 16384), (2, 5000)])
+def test_logmel_parity(b, n):
+  pcm = synth_pcm(b, n)
+  lm = LogMel(b, n)
+  out = lm(torch.tensor(pcm, device="cuda")).cpu().numpy()
+  ref = ar.extract_mfcc(pcm.astype(np.float64))
+  assert out.shape == ref.shape
+  assert gu.rel_l2(out, ref) < 1e-4, gu.rel_l2(out, ref)
+  assert np.abs(out - ref).max() < 5e-3
+
+
+def test_logmel_silence_is_log_eps():
+  lm = LogMel(1, 4096)
+  out = lm(torch.zeros(1, 4096, device="cuda")).cpu().numpy()
+  np.testing.assert_allclose(out, np.log(1e-6), rtol=1e-6)
+
+
+def test_bfmnet_manifest_matches_oracle():
+  assert [(n, s) for n, _, s in bfmnet_manifest()] == [(n, tuple(s)) for n, s in ar.bfmnet_manifest()]
+
+
+@pytest.mark.parametrize("b,t,lens", [(2, 5, [5, 3]), (3, 25, [25, 25, 7])])
+def test_bfmnet_parity(b, t, lens):
+  p = ar.init_bfmnet_params(3, dtype=np.float32)
+  rng = np.random.default_rng(4)
+  pcm = synth_pcm(b, ar.pcm_length_for(t), seed=5)
+  mfcc = ar.extract_mfcc(pcm.astype(np.float64)).astype(np.float32)
+  ears = (rng.uniform(size=(b, t, 1)) / 100).astype(np.float32)
+  eng = BFMNetEngine(b, t)
+  eng.load_params(p)
+  out = eng.forward(torch.tensor(ears, device="cuda"), torch.tensor(mfcc, device="cuda"), lens).cpu().numpy()
+  ref = ar.bfmnet_fwd({k: v.astype(np.float64) for k, v in p.items()}, ears.astype(np.float64), mfcc.astype(np.float64), lens)
+  enc = eng.tensor("MfccEncoder").cpu().numpy()
+  rnn = eng.tensor("RNNModule").cpu().numpy()
+  print("\nMfccEncoder %.2e RNN %.2e coeff %.2e" % (gu.rel_l2(enc, ref["MfccEncoder"]), gu.rel_l2(rnn, ref["RNNModule"]),
+                                                    gu.rel_l2(out, ref["BFMCoeffDecoder"])))
+  assert gu.rel_l2(enc, ref["MfccEncoder"]) < 1e-3
+  assert gu.rel_l2(rnn, ref["RNNModule"]) < 1e-3
+  assert gu.rel_l2(out, ref["BFMCoeffDecoder"]) < 1e-3
+  for i, n in enumerate(lens):       # dynamic_rnn: outputs past sequence_length are zero
+    assert np.all(rnn[i, n:] == 0)

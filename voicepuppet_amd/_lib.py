@@ -21,6 +21,16 @@ class ConvDesc(ctypes.Structure):
               ("pad", ctypes.c_int), ("dtype", ctypes.c_int), ("in_act", ctypes.c_int), ("out_act", ctypes.c_int)]
 
 
+class LogMelDesc(ctypes.Structure):
+  _fields_ = [("sample_rate", ctypes.c_int), ("num_mel_bins", ctypes.c_int), ("win_length", ctypes.c_int),
+              ("hop_step", ctypes.c_int), ("fft_length", ctypes.c_int), ("lower_hz", ctypes.c_float),
+              ("upper_hz", ctypes.c_float), ("batch", ctypes.c_int), ("samples", ctypes.c_int)]
+
+
+class BfmNetDesc(ctypes.Structure):
+  _fields_ = [("batch", ctypes.c_int), ("frames", ctypes.c_int), ("num_mel_bins", ctypes.c_int)]
+
+
 _P = ctypes.c_void_p
 _SIGNATURES = {
     "vp_version": (ctypes.c_int, []),
@@ -50,6 +60,20 @@ _SIGNATURES = {
     "vp_conv_bwd_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "vp_bn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "vp_bn_stats": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P]),
+    "vp_logmel_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(LogMelDesc)]),
+    "vp_logmel_frames": (ctypes.c_int, [ctypes.POINTER(LogMelDesc)]),
+    "vp_logmel_create": (ctypes.c_int, [ctypes.POINTER(LogMelDesc), _P, ctypes.c_size_t, _P, ctypes.POINTER(_P)]),
+    "vp_logmel_destroy": (None, [_P]),
+    "vp_logmel_forward": (ctypes.c_int, [_P, _P, _P, _P]),
+    "vp_bfmnet_param_count": (ctypes.c_size_t, []),
+    "vp_bfmnet_param_info": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
+    "vp_bfmnet_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(BfmNetDesc)]),
+    "vp_bfmnet_create": (ctypes.c_int, [ctypes.POINTER(BfmNetDesc), _P, ctypes.c_size_t, _P, _P, ctypes.POINTER(_P)]),
+    "vp_bfmnet_destroy": (None, [_P]),
+    "vp_bfmnet_params_changed": (ctypes.c_int, [_P]),
+    "vp_bfmnet_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
+    "vp_bfmnet_tensor": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     "vp_bn_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -1,0 +1,220 @@
+// Audio front-end kernels (f32): STFT framing, |DFT| -> mel -> log, and the non-GEMM pieces of MfccNet /
+// BFMNet inference (first 9x5 conv, depthwise 7x3, SAME max-pools, batch-norm folding, GRU).
+// The GEMM-shaped parts (DFT as a 512x514 matrix product, every 1x1 conv and dense layer) run on the
+// f32-MFMA implicit-GEMM kernel of conv_kernels.hip.
+// Reference: generator/generator.py:60-80, voicepuppet/bfmnet/tinynet.py:7-212, bfmnet.py:20-122.
+#include "audio_args.h"
+#include "vp_common.h"
+
+namespace vp {
+
+// frames[b*F + f][n] = pcm[b][f*hop + n] * hann_periodic(n)      (tf.signal.stft framing, no padding)
+__global__ __launch_bounds__(256) void frame_window_kernel(const float* __restrict__ pcm, const float* __restrict__ window,
+                                                           float* __restrict__ frames, int B, int L, int F, int win, int hop) {
+  const size_t total = (size_t)B * F * win;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int n = (int)(i % win);
+    const size_t t = i / win;
+    const int f = (int)(t % F), b = (int)(t / F);
+    frames[i] = pcm[(size_t)b * L + (size_t)f * hop + n] * window[n];
+  }
+}
+
+// one block per frame: |re + i*im| for the nb spectrogram bins, dot with the mel matrix, log(. + 1e-6)
+__global__ __launch_bounds__(128) void mag_mel_log_kernel(const float* __restrict__ spec, int ld, int nb,
+                                                          const float* __restrict__ mel, int nmel, float* __restrict__ out) {
+  extern __shared__ float mag[];
+  const float* s = spec + (size_t)blockIdx.x * ld;
+  for (int k = threadIdx.x; k < nb; k += 128) {
+    const float re = s[k], im = s[nb + k];
+    mag[k] = sqrtf(re * re + im * im);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < nmel; j += 128) {
+    float acc = 0.f;
+    for (int k = 0; k < nb; ++k) acc = fmaf(mag[k], mel[(size_t)k * nmel + j], acc);
+    out[(size_t)blockIdx.x * nmel + j] = logf(acc + 1e-6f);
+  }
+}
+
+// y = relu(conv9x5 stride (1,2) SAME (x[B,H,W,1]) * folded_scale + folded_bias)   (tinynet.py:168)
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w /*[45][Cout]*/,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int B, int H, int W, int Wo, int Cout, int pt, int pl) {
+  extern __shared__ float sw[];
+  for (int i = threadIdx.x; i < 45 * Cout; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const size_t total = (size_t)B * H * Wo * Cout;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int co = (int)(i % Cout);
+    size_t t = i / Cout;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc = bias[co];
+    for (int kh = 0; kh < 9; ++kh) {
+      const int ih = oh + kh - pt;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int kw = 0; kw < 5; ++kw) {
+        const int iw = ow * 2 + kw - pl;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        acc = fmaf(x[((size_t)b * H + ih) * W + iw], sw[(kh * 5 + kw) * Cout + co], acc);
+      }
+    }
+    y[i] = fmaxf(acc, 0.f);
+  }
+}
+
+// depthwise 7x3 stride 1 SAME + folded BN + relu6, 4 channels per thread     (tinynet.py:84-103)
+__global__ __launch_bounds__(256) void dwconv7x3_kernel(const float* __restrict__ x, const float* __restrict__ w /*[21][C]*/,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W, int C) {
+  const int cq = C >> 2;
+  const size_t total = (size_t)B * H * W * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % cq) * 4;
+    size_t t = i / cq;
+    const int ow = (int)(t % W); t /= W;
+    const int oh = (int)(t % H);
+    const int b = (int)(t / H);
+    float4 acc = *reinterpret_cast<const float4*>(bias + c4);
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+      const int ih = oh + kh - 3;
+      if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow + kw - 1;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float4 xv = *reinterpret_cast<const float4*>(x + (((size_t)b * H + ih) * W + iw) * C + c4);
+        const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(kh * 3 + kw) * C + c4);
+        acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y); acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+      }
+    }
+    acc.x = fminf(fmaxf(acc.x, 0.f), 6.f); acc.y = fminf(fmaxf(acc.y, 0.f), 6.f);
+    acc.z = fminf(fmaxf(acc.z, 0.f), 6.f); acc.w = fminf(fmaxf(acc.w, 0.f), 6.f);
+    *reinterpret_cast<float4*>(y + i * 4) = acc;
+  }
+}
+
+// max-pool kxk, stride s, TF 'SAME' (padding never wins), 4 channels per thread
+__global__ __launch_bounds__(256) void maxpool_same_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C,
+                                                           int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo) {
+  const int cq = C >> 2;
+  const size_t total = (size_t)B * Ho * Wo * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % cq) * 4;
+    size_t t = i / cq;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int i2 = 0; i2 < kh; ++i2) {
+      const int ih = oh * sh + i2 - pt;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int j2 = 0; j2 < kw; ++j2) {
+        const int iw = ow * sw + j2 - pl;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + ih) * W + iw) * C + c4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = m;
+  }
+}
+
+// inference batch-norm folding (contrib batch_norm: no gamma, eps 1e-3):
+//   w'[..., c] = w[..., c] / sqrt(var[c] + eps),  b'[c] = beta[c] - mean[c] / sqrt(var[c] + eps)
+__global__ __launch_bounds__(256) void fold_bn_kernel(const float* __restrict__ w, const float* __restrict__ beta, const float* __restrict__ mean,
+                                                      const float* __restrict__ var, float eps, size_t n, int C, float* __restrict__ wf,
+                                                      float* __restrict__ bf) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float s = 1.f / sqrtf(var[c] + eps);
+    wf[i] = w[i] * s;
+    if (i < (size_t)C) bf[c] = beta[c] - mean[c] * s;
+  }
+}
+
+// tf.contrib.rnn.GRUCell over T steps (dynamic_rnn semantics), one block per sequence, H = 256 = blockDim.
+//   xg [B,T,2H] = x.Wg[:H] + bg,  xc [B,T,H] = x.Wc[:H] + bc  (precomputed GEMMs);  whg [H][2H], whc [H][H]
+__global__ __launch_bounds__(256) void gru_seq_kernel(const float* __restrict__ xg, const float* __restrict__ xc, const float* __restrict__ whg,
+                                                      const float* __restrict__ whc, const int* __restrict__ seq_len, float* __restrict__ out,
+                                                      int T) {
+  constexpr int H = 256;
+  __shared__ float h[H], rh[H];
+  const int b = blockIdx.x, j = threadIdx.x;
+  const int len = seq_len[b];
+  h[j] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float* g = xg + ((size_t)b * T + t) * 2 * H;
+    float ar = g[j], au = g[H + j];
+    for (int k = 0; k < H; ++k) {
+      const float hk = h[k];
+      ar = fmaf(hk, whg[(size_t)k * 2 * H + j], ar);
+      au = fmaf(hk, whg[(size_t)k * 2 * H + H + j], au);
+    }
+    const float r = 1.f / (1.f + expf(-ar)), u = 1.f / (1.f + expf(-au));
+    const float hj = h[j];
+    rh[j] = r * hj;
+    __syncthreads();
+    float ac = xc[((size_t)b * T + t) * H + j];
+    for (int k = 0; k < H; ++k) ac = fmaf(rh[k], whc[(size_t)k * H + j], ac);
+    const float hn = u * hj + (1.f - u) * tanhf(ac);
+    const bool live = t < len;
+    out[((size_t)b * T + t) * H + j] = live ? hn : 0.f;
+    __syncthreads();
+    h[j] = live ? hn : hj;
+    __syncthreads();
+  }
+}
+
+// out[b,t,16:20] += ears[b,t] * {-2,-2,-2,-4}     (bfmnet.py:117,209)
+__global__ void add_ears_kernel(float* __restrict__ out, const float* __restrict__ ears, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float e = ears[i];
+  float* o = out + (size_t)i * 64 + 16;
+  o[0] += -2.f * e; o[1] += -2.f * e; o[2] += -2.f * e; o[3] += -4.f * e;
+}
+
+static inline int nblk(size_t work, int cap = 4096) {
+  size_t b = (work + 255) / 256;
+  if (b < 1) b = 1;
+  return (int)(b > (size_t)cap ? cap : b);
+}
+
+hipError_t launch_frame_window(const float* pcm, const float* window, float* frames, int B, int L, int F, int win, int hop, hipStream_t st) {
+  hipLaunchKernelGGL(frame_window_kernel, dim3(nblk((size_t)B * F * win)), dim3(256), 0, st, pcm, window, frames, B, L, F, win, hop);
+  return hipGetLastError();
+}
+hipError_t launch_mag_mel_log(const float* spec, int ld, int nb, const float* mel, int nmel, float* out, int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(mag_mel_log_kernel, dim3(nframes), dim3(128), nb * sizeof(float), st, spec, ld, nb, mel, nmel, out);
+  return hipGetLastError();
+}
+hipError_t launch_conv_first(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Wo, int Cout, int pt, int pl, hipStream_t st) {
+  hipLaunchKernelGGL(conv_first_kernel, dim3(nblk((size_t)B * H * Wo * Cout)), dim3(256), 45 * Cout * sizeof(float), st, x, w, bias, y, B, H, W, Wo, Cout, pt, pl);
+  return hipGetLastError();
+}
+hipError_t launch_dwconv7x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(dwconv7x3_kernel, dim3(nblk((size_t)B * H * W * (C / 4), 8192)), dim3(256), 0, st, x, w, bias, y, B, H, W, C);
+  return hipGetLastError();
+}
+hipError_t launch_maxpool_same(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, hipStream_t st) {
+  hipLaunchKernelGGL(maxpool_same_kernel, dim3(nblk((size_t)B * Ho * Wo * (C / 4))), dim3(256), 0, st, x, y, B, H, W, C, kh, kw, sh, sw, pt, pl, Ho, Wo);
+  return hipGetLastError();
+}
+hipError_t launch_fold_bn(const float* w, const float* beta, const float* mean, const float* var, float eps, size_t n, int C, float* wf, float* bf, hipStream_t st) {
+  hipLaunchKernelGGL(fold_bn_kernel, dim3(nblk(n)), dim3(256), 0, st, w, beta, mean, var, eps, n, C, wf, bf);
+  return hipGetLastError();
+}
+hipError_t launch_gru_seq(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, int B, int T, hipStream_t st) {
+  hipLaunchKernelGGL(gru_seq_kernel, dim3(B), dim3(256), 0, st, xg, xc, whg, whc, seq_len, out, T);
+  return hipGetLastError();
+}
+hipError_t launch_add_ears(float* out, const float* ears, int n, hipStream_t st) {
+  hipLaunchKernelGGL(add_ears_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out, ears, n);
+  return hipGetLastError();
+}
+
+}  // namespace vp

@@ -27,7 +27,8 @@ struct PixSrc {
 struct IgemmArgs {
   PixSrc x;
   int N, Hin, Win;
-  int Cin, log2Cin;         // total channels of x (power of two)
+  int Cin, log2Cin;         // total channels of x (power of two unless ntaps == 1)
+  int cin_mask;             // Cin-1 (ntaps > 1) or all-ones (1x1: k is the channel index itself)
   int cin_real;             // channels that carry data (accounting only)
   int Hg, Wg;               // GEMM pixel grid per class: pixel = (n, q, r)
   int sh, sw;               // ih = q*sh + dh[tap], iw = r*sw + dw[tap]

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   auto load_b = [&](int kc, int ps, int n, int bh, int bw, bool ok) -> uint4 {
     const int k0 = kc * KC + g * E;
     const int tap = k0 >> a.log2Cin;
-    const int ci = k0 & (a.Cin - 1);
+    const int ci = k0 & a.cin_mask;
     const bool tok = tap < a.ntaps;
     const int tv = ltap[tok ? tap : 0];
     const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
       if (NBA % 4 == 0 || wave + 4 * j < NBA) dma16(wrow[j] + (size_t)kc * KC, la + (wave + 4 * j) * 64);
     const int k0 = kc * KC + g * E;
     const int tap = k0 >> a.log2Cin;
-    const int ci = k0 & (a.Cin - 1);
+    const int ci = k0 & a.cin_mask;
     const bool tok = tap < a.ntaps;
     const int tv = ltap[tok ? tap : 0];
     const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);

@@ -73,7 +73,8 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   igemm_tile(p.cfg, &bc, &bp);
   a.CoutPad = round_up(rows, bc);
   a.Kpad = round_up(a.ntaps * a.Cin, kc_elems(is_bf16));
-  a.log2Cin = ilog2(a.Cin);
+  if (a.ntaps == 1) { a.log2Cin = 30; a.cin_mask = 0x3fffffff; }   // 1x1: any channel count
+  else { a.log2Cin = ilog2(a.Cin); a.cin_mask = a.Cin - 1; }
   const int blocks = ((P + bp - 1) / bp) * (a.CoutPad / bc) * a.nclass;
   a.splitk = pick_igemm_splitk(blocks, a.Kpad / kc_elems(is_bf16));
   p.partial_bytes = a.splitk > 1 ? (size_t)a.nclass * a.splitk * P * a.CoutPad * sizeof(float) : 0;

@@ -10,7 +10,7 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
+enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4, ACT_RELU6 = 5, ACT_LEAKY = 6 };
 
 __device__ __forceinline__ float act_apply(int act, float x) {
   // lrelu(x, 0.2) = 0.6*x + 0.4*|x|   (pixrefer.py:88-97)
@@ -18,6 +18,8 @@ __device__ __forceinline__ float act_apply(int act, float x) {
   if (act == ACT_RELU) return fmaxf(x, 0.f);
   if (act == ACT_TANH) return tanhf(x);
   if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-x));
+  if (act == ACT_RELU6) return fminf(fmaxf(x, 0.f), 6.f);          // tinynet.py:9
+  if (act == ACT_LEAKY) return fmaxf(x, 0.2f * x);                  // tf.nn.leaky_relu (bfmnet.py:199)
   return x;
 }
 
