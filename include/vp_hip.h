@@ -47,6 +47,8 @@ typedef struct vp_pixrefer_desc {
   int training;     /* 1: build_train_op graph (G + 3xD + VGG + losses + grads); 0: build_inference_op */
   float l1_weight;  /* pixrefer.py:30-31 */
   float gan_weight;
+  int per_sample_bn; /* inference only: batch-norm statistics per sample (== running N frames through the
+                        reference's batch-1 graph, infer_bfmvid.py:152,198, but batched on the device) */
 } vp_pixrefer_desc;
 
 typedef struct vp_pixrefer vp_pixrefer_t;

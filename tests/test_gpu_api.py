@@ -1,0 +1,92 @@
+"""-m gpu: the reference-shaped Python surface (PixReferNet / BFMNet / DataGenerator / Session, the two CLI
+entry points) driving the HIP executors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "config", "params.yml")
+
+
+def test_train_cli_runs_and_checkpoints(tmp_path, monkeypatch, capsys):
+  from voicepuppet_amd.pixrefer import train_pixrefer
+  monkeypatch.chdir(tmp_path)
+  os.makedirs("config")
+  train_pixrefer.main(["--config_path", CFG, "--steps", "3", "--batch_size", "1", "--img_size", "256"])
+  assert os.path.isdir("ckpt_pixrefer") and os.path.isdir("log/summary_pixrefer")
+
+
+def test_build_train_op_nodes_and_lr_steps():
+  from voicepuppet_amd.generator.generator import PixReferDataGenerator
+  from voicepuppet_amd.pixrefer.pixrefer import PixReferNet, TRAIN_KEYS
+  from voicepuppet_amd.runtime import Session
+  gen = PixReferDataGenerator(CFG)
+  p = gen.params
+  p.batch_size, p.img_size = 2, 256
+  it = gen.get_dataset().make_one_shot_iterator()
+  net = PixReferNet(CFG)
+  p = net.params
+  p.batch_size = 2
+  p.add_hparam("is_training", True)
+  p.sess = Session()
+  p.vgg_model_path = "allmodels/vgg_16.ckpt"
+  p.amd = dict(p.amd, dtype="f32")
+  net.set_params(p)
+  nodes = net.build_train_op(*it.get_next())
+  assert sorted(nodes) == sorted(TRAIN_KEYS)
+  sess = p.sess
+  losses = []
+  for i in range(3):
+    _, g, l1, d, lr, gs = sess.run([nodes["Train_op"], nodes["Gen_loss_GAN"], nodes["Gen_loss_L1"], nodes["Discrim_loss"],
+                                    nodes["Lr"], nodes["Global_step"]])
+    assert gs == 2 * (i + 1) and lr == pytest.approx(3e-4)
+    assert np.isfinite([g, l1, d]).all()
+    losses.append(l1)
+  out, al, pr = sess.run([nodes["Outputs"], nodes["Alphas"], nodes["Predict_real"]])
+  assert out.shape == (2, 256, 256, 3) and al.shape == (2, 256, 256, 3) and pr.shape == (2, 30, 30, 1)
+  assert 0 <= al.min() and al.max() <= 1 and 0 < pr.min() and pr.max() < 1
+  path = net.save("/tmp/vp_test_ckpt.npz")
+  z = np.load(path)
+  assert "generator/encoder_1/conv2d/kernel" in z.files and "discriminator/layer_4/conv2d/kernel/Adam_1" in z.files
+  assert int(z["global_step"]) == 6
+
+
+def test_batched_inference_equals_batch_one_loop():
+  """per-sample batch-norm statistics: N frames in one launch == the reference's N separate batch-1 runs."""
+  from voicepuppet_amd.engine import PixReferEngine
+  from oracle import pixrefer_ref as ref
+  p = ref.init_params(8, 8, seed=5, dtype=np.float32)
+  rng = np.random.default_rng(6)
+  x = [torch.tensor(rng.uniform(size=(3, 256, 256, c)).astype(np.float32), device="cuda") for c in (6, 3, 3)]
+  e3 = PixReferEngine(3, 256, 8, 8, dtype="f32", training=False, per_sample_bn=True)
+  e3.load_params(p)
+  e3.forward(*x)
+  got = e3.tensor("Outputs_raw").clone()
+  e1 = PixReferEngine(1, 256, 8, 8, dtype="f32", training=False)
+  e1.load_params(p)
+  for i in range(3):
+    e1.forward(*[t[i:i + 1].contiguous() for t in x])
+    assert gu.rel_l2(got[i].cpu().numpy(), e1.tensor("Outputs_raw")[0].cpu().numpy()) < 1e-5
+  out = ref.inference({k: v.astype(np.float64) for k, v in p.items()}, x[0][:1].cpu().numpy().astype(np.float64),
+                      x[1][:1].cpu().numpy().astype(np.float64), x[2][:1].cpu().numpy().astype(np.float64), ngf=8)
+  assert gu.rel_l2((got[0].cpu().numpy() + 1) / 2, out["Outputs"][0]) < 1e-3
+
+
+def test_infer_bfmvid_cli_end_to_end(tmp_path, monkeypatch):
+  from PIL import Image
+  from scipy.io import wavfile
+  from voicepuppet_amd.pixrefer import infer_bfmvid
+  monkeypatch.chdir(tmp_path)
+  rng = np.random.default_rng(0)
+  Image.fromarray((rng.uniform(size=(512, 1536, 3)) * 255).astype(np.uint8)).save("face.jpg")
+  t = np.arange(8000) / 16000.0
+  wavfile.write("a.wav", 16000, (0.3 * np.sin(2 * np.pi * 440 * t) * 32767).astype(np.int16))
+  infer_bfmvid.main(["--config_path", CFG, "--frame_batch", "4", "face.jpg", "a.wav"])
+  frames = sorted(os.listdir("output"))
+  assert len(frames) == int(1 + 8000 / 640)            # pad_len video frames (infer_bfmvid.py:162)
+  assert Image.open(os.path.join("output", "0.jpg")).size == (512, 512)

@@ -1,0 +1,137 @@
+"""CPU tests of the host side: config surface, data layout, session shim, LR schedule, driver arithmetic of
+infer_bfmvid.py, and that libvp_hip.so loads and exports every symbol include/vp_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "config", "params.yml")
+
+
+def test_config_surface_matches_reference_keys():
+  from voicepuppet_amd.config.configure import YParams
+  p = YParams(CFG, "default")
+  # keys of the reference config/params.yml:1-31
+  for k in ("train_dataset_path", "eval_dataset_path", "root_path", "train_by_eval", "sample_file", "model_dir", "mel",
+            "frame_rate", "training"):
+    assert k in p
+  assert p.mel == {"sample_rate": 16000, "num_mel_bins": 80, "win_length": 512, "fft_length": 512, "hop_step": 128}
+  assert p.frame_rate == 25 and p.training["decay_steps"] == 1000
+  assert set(p.sample_file) == {"landmark_name", "wav_name", "bfmcoeff_name"}
+  p.add_hparam("ngf", 64)
+  with pytest.raises(ValueError):
+    p.add_hparam("ngf", 32)
+  p.batch_size = 2            # plain attribute assignment, as the reference scripts do
+  assert p.batch_size == 2 and "batch_size" in p
+
+
+def test_pixrefernet_hparams_and_lr_schedule():
+  from voicepuppet_amd.pixrefer.pixrefer import PixReferNet, TRAIN_KEYS, INFER_KEYS
+  net = PixReferNet(CFG)
+  p = net.params
+  assert (p.ngf, p.ndf, p.l1_weight, p.gan_weight, p.separable_conv) == (64, 64, 500.0, 1.0, False)   # pixrefer.py:24-37
+  assert p.training["learning_rate"] == 0.0003 and p.training["beta1"] == 0.5 and p.training["decay_rate"] == 0.999
+  p.batch_size = 2
+  p.add_hparam("is_training", False)
+  net.set_params(p)
+  net.global_step = 999
+  assert net.current_lr() == pytest.approx(3e-4)
+  net.global_step = 1000      # == 500 iterations: global_step advances twice per iteration
+  assert net.current_lr() == pytest.approx(3e-4 * 0.999)
+  assert set(TRAIN_KEYS) >= {"Train_op", "Gen_loss_GAN", "Gen_loss_L1", "Discrim_loss", "Lr", "Global_step", "Outputs", "Alphas"}
+  assert INFER_KEYS == ["Inputs", "FGInputs", "Targets", "Outputs", "Alphas", "Outputs_FG"]
+
+
+def test_datagenerator_params_and_driver_arithmetic():
+  from voicepuppet_amd.generator.generator import DataGenerator
+  from voicepuppet_amd.pixrefer.infer_bfmvid import prepare_pcm, splice_coeff
+  g = DataGenerator(CFG)
+  g.set_params(g.params)
+  assert (g.sample_rate, g.hop_step, g.win_length, g.frame_wav_scale, g.frame_mfcc_scale) == (16000, 128, 512, 640.0, 5)
+  pcm = np.ones(16000, np.float32)            # 1 s -> pad_len = int(1 + 16000/640) = 26 (infer_bfmvid.py:162)
+  sl, pad_len = prepare_pcm(pcm, g)
+  assert pad_len == 26 and sl.shape == (1, 128 * (26 * 5 - 1) + 512)
+  assert np.all(sl[0, :16000] == 1) and np.all(sl[0, 16000:] == 0)
+  base = np.arange(257, dtype=np.float32)[None]
+  seq = splice_coeff(base, np.full((1, 4, 64), -1, np.float32))
+  assert seq.shape == (1, 4, 257) and np.all(seq[0, :, :80] == base[0, :80]) and np.all(seq[0, :, 80:144] == -1)
+  assert np.all(seq[0, 2, 144:] == base[0, 144:])
+  g2 = DataGenerator(CFG)
+  lm = np.zeros((1, 136))
+  lm[0, [72, 78]] = [0, 4]; lm[0, [75, 83]] = [1, -1]; lm[0, [77, 81]] = [1, -1]
+  lm[0, [84, 90]] = [0, 4]; lm[0, [87, 95]] = [1, -1]; lm[0, [89, 93]] = [1, -1]
+  assert g2.ear_compute(lm)[0, 0] == pytest.approx(1.0)      # (2+2)/4 per eye
+
+
+def test_pixrefer_sample_packing_layout():
+  """generator.py:1006-1019: inputs = (example 3dface, current 3dface); fg_inputs = (example tgt*mask, current tgt*mask)."""
+  from voicepuppet_amd.generator.generator import pack_sample
+  S = 4
+  rng = np.random.default_rng(0)
+  ex, cur = rng.uniform(size=(S, 3 * S, 3)).astype(np.float32), rng.uniform(size=(S, 3 * S, 3)).astype(np.float32)
+  inputs, fg, tgt, msk = pack_sample(ex, cur, S)
+  np.testing.assert_array_equal(inputs[..., 0:3], ex[:, S:2 * S])
+  np.testing.assert_array_equal(inputs[..., 3:6], cur[:, S:2 * S])
+  np.testing.assert_array_equal(fg[..., 0:3], ex[:, :S] * ex[:, 2 * S:])
+  np.testing.assert_array_equal(fg[..., 3:6], cur[:, :S] * cur[:, 2 * S:])
+  np.testing.assert_array_equal(tgt, cur[:, :S])
+  np.testing.assert_array_equal(msk, cur[:, 2 * S:])
+
+
+def test_dataset_iterator_and_session_shim():
+  from voicepuppet_amd.generator.generator import PixReferDataGenerator
+  from voicepuppet_amd.runtime import IteratorNext, Node, Session
+  g = PixReferDataGenerator(CFG)
+  p = g.params
+  p.batch_size, p.img_size = 3, 32
+  it = g.get_dataset().make_one_shot_iterator()
+  nodes = it.get_next()
+  assert [n.shape for n in nodes] == [(3, 32, 32, 6), (3, 32, 32, 6), (3, 32, 32, 3), (3, 32, 32, 3)]
+  assert all(isinstance(n, IteratorNext) for n in nodes)
+  b = it.next_batch()
+  assert [x.shape for x in b] == [n.shape for n in nodes] and all(x.dtype == np.float32 for x in b)
+  assert 0 <= b[2].min() and b[2].max() <= 1
+
+  class Owner(object):
+    calls = 0
+    def execute(self, names, feeds):
+      Owner.calls += 1
+      return {n: len(n) for n in names}
+  o = Owner()
+  sess = Session()
+  assert sess.run([Node(o, "ab"), Node(o, "abcd")]) == [2, 4] and Owner.calls == 1     # one execution per run
+  assert sess.run(Node(o, "xyz")) == 3
+
+
+def test_library_exports_every_declared_symbol():
+  from voicepuppet_amd import _lib
+  lib = _lib.lib()
+  header = open(os.path.join(ROOT, "include", "vp_hip.h")).read()
+  header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+  declared = sorted(set(re.findall(r"\b(vp_[a-z0-9_]+)\s*\(", header)))
+  assert len(declared) > 25
+  for name in declared:
+    assert hasattr(lib, name), "libvp_hip.so does not export %s" % name
+  assert set(declared) == set(_lib.exported_symbols()), set(declared) ^ set(_lib.exported_symbols())
+  assert lib.vp_version() >= 100
+  # manifests are host-side queries: usable without a GPU
+  d = _lib.PixReferDesc(1, 256, 64, 64, 1, 1, 500.0, 1.0, 0)
+  assert [lib.vp_pixrefer_param_count(ctypes.byref(d), w) for w in range(3)] == [35158852, 2769601, 1735488]
+  assert lib.vp_pixrefer_workspace_bytes(ctypes.byref(d)) > 0
+  bad = _lib.PixReferDesc(1, 100, 64, 64, 1, 1, 500.0, 1.0, 0)
+  assert lib.vp_pixrefer_workspace_bytes(ctypes.byref(bad)) == 0                        # height must be a multiple of 256
+  assert lib.vp_bfmnet_param_count() > 7_000_000
+
+
+def test_missing_config_exits_with_status_zero(tmp_path):
+  """train_pixrefer.py:24-32: logger.error + exit(0)."""
+  from voicepuppet_amd.pixrefer import train_pixrefer
+  with pytest.raises(SystemExit) as e:
+    train_pixrefer.main(["--config_path", str(tmp_path / "nope.yml")])
+  assert e.value.code == 0
+  with pytest.raises(SystemExit) as e:
+    train_pixrefer.main([])
+  assert e.value.code == 0

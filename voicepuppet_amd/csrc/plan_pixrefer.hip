@@ -166,8 +166,8 @@ static int add_layer(Net& n, const std::string& prefix, const std::string& scope
   return L.out;
 }
 
-static void build_generator(Net& n, int N, int H, int ngf) {
-  n.batch = N; n.groups = 1;
+static void build_generator(Net& n, int N, int H, int ngf, int groups = 1) {
+  n.batch = N; n.groups = groups;
   const int tin = add_tensor(n, "inputs", N, H, H, 8, false, true);
   const int tfg = add_tensor(n, "fg_inputs", N, H, H, 8, false, true);
   const char* CK = "conv2d/kernel"; const char* CB = "conv2d/bias";
@@ -340,7 +340,7 @@ static void init_handle(vp_pixrefer* h, const vp_pixrefer_desc* d) {
   h->d = *d;
   h->bf16 = d->dtype == VP_BF16;
   h->es = h->bf16 ? 2 : 4;
-  build_generator(h->G, d->batch, d->height, d->ngf);
+  build_generator(h->G, d->batch, d->height, d->ngf, (!d->training && d->per_sample_bn) ? d->batch : 1);
   size_t smax = 0;
   plan_net(h->G, h->bf16, d->training, d->training, 0, &smax);
   if (d->training) {

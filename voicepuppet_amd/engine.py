@@ -39,13 +39,13 @@ class PixReferEngine:
   """One replica of the PixReferNet graph (pixrefer.py:356-438) on the current device."""
 
   def __init__(self, batch, height, ngf=64, ndf=64, dtype="bf16", training=True, l1_weight=500.0, gan_weight=1.0,
-               device=None):
+               device=None, per_sample_bn=False):
     if not torch.cuda.is_available():
       raise RuntimeError("PixReferEngine needs an MI355X (no CPU fallback)")
     self.L = _lib.lib()
     self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
     self.desc = PixReferDesc(batch, height, ngf, ndf, VP_BF16 if dtype == "bf16" else VP_F32, 1 if training else 0,
-                             l1_weight, gan_weight)
+                             l1_weight, gan_weight, 1 if (per_sample_bn and not training) else 0)
     self.training = training
     self.compute_dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
     d = ctypes.byref(self.desc)
@@ -133,15 +133,13 @@ class PixReferEngine:
     """One iteration of train_pixrefer.py:136-143 on this replica: forward, both backward passes,
     (data parallel: RCCL all-reduce-mean of the two gradient arenas, the discriminator's overlapped
     with the generator backward), Adam(D) then Adam(G)."""
-    import torch.distributed as dist
+    from .parallel import allreduce_mean
     self.forward(inputs, fg_inputs, targets, masks)
     self.backward_d()
-    wd = None
-    if group is not None and dist.get_world_size(group) > 1:
-      wd = dist.all_reduce(self.grads_d, op=dist.ReduceOp.AVG, group=group, async_op=True)
+    wd = allreduce_mean(self.grads_d, group, async_op=True) if group is not None else None
     self.backward_g()
     if wd is not None:
-      wg = dist.all_reduce(self.grads_g, op=dist.ReduceOp.AVG, group=group, async_op=True)
+      wg = allreduce_mean(self.grads_g, group, async_op=True)
       wd.wait()
       wg.wait()
     self.adam_step(lr, beta1)

@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+# -*- encoding: utf-8 -*-
+"""End-to-end inference, same CLI as the reference (voicepuppet/pixrefer/infer_bfmvid.py):
+
+    python voicepuppet/pixrefer/infer_bfmvid.py --config_path config/params.yml <image 1536x512> <audio.wav>
+
+wav -> log-mel -> BFMNet -> 64 expression coefficients per video frame -> (3-D face conditioning image) ->
+PixReferNet -> output/<i>.jpg (-> ffmpeg mux when ffmpeg exists).
+
+The per-frame conditioning image needs the BFM reconstruction + rasteriser (utils/reconstruct_mesh.py,
+utils/cython/mesh_core.cpp) and their external assets (BFM_model_front.mat, FaceReconModel.pb, the dlib/MXNet
+aligners).  Those are the "next" rows of SURVEY.md 8f; without them every frame is conditioned on the 3-D face
+panel of the input image (a warning is printed), which still exercises audio -> coefficients -> generator.
+Frames are batched on the device with per-sample batch-norm statistics, which is arithmetically the
+reference's batch-1 loop (infer_bfmvid.py:231-243).
+"""
+import logging
+import os
+import shutil
+import subprocess
+import sys
+from optparse import OptionParser
+
+import numpy as np
+
+sys.path.append(os.getcwd())
+
+from voicepuppet_amd.bfmnet.bfmnet import BFMNet
+from voicepuppet_amd.generator.generator import DataGenerator
+from voicepuppet_amd.generator.loader import ImageLoader, WavLoader
+from voicepuppet_amd.pixrefer.pixrefer import PixReferNet
+from voicepuppet_amd.runtime import Session, convert_to_tensor, placeholder
+
+logging.basicConfig(level=logging.INFO, format='%(asctime)s - %(name)s - %(levelname)s - %(message)s')
+logger = logging.getLogger(__name__)
+
+
+def prepare_pcm(pcm, gen):
+  """infer_bfmvid.py:162-167: pad so that the mel sequence is exactly pad_len * frame_mfcc_scale frames."""
+  pad_len = int(1 + pcm.shape[0] / gen.frame_wav_scale)
+  pcm_length = gen.hop_step * (pad_len * gen.frame_mfcc_scale - 1) + gen.win_length
+  if (pcm.shape[0] < pcm_length):
+    pcm = np.pad(pcm, (0, pcm_length - pcm.shape[0]), 'constant', constant_values=(0))
+  return pcm[:pcm_length][np.newaxis, :], pad_len
+
+
+def splice_coeff(bfmcoeff, expr_seq):
+  """infer_bfmvid.py:223-224: identity 0:80 and 144:257 from the photo, expression 80:144 predicted."""
+  tiled = np.tile(bfmcoeff[:, np.newaxis, :], [1, expr_seq.shape[1], 1])
+  return np.concatenate([tiled[:, :, :80], expr_seq, tiled[:, :, 144:]], axis=2)
+
+
+def main(argv=None):
+  cmd_parser = OptionParser(usage="usage: %prog [options] --config_path <> image audio")
+  cmd_parser.add_option('--config_path', type="string", dest="config_path", help='the config yaml file')
+  cmd_parser.add_option('--frame_batch', type="int", dest="frame_batch", default=8, help='frames per device batch')
+  opts, argv = cmd_parser.parse_args(argv)
+
+  if (opts.config_path is None):
+    logger.error('Please check your parameters.')
+    exit(0)
+  config_path = opts.config_path
+  if (not os.path.exists(config_path)):
+    logger.error('config_path not exists')
+    exit(0)
+
+  image_file, audio_file = argv
+
+  if not os.path.exists('output'):
+    os.makedirs('output')
+  for file in os.listdir('output'):
+    p = os.path.join('output', file)
+    shutil.rmtree(p) if os.path.isdir(p) else os.remove(p)
+
+  batch_size = 1
+  ### Generator for inference setting
+  infer_generator = DataGenerator(config_path)
+  params = infer_generator.params
+  params.batch_size = batch_size
+  infer_generator.set_params(params)
+  pcm = WavLoader(sr=infer_generator.sample_rate).get_data(audio_file)
+  pcm_slice, pad_len = prepare_pcm(pcm, infer_generator)
+  mfcc = infer_generator.extract_mfcc(pcm_slice)
+
+  img_size = 512
+  img = ImageLoader().get_data(image_file)[:, :, ::-1]      # RGB float in [0,1], 512 x 1536
+  face3d_refer = img[:, 512:512 * 2, :]
+  fg_refer = img[:, :512, :] * img[:, 512 * 2:, :]
+  img = img[:, :512, :]
+
+  with Session() as sess:
+    seq_len = convert_to_tensor(np.array([pad_len], dtype=np.int32))
+    ear = convert_to_tensor(np.random.rand(1, pad_len, 1).astype(np.float32) / 100)
+
+    ### BFMNet setting
+    bfmnet = BFMNet(config_path)
+    params = bfmnet.params
+    params.batch_size = 1
+    bfmnet.set_params(params)
+    bfmnet_nodes = bfmnet.build_inference_op(ear, mfcc, seq_len)
+
+    ### Vid2VidNet setting
+    nb = max(1, min(opts.frame_batch, pad_len))
+    vid2vidnet = PixReferNet(config_path)
+    params = vid2vidnet.params
+    params.batch_size = nb
+    params.add_hparam('is_training', False)
+    vid2vidnet.set_params(params)
+    inputs_holder = placeholder([None, img_size, img_size, 6])
+    fg_inputs_holder = placeholder([None, img_size, img_size, 3])
+    targets_holder = placeholder([None, img_size, img_size, 3])
+    vid2vid_nodes = vid2vidnet.build_inference_op(inputs_holder, fg_inputs_holder, targets_holder)
+
+    for net, ckpt in ((bfmnet, 'ckpt_bfmnet/bfmnet-65000.npz'), (vid2vidnet, 'ckpt_pixrefer/pixrefernet-20000.npz')):
+      if os.path.exists(ckpt):
+        net.restore(ckpt)
+      else:
+        logger.warning('%s not found: running with randomly initialised weights', ckpt)
+    if not os.path.exists('ckpt_bfmnet/bfmnet-65000.npz'):
+      bfmnet.init_variables()
+
+    ### Run inference
+    bfm_coeff_seq = sess.run(bfmnet_nodes['BFMCoeffDecoder'])
+    logger.warning('BFM assets unavailable: conditioning every frame on the reference 3-D face panel')
+
+    T = bfm_coeff_seq.shape[1]
+    inputs = np.zeros([nb, img_size, img_size, 6], dtype=np.float32)
+    fg_inputs = np.zeros([nb, img_size, img_size, 3], dtype=np.float32)
+    targets = np.zeros([nb, img_size, img_size, 3], dtype=np.float32)
+    inputs[:, ..., 0:3] = face3d_refer
+    fg_inputs[:, ..., 0:3] = fg_refer
+    from PIL import Image
+    for i0 in range(0, T, nb):
+      for k in range(nb):
+        i = min(i0 + k, T - 1)
+        inputs[k, ..., 3:6] = face3d_refer
+        bg = 'background/{}.jpg'.format(i % 100 + 1)
+        targets[k] = (ImageLoader(resize=(img_size, img_size)).get_data(bg)[:, :, ::-1] if os.path.exists(bg) else 0.5)
+      frames, last = sess.run([vid2vid_nodes['Outputs'], vid2vid_nodes['Outputs_FG']],
+                              feed_dict={inputs_holder: inputs, fg_inputs_holder: fg_inputs, targets_holder: targets})
+      for k in range(nb):
+        if i0 + k < T:
+          Image.fromarray((np.clip(frames[k], 0, 1) * 255).astype(np.uint8)).save('output/{}.jpg'.format(i0 + k))
+
+    if shutil.which('ffmpeg'):
+      cmd = 'ffmpeg -i output/%d.jpg -i ' + audio_file + ' -c:v libx264 -c:a aac -strict experimental -y output.mp4'
+      subprocess.call(cmd, shell=True)
+    else:
+      logger.warning('ffmpeg not found: frames are in output/, no mp4 written')
+
+
+if (__name__ == '__main__'):
+  main()

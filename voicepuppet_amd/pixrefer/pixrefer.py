@@ -1,0 +1,217 @@
+"""PixReferNet with the reference's class surface (voicepuppet/pixrefer/pixrefer.py:15-438) on MI355X.
+
+`build_train_op` / `build_inference_op` return the same `nodes` dictionary keys as the reference; the
+values are handles executed by voicepuppet_amd.runtime.Session.  The graph itself (generator, three
+discriminator applications, VGG-16 trunk, losses, two TF-style Adam optimisers) is the HIP step executor
+behind the C ABI (include/vp_hip.h); nothing here computes on the host.
+"""
+import logging
+import os
+
+import numpy as np
+
+from ..builder import ModelBuilder
+from ..config.configure import YParams
+from ..runtime import Constant, IteratorNext, Node, Placeholder
+
+logger = logging.getLogger(__name__)
+
+TRAIN_KEYS = ['Inputs', 'FGInputs', 'Targets', 'Masks', 'Outputs', 'Alphas', 'Outputs_FG', 'Predict_real', 'Predict_fake',
+              'Perceptual_loss', 'Discrim_loss', 'Gen_loss_GAN', 'Gen_loss_L1', 'Gen_loss', 'Global_step', 'Lr', 'Train_op',
+              'Discrim_grads_and_vars', 'Gen_grads_and_vars']
+INFER_KEYS = ['Inputs', 'FGInputs', 'Targets', 'Outputs', 'Alphas', 'Outputs_FG']
+
+
+class PixReferNet(ModelBuilder):
+
+  def __init__(self, config_path):
+    if (not os.path.exists(config_path)):
+      logger.error('config_path not exists.')
+      exit(0)
+    self.__params = PixReferNet.default_hparams(config_path)
+    self.engine = None
+    self.global_step = 0
+
+  @staticmethod
+  def default_hparams(config_path, name='default'):
+    params = YParams(config_path, name)
+    params.add_hparam('separable_conv', False)
+    params.add_hparam('ngf', 64)
+    params.add_hparam('ndf', 64)
+    params.add_hparam('l1_weight', 500.0)
+    params.add_hparam('gan_weight', 1.0)
+    params.training['learning_rate'] = 0.0003
+    params.training['beta1'] = 0.5
+    params.training['decay_rate'] = 0.999
+    return params
+
+  @property
+  def params(self):
+    return self.__params
+
+  def set_params(self, params):
+    self.learning_rate = params.training['learning_rate']
+    self.beta1 = params.training['beta1']
+    self.decay_rate = params.training['decay_rate']
+    self.decay_steps = params.training['decay_steps']
+    self.batch_size = params.batch_size
+    self.separable_conv = params.separable_conv
+    if self.separable_conv:
+      raise NotImplementedError('separable_conv=True is a dead branch of the reference (pixrefer.py:69-71) and is not built')
+    self.ngf = params.ngf
+    self.ndf = params.ndf
+    self.l1_weight = params.l1_weight
+    self.gan_weight = params.gan_weight
+    self.dtype = (params.get('amd') or {}).get('dtype', 'bf16')
+    self.is_training = params.is_training
+    if (params.is_training):
+      self.sess = params.sess
+      self.vgg_model_path = params.vgg_model_path
+
+  # ---- graph construction ---------------------------------------------------------------------
+  def _make_engine(self, height, training):
+    from ..engine import PixReferEngine
+    self.engine = PixReferEngine(self.batch_size, height, self.ngf, self.ndf, dtype=self.dtype, training=training,
+                                 l1_weight=self.l1_weight, gan_weight=self.gan_weight, per_sample_bn=not training)
+    self.init_variables()
+
+  def init_variables(self, seed=None):
+    """tf.variables_initializer of the non-VGG variables (train_pixrefer.py:89-92): kernels N(0,0.02),
+    gamma N(1,0.02), bias/beta 0 (pixrefer.py:64,68,100-101); VGG restored from vgg_model_path when it is
+    an .npz of TF-named arrays (a TF checkpoint importer is a queued follow-up), else He-normal."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for which in (0, 1):
+      if self.engine.arena(which) is None:
+        continue
+      for name, _, shape in self.engine.manifests[which]:
+        if name.endswith('kernel'):
+          p[name] = rng.normal(0, 0.02, shape).astype(np.float32)
+        elif name.endswith('gamma'):
+          p[name] = rng.normal(1.0, 0.02, shape).astype(np.float32)
+        else:
+          p[name] = np.zeros(shape, np.float32)
+    if self.engine.arena(2) is not None:
+      path = getattr(self, 'vgg_model_path', None)
+      npz = None
+      for cand in (path, (path or '') + '.npz'):
+        if cand and os.path.exists(cand) and cand.endswith('.npz'):
+          npz = np.load(cand)
+      for name, _, shape in self.engine.manifests[2]:
+        if npz is not None and name in npz:
+          p[name] = npz[name].astype(np.float32)
+        elif name.endswith('weights'):
+          p[name] = rng.normal(0, np.sqrt(2.0 / (shape[0] * shape[1] * shape[2])), shape).astype(np.float32)
+        else:
+          p[name] = np.zeros(shape, np.float32)
+      if npz is None:
+        logger.warning('vgg_16 weights not found at %s: perceptual trunk uses He-normal stand-in weights', path)
+    self.engine.load_params(p)
+
+  def build_network(self, inputs, fg_inputs, targets, trainable=True):
+    raise NotImplementedError('the network is built inside libvp_hip.so; use build_train_op / build_inference_op')
+
+  def _bind(self, keys, feeds, training):
+    h = None
+    for f in feeds.values():
+      if f is not None and f.shape is not None and len(f.shape) == 4:
+        h = int(f.shape[1])
+        break
+    if h is None:
+      raise ValueError('cannot infer the image size from the input nodes')
+    self._feeds = feeds
+    self._make_engine(h, training)
+    return {k: Node(self, k) for k in keys}
+
+  def build_train_op(self, inputs, fg_inputs, targets, masks):
+    return self._bind(TRAIN_KEYS, {'Inputs': inputs, 'FGInputs': fg_inputs, 'Targets': targets, 'Masks': masks}, True)
+
+  def build_inference_op(self, inputs, fg_inputs, targets):
+    return self._bind(INFER_KEYS, {'Inputs': inputs, 'FGInputs': fg_inputs, 'Targets': targets}, False)
+
+  # ---- execution (called by runtime.Session.run) --------------------------------------------------
+  def _resolve(self, feed_dict):
+    import torch
+    vals, pulled = {}, {}
+    for key, node in self._feeds.items():
+      if isinstance(node, IteratorNext):
+        if id(node.iterator) not in pulled:
+          pulled[id(node.iterator)] = node.iterator.next_batch()
+        v = pulled[id(node.iterator)][node.index]
+      elif isinstance(node, Placeholder):
+        if node not in feed_dict:
+          raise ValueError('placeholder %s (%s) was not fed' % (key, node.name))
+        v = feed_dict[node]
+      elif isinstance(node, Constant):
+        v = node.value
+      else:
+        v = node
+      vals[key] = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v, dtype=np.float32))
+      vals[key] = vals[key].to(self.engine.device, torch.float32)
+    return vals
+
+  def current_lr(self):
+    return self.learning_rate * self.decay_rate ** (self.global_step // self.decay_steps)   # staircase
+
+  def execute(self, names, feed_dict):
+    eng = self.engine
+    v = self._resolve(feed_dict)
+    lr = self.current_lr()
+    if 'Train_op' in names:
+      eng.train_step(v['Inputs'], v['FGInputs'], v['Targets'], v['Masks'], lr, self.beta1, group=getattr(self, 'group', None))
+      self.global_step += 2          # both apply_gradients increment global_step (pixrefer.py:400,407)
+    else:
+      eng.forward(v['Inputs'], v['FGInputs'], v['Targets'], v.get('Masks'))
+    out = {}
+    losses = eng.losses() if eng.training else {}
+    for n in names:
+      if n in ('Inputs', 'FGInputs', 'Targets', 'Masks'):
+        out[n] = v[n].cpu().numpy()
+      elif n == 'Outputs':
+        out[n] = ((eng.tensor('Outputs_raw') + 1) / 2).cpu().numpy()                      # deprocess
+      elif n == 'Alphas':
+        out[n] = ((eng.tensor('gen_out4')[..., 3:] + 1) / 2).repeat(1, 1, 1, 3).cpu().numpy()
+      elif n == 'Outputs_FG':
+        fg = eng.tensor('Outputs_FG')
+        if not eng.training:   # build_inference_op quirk: deprocess(Outputs_FG + Alphas - 1)  (pixrefer.py:436)
+          fg = ((fg + (eng.tensor('gen_out4')[..., 3:] + 1) / 2 - 1) + 1) / 2
+        out[n] = fg.cpu().numpy()
+      elif n in ('Predict_real', 'Predict_fake'):
+        p = eng.tensor('Predict')
+        out[n] = p[0 if n == 'Predict_real' else 1].unsqueeze(-1).cpu().numpy()
+      elif n in losses:
+        out[n] = np.float32(losses[n])
+      elif n == 'Global_step':
+        out[n] = self.global_step
+      elif n == 'Lr':
+        out[n] = np.float32(lr)
+      elif n == 'Train_op':
+        out[n] = None
+      elif n in ('Discrim_grads_and_vars', 'Gen_grads_and_vars'):
+        which = 1 if n.startswith('Discrim') else 0
+        g = eng.get_params(which, src=eng.grads_d if which else eng.grads_g)
+        w = eng.get_params(which)
+        out[n] = [(g[k], w[k]) for k, _, _ in eng.manifests[which]]
+      else:
+        raise KeyError(n)
+    return out
+
+  # ---- checkpoints (own format: .npz keyed by the TF variable names) ------------------------------
+  def save(self, path):
+    eng = self.engine
+    d = {}
+    for which in (0, 1):
+      d.update(eng.get_params(which))
+      for tag, idx in (('Adam', 0), ('Adam_1', 1)):
+        st = eng.get_params(which, src=eng.adam['g' if which == 0 else 'd'][idx])
+        d.update({'%s/%s' % (k, tag): v for k, v in st.items()})
+    d['global_step'] = np.int64(self.global_step)
+    d['adam_t'] = np.int64([eng.t_g, eng.t_d])
+    np.savez(path, **d)
+    return path
+
+  def restore(self, path):
+    z = np.load(path)
+    self.engine.load_params({k: z[k] for k in z.files})
+    if 'global_step' in z.files:
+      self.global_step = int(z['global_step'])

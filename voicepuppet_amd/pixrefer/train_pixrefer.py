@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+# -*- encoding: utf-8 -*-
+"""PixReferNet training entry point, same CLI as the reference (voicepuppet/pixrefer/train_pixrefer.py):
+
+    python voicepuppet/pixrefer/train_pixrefer.py --config_path config/params.yml
+
+One process per GPU; under torch.distributed.run (WORLD_SIZE > 1) the G/D gradient arenas are
+all-reduced over RCCL every step (plain data parallel, per-replica batch statistics).
+Extra, optional flags (defaults reproduce the reference run): --steps, --batch_size, --img_size.
+"""
+import logging
+import os
+import sys
+import time
+from optparse import OptionParser
+
+import numpy as np
+
+sys.path.append(os.getcwd())
+
+from voicepuppet_amd.generator.generator import PixReferDataGenerator
+from voicepuppet_amd.pixrefer.pixrefer import PixReferNet
+from voicepuppet_amd.runtime import Session
+
+logging.basicConfig(level=logging.INFO, format='%(asctime)s - %(name)s - %(levelname)s - %(message)s')
+logger = logging.getLogger(__name__)
+
+
+def mkdir(path):
+  if not os.path.exists(path):
+    os.makedirs(path)
+
+
+def save_image(path, arr):
+  from PIL import Image
+  Image.fromarray((np.clip(arr, 0, 1) * 255).astype(np.uint8)).save(path)
+
+
+def main(argv=None):
+  cmd_parser = OptionParser(usage="usage: %prog [options] --config_path <>")
+  cmd_parser.add_option('--config_path', type="string", dest="config_path", help='the config yaml file')
+  cmd_parser.add_option('--steps', type="int", dest="steps", default=None, help='iterations to run (default: training.epochs)')
+  cmd_parser.add_option('--batch_size', type="int", dest="batch_size", default=2, help='per-GPU batch (reference: 2)')
+  cmd_parser.add_option('--img_size', type="int", dest="img_size", default=None, help='override amd.img_size')
+  opts, _ = cmd_parser.parse_args(argv)
+
+  if (opts.config_path is None):
+    logger.error('Please check your parameters.')
+    exit(0)
+  config_path = opts.config_path
+  if (not os.path.exists(config_path)):
+    logger.error('config_path not exists')
+    exit(0)
+
+  import torch
+  import torch.distributed as dist
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+  group = None
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl')
+    group = dist.group.WORLD
+
+  batch_size = opts.batch_size
+  ### Generator for training setting
+  train_generator = PixReferDataGenerator(config_path)
+  params = train_generator.params
+  params.dataset_path = params.train_dataset_path
+  params.batch_size = batch_size
+  if opts.img_size:
+    params.img_size = opts.img_size
+  train_generator.set_params(params)
+  train_dataset = train_generator.get_dataset()
+
+  sess = Session()
+  train_iter = train_dataset.make_one_shot_iterator()
+
+  ### Vid2VidNet setting
+  vid2vidnet = PixReferNet(config_path)
+  params = vid2vidnet.params
+  epochs = opts.steps if opts.steps is not None else params.training['epochs']
+  params.add_hparam('max_to_keep', 2)
+  params.add_hparam('save_dir', 'ckpt_pixrefer')
+  params.add_hparam('save_name', 'pixrefernet')
+  params.add_hparam('save_step', 5000)
+  params.add_hparam('summary_step', 100)
+  params.add_hparam('summary_dir', 'log/summary_pixrefer')
+  params.batch_size = batch_size
+  params.add_hparam('is_training', True)
+  params.sess = sess
+  params.vgg_model_path = os.path.join(params.model_dir, 'vgg_16.ckpt')
+  vid2vidnet.set_params(params)
+  vid2vidnet.group = group
+
+  if rank == 0:
+    mkdir(params.save_dir)
+    mkdir(params.summary_dir)
+
+  train_nodes = vid2vidnet.build_train_op(*train_iter.get_next())
+  if world > 1:   # identical initial weights on every replica
+    for a in (vid2vidnet.engine.params_g, vid2vidnet.engine.params_d, vid2vidnet.engine.params_vgg):
+      dist.broadcast(a, 0)
+    vid2vidnet.engine.params_changed()
+
+  saved = []
+  t0 = time.time()
+  for i in range(epochs):
+    ### Run training
+    fetch = [train_nodes['Train_op'], train_nodes['Gen_loss_GAN'], train_nodes['Gen_loss_L1'], train_nodes['Discrim_loss'],
+             train_nodes['Lr'], train_nodes['Global_step']]
+    _, gen_loss_GAN, gen_loss_L1, discrim_loss, lr, global_step = sess.run(fetch)
+    if (global_step % params.summary_step == 0 and rank == 0):
+      print('Step {}, Lr= {:.2e}: \n\tgen_loss_GAN= {:.3f}, \n\tgen_loss_L1= {:.3f}, \n\tdiscrim_loss= {:.3f}'.format(
+          global_step, lr, gen_loss_GAN, gen_loss_L1, discrim_loss))
+      fps = (i + 1) * batch_size * world / (time.time() - t0)
+      logger.info('%.1f frames/s', fps)
+      eng = vid2vidnet.engine
+      save_image(os.path.join(params.summary_dir, 'outputs_%d.png' % global_step), ((eng.tensor('Outputs_raw')[0] + 1) / 2).cpu().numpy())
+
+    ### Save checkpoint
+    if (global_step % params.save_step == 0 and rank == 0):
+      path = vid2vidnet.save(os.path.join(params.save_dir, '%s-%d.npz' % (params.save_name, global_step)))
+      saved.append(path)
+      while len(saved) > params.max_to_keep:
+        os.remove(saved.pop(0))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if (__name__ == '__main__'):
+  main()
