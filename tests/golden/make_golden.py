@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""Generates the committed fixtures under tests/golden/ (run in the BUILD container only):
+
+  sample22_256.npz   the reference's inference fixture sample/22.jpg (1536x512 triptych: frame | 3-D face | matte)
+                     and background/1.jpg, decoded HERE with PIL and resized to 256x256 uint8, so that no JPEG
+                     decoder has to agree on the GPU box (BASELINE config 1 input)
+  ops.npz            toy-size conv / deconv / batch-norm / pool forward+backward results of the float64 oracle
+  mini_step.npz      one G+D step of a mini PixReferNet (ngf=ndf=8, N=1, 256x256) on sample22: losses, output
+                     crop, per-tensor gradient norms, post-Adam parameter checksums
+  logmel.npz         log-mel of a seeded 4096-sample chirp+noise, and the 257x80 mel matrix
+  bfmnet.npz         BFMNet coefficients for a seeded 5-frame clip (parameters regenerated from the seed)
+
+The reference itself cannot produce vectors for this path (TF1.x is not installable: SURVEY.md 8c), so these
+pin the ORACLE against drift and give the GPU tests fixed inputs; they are not reference-captured outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import audio_ref as ar
+from oracle import nn_ops as ops
+from oracle import pixrefer_ref as ref
+
+REF = "/root/reference"
+
+
+def sample22():
+  from PIL import Image
+  img = Image.open(os.path.join(REF, "sample", "22.jpg")).convert("RGB")
+  assert img.size == (1536, 512)
+  panels = [np.asarray(img.crop((k * 512, 0, (k + 1) * 512, 512)).resize((256, 256), Image.BILINEAR)) for k in range(3)]
+  bg = np.asarray(Image.open(os.path.join(REF, "background", "1.jpg")).convert("RGB").resize((256, 256), Image.BILINEAR))
+  np.savez_compressed(os.path.join(HERE, "sample22_256.npz"), frame=panels[0], face3d=panels[1], matte=panels[2], background=bg)
+  return panels, bg
+
+
+def toy_ops():
+  rng = np.random.default_rng(42)
+  d = {}
+  x, w, b = rng.normal(size=(2, 8, 8, 4)), rng.normal(size=(4, 4, 4, 6)), rng.normal(size=6)
+  d["conv_x"], d["conv_w"], d["conv_b"] = x, w, b
+  d["conv_s2_y"] = ops.conv2d_fwd(x, w, b, 2, 1)
+  dy = rng.normal(size=d["conv_s2_y"].shape)
+  d["conv_s2_dy"] = dy
+  d["conv_s2_dx"], d["conv_s2_dw"], d["conv_s2_db"] = ops.conv2d_bwd(x, w, dy, 2, 1)
+  d["conv_s1_y"] = ops.conv2d_fwd(x, w, b, 1, 1)
+  wd = rng.normal(size=(4, 4, 5, 4))
+  d["deconv_w"] = wd
+  d["deconv_y"] = ops.deconv4s2_fwd(x, wd, None)
+  dyd = rng.normal(size=d["deconv_y"].shape)
+  d["deconv_dy"] = dyd
+  d["deconv_dx"], d["deconv_dw"], _ = ops.deconv4s2_bwd(x, wd, dyd)
+  g, bt = rng.normal(1, 0.1, 4), rng.normal(0, 0.1, 4)
+  z, cache = ops.bn_train_fwd(x, g, bt)
+  d["bn_gamma"], d["bn_beta"], d["bn_z"] = g, bt, z
+  dz = rng.normal(size=x.shape)
+  d["bn_dz"] = dz
+  d["bn_dy"], d["bn_dgamma"], d["bn_dbeta"] = ops.bn_train_bwd(dz, cache)
+  y, idx = ops.maxpool2x2_fwd(x)
+  d["pool_y"] = y
+  d["pool_dx"] = ops.maxpool2x2_bwd(y * 0 + 1.5, idx, x.shape)
+  np.savez_compressed(os.path.join(HERE, "ops.npz"), **d)
+
+
+def mini_step(panels, bg):
+  ngf = ndf = 8
+  frame, face3d, matte = [p.astype(np.float64) / 255.0 for p in panels]
+  # inference-style packing of infer_bfmvid.py:175-178,226-229 used as a training sample (example == current)
+  inputs = np.concatenate([face3d, face3d], axis=-1)[None]
+  fg = np.concatenate([frame * matte, frame * matte], axis=-1)[None]
+  targets, masks = frame[None], matte[None]
+  p = ref.init_params(ngf, ndf, seed=7)
+  st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf)
+  nodes = st.step(inputs, fg, targets, masks)
+  inf = ref.inference(p, inputs, fg[..., :3], bg[None].astype(np.float64) / 255.0, ngf)
+  d = {"seed": 7, "ngf": ngf}
+  for k in ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss"):
+    d[k] = np.float64(nodes[k])
+  d["Outputs_crop"] = nodes["Outputs"][0, 96:160, 96:160]
+  d["Infer_Outputs_crop"] = inf["Outputs"][0, 96:160, 96:160]
+  d["Infer_Outputs_mean"] = inf["Outputs"].mean(axis=(0, 1, 2))
+  names = sorted(nodes["Gen_grads"]) + sorted(nodes["Discrim_grads"])
+  d["grad_names"] = np.array(names)
+  d["grad_norms"] = np.array([np.linalg.norm(nodes["Gen_grads" if n.startswith("generator") else "Discrim_grads"][n]) for n in names])
+  d["param_sums_after"] = np.array([st.p[n].sum() for n in names])
+  np.savez_compressed(os.path.join(HERE, "mini_step.npz"), **d)
+
+
+def audio():
+  rng = np.random.default_rng(11)
+  t = np.arange(4096) / 16000.0
+  pcm = np.clip(0.1 * rng.normal(size=(1, 4096)) + 0.3 * np.sin(2 * np.pi * (100 + 3900 * t / t[-1] / 2) * t), -1, 1)
+  np.savez_compressed(os.path.join(HERE, "logmel.npz"), pcm=pcm.astype(np.float32), logmel=ar.extract_mfcc(pcm.astype(np.float32).astype(np.float64)),
+                      mel_matrix=ar.linear_to_mel_weight_matrix())
+  p = ar.init_bfmnet_params(21)
+  pcm5 = np.clip(0.2 * rng.normal(size=(1, ar.pcm_length_for(5))), -1, 1).astype(np.float32)
+  mf = ar.extract_mfcc(pcm5.astype(np.float64))
+  ears = np.full((1, 5, 1), 0.003)
+  out = ar.bfmnet_fwd(p, ears, mf, [5])
+  np.savez_compressed(os.path.join(HERE, "bfmnet.npz"), seed=21, pcm=pcm5, ears=ears, mfcc=mf, coeff=out["BFMCoeffDecoder"], enc=out["MfccEncoder"])
+
+
+if __name__ == "__main__":
+  panels, bg = sample22()
+  toy_ops()
+  mini_step(panels, bg)
+  audio()
+  for f in sorted(os.listdir(HERE)):
+    print(f, os.path.getsize(os.path.join(HERE, f)))

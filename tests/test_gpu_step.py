@@ -137,3 +137,38 @@ def test_inference_plan_matches_training_forward(oracle_step):
                       *[b.astype(np.float64) for b in (o["batch"][0], o["batch"][1][..., :3], o["batch"][2])], ngf=o["ngf"])
   got = (eng.tensor("Outputs_raw").cpu().numpy() + 1) / 2
   assert gu.rel_l2(got, out["Outputs"]) < 1e-3
+
+
+def test_sample22_fixture_forward_and_step_vs_golden():
+  """BASELINE config 1: generator forward on the reference's own sample/22.jpg (decoded fixture), plus one G+D
+  step, against the golden values the float64 oracle produced in the build container."""
+  import os
+  G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+  s, d = np.load(os.path.join(G, "sample22_256.npz")), np.load(os.path.join(G, "mini_step.npz"))
+  frame, face3d, matte, bg = [s[k].astype(np.float32) / 255.0 for k in ("frame", "face3d", "matte", "background")]
+  inputs = np.concatenate([face3d, face3d], axis=-1)[None]
+  fg = np.concatenate([frame * matte, frame * matte], axis=-1)[None]
+  ngf = int(d["ngf"])
+  p = ref.init_params(ngf, ngf, seed=int(d["seed"]), dtype=np.float32)
+  dev = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+  inf = PixReferEngine(1, 256, ngf, ngf, dtype="f32", training=False)
+  inf.load_params(p)
+  inf.forward(dev(inputs), dev(fg[..., :3]), dev(bg[None]))
+  out = (inf.tensor("Outputs_raw").cpu().numpy() + 1) / 2
+  assert gu.rel_l2(out[0, 96:160, 96:160], d["Infer_Outputs_crop"]) < 1e-3
+  np.testing.assert_allclose(out.mean(axis=(0, 1, 2)), d["Infer_Outputs_mean"], rtol=1e-4)
+  eng = PixReferEngine(1, 256, ngf, ngf, dtype="f32", training=True)
+  eng.load_params(p)
+  eng.forward(dev(inputs), dev(fg), dev(frame[None]), dev(matte[None]))
+  eng.backward()
+  got = eng.losses()
+  for k in ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss"):
+    assert got[k] == pytest.approx(float(d[k]), rel=1e-4), k
+  assert gu.rel_l2((eng.tensor("Outputs_raw").cpu().numpy()[0, 96:160, 96:160] + 1) / 2, d["Outputs_crop"]) < 1e-3
+  names = list(d["grad_names"])
+  gg, gd = eng.get_params(0, src=eng.grads_g), eng.get_params(1, src=eng.grads_d)
+  norms = np.array([np.linalg.norm(gg[n] if n.startswith("generator") else gd[n]) for n in names])
+  ok = d["grad_norms"] > 0
+  # N=1: batch-norm over a single 1x1 bottleneck pixel kills the gradient of the deepest layers (norm ~ 0); compare the rest
+  big = ok & (d["grad_norms"] > 1e-6 * d["grad_norms"].max())
+  np.testing.assert_allclose(norms[big], d["grad_norms"][big], rtol=2e-2)
