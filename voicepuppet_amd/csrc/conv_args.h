@@ -52,7 +52,6 @@ struct IgemmArgs {
   int splitk;
   float* partial;           // [nclass][splitk][P][CoutPad] when splitk > 1
   int vec_epi;              // staged (LDS) epilogue with 16-byte row stores (set by the launcher)
-  int dbg;                  // ablation switches (VP_DBG): 1 = skip MFMA, 2 = skip DMA after the prologue
   const void* zeros;        // >= 16 bytes of zeros (padding source of the LDS-DMA loader); null: register loader
 };
 

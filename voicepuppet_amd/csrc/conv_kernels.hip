@@ -512,9 +512,9 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
         __builtin_amdgcn_s_barrier();   // every wave's DMA of chunk kc landed; every wave is done reading chunk kc-1
         asm volatile("" ::: "memory");
         const int st2 = st == 0 ? 2 : st - 1;   // == (st + 2) % 3, the buffer chunk kc-1 used
-        if (kc + 2 < kc1 && !(a.dbg & 2)) issue(kc + 2, st2);
+        if (kc + 2 < kc1) issue(kc + 2, st2);
         const uint4* la = lds + st * BUF;
-        if (!(a.dbg & 1)) mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
+        mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
         st = st == 2 ? 0 : st + 1;
       }
     } else {
@@ -815,7 +815,6 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   static const int dbg = getenv("VP_DBG") ? atoi(getenv("VP_DBG")) : 0;
   if (plain) {
     IgemmArgs b = a;
-    b.dbg = dbg & 3;
     b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
     hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, b);
     return hipGetLastError();
