@@ -72,6 +72,7 @@ struct WgradArgs {
   float* partial;           // [splitk][Mpad][Dpad]
   float* dW;                // [ntaps][Greal][Dreal]
   int Greal, Dreal, accumulate;
+  const void* zeros;        // >= 16 zero bytes: enables the branch-free loader for prologue-free operands
 };
 
 }  // namespace vp

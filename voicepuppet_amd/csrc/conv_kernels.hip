@@ -601,7 +601,49 @@ template <> struct Transposer<bf16> {
   }
 };
 
-template <typename T, int WC, int WP, int TC, int TP, int KCH>
+// One loader task: E consecutive pixels x E consecutive channels of ONE source tensor, fixed for the whole
+// K loop (which tensor, which channels, which tap); only the pixel window moves.
+template <typename T> struct WgTask {
+  const T* base;      // source pointer + channel offset (plain path)
+  int C;              // channels of that source (pixel stride)
+  int s, dh, dw;      // source pixel = (q*s + dh, r*s + dw)
+  int Hs, Ws;
+  int ch;             // channel index inside the PixSrc (prologue path)
+  bool ok;
+};
+
+template <typename T, int E, int KCH, bool PLAIN>
+__device__ __forceinline__ void wg_stage_load(const WgradArgs& a, const WgTask<T>& t, const PixSrc& src, int it, int kq, int P,
+                                              uint4 (&rin)[E]) {
+  constexpr int KC = 4 * E;
+  int pidx = it * (KC * KCH) + kq * E;
+  const int hw = a.Hb * a.Wb;
+  int n = pidx / hw;
+  const int rem = pidx - n * hw;
+  int q = rem / a.Wb;
+  int r = rem - q * a.Wb;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int ih = q * t.s + t.dh, iw = r * t.s + t.dw;
+    const bool ok = t.ok && (pidx + e < P);
+    if (PLAIN) {
+      const bool inb = ok && (unsigned)ih < (unsigned)t.Hs && (unsigned)iw < (unsigned)t.Ws;
+      const T* p = t.base + ((size_t)(n * t.Hs + ih) * t.Ws + iw) * t.C;
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(inb ? (const void*)p : a.zeros);
+      rin[e] = make_uint4(v.x, v.y, v.z, v.w);    // unconditional global load: all E loads stay in flight
+    } else {
+      rin[e] = load_pix_piece<T>(src, n, ih, iw, t.Hs, t.Ws, t.ch, ok);
+    }
+    const bool wrap = (r + 1 == a.Wb);
+    r = wrap ? 0 : r + 1;
+    const bool wrap2 = wrap && (q + 1 == a.Hb);
+    q = wrap ? (wrap2 ? 0 : q + 1) : q;
+    n += wrap2 ? 1 : 0;
+  }
+}
+
+template <typename T, int WC, int WP, int TC, int TP, int KCH, bool PLAIN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;           // KC pixels per 64-byte chunk; KCH chunks per iteration
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
@@ -619,27 +661,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int per = (niter + a.splitk - 1) / a.splitk;
   const int it0 = split * per, it1 = min(niter, it0 + per);
 
-  // loader task of this thread: E consecutive pixels x E consecutive channels
+  // this thread's loader task (A: gathered operand rows (tap, channel); B: dense operand channels)
   const bool isA = tid < TA;
-  const bool isB = !isA && tid < TA + TB;
+  const bool active = tid < TA + TB;
   const int tt = isA ? tid : tid - TA;
-  const int ncg = (isA ? BC : BP) / E;       // channel groups
+  const int ncg = (isA ? BC : BP) / E;
   const int cg = tt % ncg, kq = tt / ncg;    // channel group, pixel group (kq / 4 = chunk, kq % 4 = plane)
-  int tdh = 0, tdw = 0, gch = 0;
-  bool rowok = false;
-  if (isA) {
-    const int m = m_base + cg * E;
-    const int tap = m >> a.log2Gc;
-    gch = m & (a.Gc - 1);
-    rowok = tap < a.ntaps;
-    if (rowok) {
+  WgTask<T> task;
+  {
+    int ch, tap = 0;
+    if (isA) { const int m = m_base + cg * E; tap = m >> a.log2Gc; ch = m & (a.Gc - 1); task.ok = tap < a.ntaps; }
+    else { ch = d_base + cg * E; task.ok = ch < a.Dc; }
+    task.ok = task.ok && active;
+    int tdh = 0, tdw = 0;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) if (t == tap) { tdh = a.taps.dh[t]; tdw = a.taps.dw[t]; }
-    }
-  } else if (isB) {
-    gch = d_base + cg * E;
-    rowok = gch < a.Dc;
+    for (int t = 0; t < 16; ++t) if (t == tap) { tdh = a.taps.dh[t]; tdw = a.taps.dw[t]; }
+    task.s = isA ? a.s : 1; task.dh = isA ? tdh : 0; task.dw = isA ? tdw : 0;
+    task.Hs = isA ? a.Hgin : a.Hb; task.Ws = isA ? a.Wgin : a.Wb;
+    task.ch = ch;
+    const int c0 = isA ? a.g.C[0] : a.d.C[0];
+    const int c1 = isA ? a.g.C[1] : a.d.C[1];
+    const void* p0 = isA ? a.g.ptr[0] : a.d.ptr[0];
+    const void* p1 = isA ? a.g.ptr[1] : a.d.ptr[1];
+    const bool second = ch >= c0;
+    task.C = second ? c1 : c0;
+    task.base = reinterpret_cast<const T*>(second ? p1 : p0) + (second ? ch - c0 : ch);
+    if (!task.ok) { task.base = reinterpret_cast<const T*>(a.zeros); task.C = 0; }
   }
+  const PixSrc& psrc = isA ? a.g : a.d;
 
   f32x4 acc[TC][TP];
 #pragma unroll
@@ -648,47 +697,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   uint4 rin[E], rout[E];
-  auto stage_load = [&](int it) {
-    if (!(isA || isB)) return;
-    int pidx = it * (KC * KCH) + kq * E;
-    const int hw = a.Hb * a.Wb;
-    int n = pidx / hw;
-    int rem = pidx - n * hw;
-    int q = rem / a.Wb;
-    int r = rem - q * a.Wb;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const bool ok = rowok && (pidx + e < P);
-      if (isA) rin[e] = load_pix_piece<T>(a.g, n, q * a.s + tdh, r * a.s + tdw, a.Hgin, a.Wgin, gch, ok);
-      else     rin[e] = load_pix_piece<T>(a.d, n, q, r, a.Hb, a.Wb, gch, ok);
-      if (++r == a.Wb) { r = 0; if (++q == a.Hb) { q = 0; ++n; } }
-    }
-  };
-  auto stage_store = [&](int buf) {
-    if (!(isA || isB)) return;
-    Transposer<T>::run(rin, rout);
-    uint4* base = lds + buf * BUF + (kq >> 2) * CH + (isA ? 0 : 4 * BC) + (kq & 3) * (isA ? BC : BP);
-#pragma unroll
-    for (int e = 0; e < E; ++e) base[lds_slot<1, E>(cg * E + e)] = rout[e];
-  };
-
   const int wc = wave / WP, wpi = wave - wc * WP;
   const int rowA0 = wc * TC * 16, rowB0 = wpi * TP * 16;
+  const int store_off = (kq >> 2) * CH + (isA ? 0 : 4 * BC) + (kq & 3) * (isA ? BC : BP);
 
   if (it0 < it1) {
-    stage_load(it0);
-    stage_store(0);
+    wg_stage_load<T, E, KCH, PLAIN>(a, task, psrc, it0, kq, P, rin);
+    Transposer<T>::run(rin, rout);
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) lds[store_off + lds_slot<1, E>(cg * E + e)] = rout[e];
+    }
     __syncthreads();
     for (int it = it0; it < it1; ++it) {
       const int buf = (it - it0) & 1;
       const bool more = it + 1 < it1;
-      if (more) stage_load(it + 1);
+      if (more) wg_stage_load<T, E, KCH, PLAIN>(a, task, psrc, it + 1, kq, P, rin);
 #pragma unroll
       for (int c = 0; c < KCH; ++c) {
         const uint4* la = lds + buf * BUF + c * CH;
         mma_chunk<T, TC, TP, BC, BP, 1>(la, la + 4 * BC, rowA0, rowB0, lane, acc);
       }
-      if (more) stage_store(buf ^ 1);
+      if (more) {
+        Transposer<T>::run(rin, rout);
+        if (active) {
+          uint4* dst = lds + (buf ^ 1) * BUF + store_off;
+#pragma unroll
+          for (int e = 0; e < E; ++e) dst[lds_slot<1, E>(cg * E + e)] = rout[e];
+        }
+      }
       __syncthreads();
     }
   }
@@ -870,7 +907,9 @@ static hipError_t launch_wgrad_cfg(const WgradArgs& a, hipStream_t st) {
   // bf16 tasks are 8x8 blocks: two chunks per iteration keep all 256 threads loading
   constexpr int KCH = (sizeof(T) == 2) ? 2 : 1;
   const size_t smem = 2 * KCH * 4 * (BC + BP) * 16;
-  hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP, KCH>), grid, dim3(256), smem, st, a);
+  const bool plain = a.zeros && !a.g.aff_a[0] && !a.g.aff_a[1] && a.g.act == ACT_NONE && !a.d.aff_a[0] && !a.d.aff_a[1] && a.d.act == ACT_NONE;
+  if (plain) hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP, KCH, true>), grid, dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP, KCH, false>), grid, dim3(256), smem, st, a);
   return hipGetLastError();
 }
 

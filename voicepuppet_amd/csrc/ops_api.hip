@@ -51,7 +51,7 @@ size_t vp_conv_workspace_bytes(const vp_conv_desc* d) {
     size_t b = align256(p.pack_elems * es) + p.partial_bytes;
     if (b > best) best = b;
     WgradPlan w = plan_wgrad(g, bf);
-    if (w.partial_bytes > best) best = w.partial_bytes;
+    if (w.partial_bytes + 512 > best) best = w.partial_bytes + 512;
   }
   return best + 1024;
 }
@@ -109,6 +109,7 @@ int vp_conv_bwd_weight(const vp_conv_desc* d, const void* x, const float* in_sca
   if (d->kind == 0) { a.g = xs; a.d = ds; } else { a.g = ds; a.d = xs; }
   a.partial = (float*)workspace;
   a.dW = dw;
+  a.zeros = zero_page((char*)workspace, p.partial_bytes, st);
   VP_HIP_CHECK(launch_wgrad(a, bf, p.cfg, st));
   return VP_OK;
 }

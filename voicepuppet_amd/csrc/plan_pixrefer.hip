@@ -440,6 +440,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     w.partial = (float*)h->scratch;
     w.dW = n.grads + L.w_off;
     w.accumulate = 0;
+    w.zeros = h->zeros;
     profile_tag((L.scope + ":wgrad").c_str());
     VP_HIP_CHECK(launch_wgrad(w, h->bf16, L.wg.cfg, st));
     float* db = n.grads + L.b_off;
