@@ -354,6 +354,7 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, int cls, int
           const int row = (blkB0 + tp) * 16 + (lane & 15) - ps * RP;
           const int ch = (blkA0 + tc) * 16 + 4 * (lane >> 4);
           *reinterpret_cast<f32x4*>(smem + row * PITCH + ch * 4) = acc[tc][tp];
+          __builtin_amdgcn_sched_barrier(0);   // keep the AGPR->VGPR copies 4 at a time (register budget of the K loop)
         }
     }
     __syncthreads();
@@ -415,7 +416,7 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, int cls, int
   }
 }
 
-template <typename T, int WC, int WP, int TC, int TP>
+template <typename T, int WC, int WP, int TC, int TP, bool STAGED>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
     }
   }
 
-  if (a.vec_epi) {
+  if (STAGED) {
     constexpr int RINGB = NST * BUF * 16;
     constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : ((WP >= 2 && BP / 2 * (BC * 4 + 16) + BP * 4 <= RINGB) ? 2 : (WP >= 4 ? 4 : 2));
     staged_epilogue<T, TC, TP, BC, BP, NPASS>(a, cls, p_base, c_base, blkA0, blkB0, acc, smem);
@@ -853,10 +854,10 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   if (plain) {
     IgemmArgs b = a;
     b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
-    hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, b);
+    if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(256), smem, st, b);
+    else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(256), smem, st, b);
     return hipGetLastError();
   }
-  if (false) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
   else hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
   return hipGetLastError();
 }
