@@ -30,6 +30,9 @@ FWD_CASES = [
     (1, 2, 8, 8, 128, 4, 4, 2, 1, 2, 3, True),        # decoder_1-like: 4 channels + tanh
     (1, 2, 1, 1, 512, 512, 4, 2, 1, 2, 0, True),      # merged_decoder_5-like: 1x1 -> 2x2, split-K
     (1, 3, 16, 16, 64, 64, 4, 2, 1, 2, 0, False),
+    (0, 2, 24, 40, 64, 128, 3, 1, 1, 0, 2, False),    # patch kernel: 3x3 s1, ragged 8x16 tiles
+    (0, 3, 17, 19, 32, 64, 4, 1, 1, 0, 0, False),     # patch kernel: 4x4 s1 (D layer_4 geometry), odd sizes
+    (0, 1, 32, 32, 256, 256, 3, 1, 1, 0, 2, False),   # patch kernel: many channel chunks
 ]
 
 

@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvp_hip.so")
+LIB_PATH = os.environ.get("VP_LIB", os.path.join(_HERE, "libvp_hip.so"))   # VP_LIB: ablation builds only
 
 VP_F32, VP_BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4

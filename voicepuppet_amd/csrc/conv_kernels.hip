@@ -21,6 +21,10 @@
 #include "conv_args.h"
 #include "vp_common.h"
 
+#ifndef VP_ABLATE
+#define VP_ABLATE 0   // build-time ablation of the LDS-DMA GEMM loop: 1 = no MFMA, 2 = no DMA in the loop
+#endif
+
 namespace vp {
 
 // ------------------------------------------------------------------------------------------------
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
     pn[ps] = n; pbh[ps] = q * a.sh; pbw[ps] = (rem - q * a.Wg) * a.sw;
   }
-  const T* wp = reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad;
+  const T* wp = reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad;   // [K chunk][row][KC]
 
   const int nchunk = a.Kpad / KC;
   const int per = (nchunk + a.splitk - 1) / a.splitk;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
   auto load_a = [&](int kc, int ps) -> uint4 {
     const int row = ps * 64 + wave * 16 + r16;
-    if (BC % 64 == 0 || row < BC) return *reinterpret_cast<const uint4*>(wp + (size_t)(c_base + row) * a.Kpad + (kc * KC + g * E));
+    if (BC % 64 == 0 || row < BC) return *reinterpret_cast<const uint4*>(wp + ((size_t)kc * a.wp_rows + c_base + row) * KC + g * E);
     return make_uint4(0, 0, 0, 0);
   };
   auto load_b = [&](int kc, int ps, int n, int bh, int bw, bool ok) -> uint4 {
@@ -322,30 +326,32 @@ __device__ __forceinline__ void dma16(const void* src, uint4* lds_dst_wave_unifo
 // issues ONE 16-byte store; 16 adjacent lanes cover 256 contiguous bytes of an NHWC row.  (The direct
 // MFMA-layout store writes 8 bytes per lane at a 32-byte granularity and ran at ~0.4 TB/s.)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TC, int TP, int BC, int BP, int NPASS>
-__device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, int cls, int p_base, int c_base, int blkA0, int blkB0,
+// default tile-row -> output-pixel map: rows are consecutive pixels of the flattened (n, q, r) grid
+struct LinearPix {
+  const IgemmArgs& a; int cls, p_base, P;
+  __device__ __forceinline__ long long operator()(int row) const {
+    const int pidx = p_base + row;
+    if (pidx >= P) return -1;
+    const int hw = a.Hg * a.Wg;
+    const int n = pidx / hw, rem = pidx - n * hw, q = rem / a.Wg, r = rem - q * a.Wg;
+    long long off = (((long long)n * a.Hof + (q * a.os + a.o0h[cls])) * a.Wof + (r * a.os + a.o0w[cls])) * a.ldY;
+    return (off << 8) | (long long)(n / a.ref_group_n);   // BN group of the pixel in the low byte
+  }
+};
+
+template <typename T, int TC, int TP, int BC, int BP, int NPASS, typename PixFn>
+__device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn& pixfn, int c_base, int blkA0, int blkB0,
                                                 f32x4 (&acc)[TC][TP], char* smem) {
   constexpr int PITCH = BC * 4 + 16;                 // bytes per pixel row (+16: conflict-free b128 writes)
   constexpr int CG = BC / 8;                         // 8-channel groups per row
   constexpr int RP = BP / NPASS;                     // pixel rows staged per pass (keeps the tile inside the ring's LDS)
   static_assert(RP % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
   const int tid = threadIdx.x, lane = tid & 63;
-  const int P = a.N * a.Hg * a.Wg;
   long long* otab = reinterpret_cast<long long*>(smem + RP * PITCH);
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     __syncthreads();                                 // ring (pass 0) / previous pass's tile no longer needed
-    if (tid < RP) {
-      const int pidx = p_base + ps * RP + tid;
-      long long off = -1;
-      if (pidx < P) {
-        const int hw = a.Hg * a.Wg;
-        const int n = pidx / hw, rem = pidx - n * hw, q = rem / a.Wg, r = rem - q * a.Wg;
-        off = (((long long)n * a.Hof + (q * a.os + a.o0h[cls])) * a.Wof + (r * a.os + a.o0w[cls])) * a.ldY;
-        off = (off << 8) | (long long)(n / a.ref_group_n);   // BN group of the pixel in the low byte
-      }
-      otab[tid] = off;
-    }
+    if (tid < RP) otab[tid] = pixfn(ps * RP + tid);
     if (blkB0 * 16 >= ps * RP && blkB0 * 16 < (ps + 1) * RP) {
 #pragma unroll
       for (int tp = 0; tp < TP; ++tp)
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
   const T* wrow[JA];
 #pragma unroll
   for (int j = 0; j < JA; ++j)
-    wrow[j] = reinterpret_cast<const T*>(a.Wp) + ((size_t)cls * a.wp_rows + c_base + (wave + 4 * j) * 16 + r) * a.Kpad + g * E;
+    wrow[j] = reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad + ((size_t)c_base + (wave + 4 * j) * 16 + r) * KC + g * E;
   int pn[JB], pbh[JB], pbw[JB];
   bool pok[JB];
 #pragma unroll
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
     uint4* lb = la + 4 * BC;
 #pragma unroll
     for (int j = 0; j < JA; ++j)
-      if (NBA % 4 == 0 || wave + 4 * j < NBA) dma16(wrow[j] + (size_t)kc * KC, la + (wave + 4 * j) * 64);
+      if (NBA % 4 == 0 || wave + 4 * j < NBA) dma16(wrow[j] + (size_t)kc * a.wp_rows * KC, la + (wave + 4 * j) * 64);
     const int k0 = kc * KC + g * E;
     const int tap = k0 >> a.log2Cin;
     const int ci = k0 & a.cin_mask;
@@ -513,9 +519,13 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
         __builtin_amdgcn_s_barrier();   // every wave's DMA of chunk kc landed; every wave is done reading chunk kc-1
         asm volatile("" ::: "memory");
         const int st2 = st == 0 ? 2 : st - 1;   // == (st + 2) % 3, the buffer chunk kc-1 used
+#if !(VP_ABLATE & 2)
         if (kc + 2 < kc1) issue(kc + 2, st2);
+#endif
         const uint4* la = lds + st * BUF;
+#if !(VP_ABLATE & 1)
         mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
+#endif
         st = st == 2 ? 0 : st + 1;
       }
     } else {
@@ -533,7 +543,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
   if (STAGED) {
     constexpr int RINGB = NST * BUF * 16;
     constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : ((WP >= 2 && BP / 2 * (BC * 4 + 16) + BP * 4 <= RINGB) ? 2 : (WP >= 4 ? 4 : 2));
-    staged_epilogue<T, TC, TP, BC, BP, NPASS>(a, cls, p_base, c_base, blkA0, blkB0, acc, smem);
+    staged_epilogue<T, TC, TP, BC, BP, NPASS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem);
     return;
   }
 #pragma unroll
@@ -552,6 +562,140 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// igemm_patch_kernel: stride-1 convolutions (VGG 3x3, discriminator 4x4 s1, their backward-data) with the
+// input tile staged ONCE per channel chunk.  The 128 output pixels of a block are an 8 x 16 patch of one
+// image; the (8+k-1) x (16+k-1) input patch of a 64-byte channel chunk is DMA'd into LDS once and every tap
+// reads its B fragments from shifted positions of it, so the pixel operand moves ~k*k/1.4 times fewer bytes
+// through the vector-memory path than the gather-per-tap kernel (the step-1 bottleneck: TA ~ MFMA time).
+// Weights still stream per (chunk, tap) through the 3-deep ring.  K order = [chunk][tap].
+// ------------------------------------------------------------------------------------------------
+struct PatchPix {
+  const IgemmArgs& a; int n, y0, x0;
+  __device__ __forceinline__ long long operator()(int row) const {
+    const int y = y0 + (row >> 4), x = x0 + (row & 15);
+    if (y >= a.Hg || x >= a.Wg) return -1;
+    long long off = (((long long)n * a.Hof + y) * a.Wof + x) * a.ldY;
+    return (off << 8) | (long long)(n / a.ref_group_n);
+  }
+};
+
+template <typename T, int WC, int WP, int TC, int TP>
+__global__ __launch_bounds__(256) void igemm_patch_kernel(const IgemmArgs a) {
+  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  static_assert(BP == 128, "8 x 16 pixel patch");
+  constexpr int NBA = BC / 16, JA = NBA / 4;
+  static_assert(NBA % 4 == 0, "every wave issues JA weight DMAs per iteration");
+  constexpr int ABUF = 4 * BC;                 // slots per weight stage
+  constexpr int PMAX = 224;                    // patch pixels (padded to 16): 11 x 19 = 209 for 4x4, 10 x 18 = 180 for 3x3
+  constexpr int PBUF = 4 * PMAX;
+  constexpr int JP = (PMAX / 16 + 3) / 4;      // patch DMA instructions per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  uint4* lpatch = lds + 3 * ABUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c_base = blockIdx.y * BC;
+  // block -> (image, tile row, tile col)
+  const int tx_n = (a.Wg + 15) >> 4, ty_n = (a.Hg + 7) >> 3;
+  const int bt = blockIdx.x;
+  const int n = bt / (tx_n * ty_n);
+  const int trem = bt - n * (tx_n * ty_n);
+  const int y0 = (trem / tx_n) * 8, x0 = (trem % tx_n) * 16;
+  // tap offset range (host guarantees stride 1)
+  int dh0 = 127, dw0 = 127, dh1 = -127, dw1 = -127;
+  for (int t = 0; t < a.ntaps; ++t) {
+    dh0 = min(dh0, (int)a.taps[0].dh[t]); dh1 = max(dh1, (int)a.taps[0].dh[t]);
+    dw0 = min(dw0, (int)a.taps[0].dw[t]); dw1 = max(dw1, (int)a.taps[0].dw[t]);
+  }
+  const int PW = 16 + dw1 - dw0, PH = 8 + dh1 - dh0;
+
+  // weight DMA rows and patch DMA pixels of this thread
+  const int r = lane >> 2, gp = (lane & 3) ^ rb_swz(lane >> 2);
+  const T* wrow[JA];
+#pragma unroll
+  for (int j = 0; j < JA; ++j)
+    wrow[j] = reinterpret_cast<const T*>(a.Wp) + ((size_t)c_base + (wave + 4 * j) * 16 + r) * KC + gp * E;
+  const T* prow[JP];
+  bool pok[JP];
+  const T* x0p = reinterpret_cast<const T*>(a.x.ptr[0]);
+#pragma unroll
+  for (int j = 0; j < JP; ++j) {
+    const int pp = (wave + 4 * j) * 16 + (lane >> 2);          // patch pixel of this lane
+    const int py = pp / PW, px = pp - py * PW;
+    const int iy = y0 + dh0 + py, ix = x0 + dw0 + px;
+    pok[j] = pp < PH * PW && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+    // LDS slot of (pixel pp, piece g) is pp*4 + (g ^ rb_swz(pp)); the DMA writes slot = lane, i.e. piece (lane&3)^swz
+    const int g = (lane & 3) ^ rb_swz(pp & 15);
+    prow[j] = x0p + ((size_t)(n * a.Hin + iy) * a.Win + ix) * a.Cin + g * E;
+  }
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nc = a.Cin / KC, nt = a.ntaps;
+  const int niter = nc * nt;
+  auto issue_w = [&](int it, int st) {          // weights of iteration it = (chunk, tap): k offset tap*Cin + chunk*KC
+    const int c = it / nt, t = it - c * nt;
+    uint4* la = lds + st * ABUF;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) dma16(wrow[j] + (size_t)(t * nc + c) * a.wp_rows * KC, la + (wave + 4 * j) * 64);
+  };
+  auto issue_p = [&](int c, int buf) {
+    uint4* lp = lpatch + buf * PBUF;
+#pragma unroll
+    for (int j = 0; j < JP; ++j)
+      if ((wave + 4 * j) * 16 < PMAX) dma16(pok[j] ? (const void*)(prow[j] + c * KC) : a.zeros, lp + (wave + 4 * j) * 64);
+  };
+
+  const int wc = wave / WP, wpi = wave - wc * WP;
+  const int blkA0 = wc * TC, rowB0 = wpi * TP;   // first pixel row (of 8) of this wave
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int aso = i16 * 4 + (g4 ^ rb_swz(i16));
+
+  issue_p(0, 0);
+  issue_w(0, 0);
+  if (niter > 1) issue_w(1, 1);
+  int st = 0;
+  for (int it = 0; it < niter; ++it) {
+    const int c = it / nt, t = it - c * nt;
+    if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t == 0 && c + 1 < nc) issue_p(c + 1, (c + 1) & 1);      // older than the weight DMA below: waited one iteration later
+    if (it + 2 < niter) issue_w(it + 2, st == 0 ? 2 : st - 1);
+    // B fragments: pixel (row + dh - dh0, i + dw - dw0) of the patch
+    int tdh = 0, tdw = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k == t) { tdh = a.taps[0].dh[k]; tdw = a.taps[0].dw[k]; }
+    const uint4* la = lds + st * ABUF;
+    const uint4* lp = lpatch + (c & 1) * PBUF;
+    uint4 fa[TC], fb[TP];
+#pragma unroll
+    for (int k = 0; k < TC; ++k) fa[k] = la[(blkA0 + k) * 64 + aso];
+#pragma unroll
+    for (int k = 0; k < TP; ++k) {
+      const int pp = (rowB0 + k + tdh - dh0) * PW + i16 + tdw - dw0;
+      fb[k] = lp[pp * 4 + (g4 ^ rb_swz(pp & 15))];
+    }
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], fb[tp], acc[tc][tp]);
+    st = st == 2 ? 0 : st + 1;
+  }
+
+  constexpr int RINGB = (3 * ABUF + 2 * PBUF) * 16;
+  constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : 2;
+  staged_epilogue<T, TC, TP, BC, BP, NPASS>(a, PatchPix{a, n, y0, x0}, c_base, blkA0, rowB0, acc, smem);
 }
 
 // sums the split-K slabs in a fixed order (deterministic) and applies the igemm epilogue
@@ -862,6 +1006,30 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <typename T, int WC, int WP, int TC, int TP>
+static hipError_t launch_patch_cfg(const IgemmArgs& a, hipStream_t st) {
+  constexpr int BC = WC * TC * 16;
+  const int tiles = a.N * ((a.Hg + 7) / 8) * ((a.Wg + 15) / 16);
+  dim3 grid(tiles, a.CoutPad / BC, 1);
+  size_t smem = (3 * 4 * BC + 2 * 4 * 224) * 16;
+  const size_t epi = (size_t)64 * (BC * 4 + 16) + 128 * 8;
+  if (smem < epi) smem = epi;
+  IgemmArgs b = a;
+  b.vec_epi = 1;
+  hipLaunchKernelGGL((igemm_patch_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, b);
+  return hipGetLastError();
+}
+
+// stride-1 convs whose channel chunks stay inside one tap, with the 16-byte row-store epilogue available
+static bool patch_ok(const IgemmArgs& a, int kc) {
+  // measured 3-6 % SLOWER than the gather-per-tap kernel on MI355X (round 1): the weight stream, not the pixel
+  // operand, saturates the LDS-DMA path; kept as an opt-in experiment
+  static const bool on = getenv("VP_PATCH") != nullptr;
+  return on && a.zeros && a.nclass == 1 && a.splitk == 1 && a.sh == 1 && a.sw == 1 && a.os == 1 && a.ntaps > 1 && a.x.C[1] == 0 &&
+         a.Cin % kc == 0 && a.Cin == a.x.C[0] && a.Wg >= 16 && a.Hg >= 8 && a.Cout % 8 == 0 && a.ldY % 8 == 0 &&
+         !a.x.aff_a[0] && a.x.act == ACT_NONE && a.Hof == a.Hg && a.Wof == a.Wg;
+}
+
 template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int cfg, hipStream_t st) {
   hipError_t e;
   int pbc, pbp;
@@ -870,8 +1038,10 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   const double Pn = (double)a.N * a.Hg * a.Wg * a.nclass;
   const double kreal = (double)a.ntaps * a.cin_real;
   const double es = sizeof(T);
-  ProfScope prof("igemm", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
+  const bool use_patch = (cfg == 0 || cfg == 1) && patch_ok(a, 4 * Elem<T>::E);
+  ProfScope prof(use_patch ? "patch" : "igemm", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
                  es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+  if (use_patch) return cfg == 0 ? launch_patch_cfg<T, 2, 2, 4, 4>(a, st) : launch_patch_cfg<T, 1, 4, 4, 2>(a, st);
   switch (cfg) {
     case 0: e = launch_igemm_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 ch x 128 px
     case 1: e = launch_igemm_cfg<T, 1, 4, 4, 2>(a, st); break;   //  64 ch x 128 px

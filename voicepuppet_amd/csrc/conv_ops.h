@@ -82,6 +82,7 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   a.wp_rows = round_up(rows, 128);
   p.pack.rows_pad = a.wp_rows;
   p.pack.Kpad = a.Kpad;
+  p.pack.kc = kc_elems(is_bf16);
   p.pack_elems = (size_t)a.nclass * a.wp_rows * a.Kpad;
 }
 

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __res
     float v = 0.f;
     if (row < d.rows_real && tap < d.ntaps && c < d.C_real)
       v = src[(size_t)d.kh[cls][tap] * d.s_kh + (size_t)d.kw[cls][tap] * d.s_kw + (size_t)row * d.s_row + (size_t)c * d.s_ch];
-    Elem<T>::st(dst + i, v);
+    Elem<T>::st(dst + (((size_t)cls * (d.Kpad / d.kc) + k / d.kc) * d.rows_pad + row) * d.kc + k % d.kc, v);
   }
 }
 
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void pack_weights_one_kernel(const PackDesc d,
           if (cc == cls && tt == tap) { kh = d.kh[cc][tt]; kw = d.kw[cc][tt]; }
       v = src[(size_t)kh * d.s_kh + (size_t)kw * d.s_kw + (size_t)row * d.s_row + (size_t)c * d.s_ch];
     }
-    Elem<T>::st(dst + i, v);
+    Elem<T>::st(dst + (((size_t)cls * (d.Kpad / d.kc) + k / d.kc) * d.rows_pad + row) * d.kc + k % d.kc, v);
   }
 }
 

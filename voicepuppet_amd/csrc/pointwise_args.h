@@ -5,11 +5,15 @@
 
 namespace vp {
 
-// dst[cls][row][tap*C + c] = src[kh*s_kh + kw*s_kw + row*s_row + c*s_ch]   (0 in the padding)
+// W[cls][row][k = tap*C + c] = src[kh*s_kh + kw*s_kw + row*s_row + c*s_ch]   (0 in the padding), stored CHUNK-MAJOR:
+// element (cls, row, k) lives at ((cls*(Kpad/kc) + k/kc)*rows_pad + row)*kc + k%kc, so the 64-byte pieces a block needs
+// for one K chunk are contiguous (a [row][K] image strides by K*2 bytes = a power of two: every row of a tile
+// would sit on the same L2 channel)
 struct PackDesc {
   size_t src_off;           // floats into the fp32 master arena
   size_t dst_off;           // elements into the packed arena
   int nclass, rows_real, rows_pad, ntaps, C, C_real, Kpad;
+  int kc;                   // elements per 64-byte K chunk; packed layout is [class][K chunk][row][kc]
   int s_kh, s_kw, s_row, s_ch;
   int8_t kh[4][16];
   int8_t kw[4][16];
