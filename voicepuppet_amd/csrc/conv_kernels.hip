@@ -875,7 +875,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
   }
 
-  // slab store: lane holds d column (lane&15), rows 4*(lane>>4) .. +3
+  // lane holds d column (lane&15), rows 4*(lane>>4) .. +3
+  if (a.splitk == 1) {   // no K split: write the gradient itself (real taps / channels only), no slab, no reduce pass
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        const int m0 = m_base + rowA0 + tc * 16 + 4 * (lane >> 4);
+        const int d = d_base + rowB0 + tp * 16 + (lane & 15);
+        if (d >= a.Dreal) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + e, tap = m >> a.log2Gc, gc = m & (a.Gc - 1);
+          if (tap < a.ntaps && gc < a.Greal) {
+            float* o = a.dW + ((size_t)tap * a.Greal + gc) * a.Dreal + d;
+            *o = acc[tc][tp][e] + (a.accumulate ? *o : 0.f);
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
@@ -889,6 +908,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
+  if ((a.Dreal & 3) == 0) {   // 16-byte path
+    const int dq = a.Dreal >> 2;
+    const size_t total = (size_t)a.ntaps * a.Greal * dq;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+      const int d = (int)(i % dq) * 4;
+      const size_t t = i / dq;
+      const int gc = (int)(t % a.Greal);
+      const int tap = (int)(t / a.Greal);
+      const size_t m = (size_t)tap * a.Gc + gc;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < a.splitk; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(a.partial + ((size_t)k * a.Mpad + m) * a.Dpad + d);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float4* o = reinterpret_cast<float4*>(a.dW + (t * a.Dreal + d));
+      if (a.accumulate) { const float4 e = *o; s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w; }
+      *o = s;
+    }
+    return;
+  }
   const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int d = (int)(i % a.Dreal);
@@ -1097,8 +1136,8 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
     case 2: e = launch_wgrad_cfg<T, 4, 1, 2, 1>(a, st); break;   // 128 rows x  16 cols
     default: return hipErrorInvalidValue;
   }
-  if (e != hipSuccess) return e;
-  const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal;
+  if (e != hipSuccess || a.splitk == 1) return e;
+  const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal / ((a.Dreal & 3) ? 1 : 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);

@@ -208,7 +208,8 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16) {
   const int kiter = kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of wgrad_kernel
   const int nchunk = (P + kiter - 1) / kiter;
   const int tiles = (a.Mpad / bm) * (a.Dpad / bn);
-  int s = (1024 + tiles - 1) / tiles;
+  int s = (768 + tiles - 1) / tiles;     // ~3 blocks per CU
+  if (tiles >= 384) s = 1;               // enough tiles already: write dW directly, no slab
   if (s > nchunk / 4) s = nchunk / 4;
   if (s > 512) s = 512;
   if (s < 1) s = 1;

@@ -401,13 +401,15 @@ __global__ __launch_bounds__(256) void perceptual_kernel(const PerceptualArgs a)
   if (threadIdx.x == 0) a.partial[blockIdx.x] = acc[0];
 }
 
-__global__ void loss_final_kernel(const LossFinalArgs a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double l1 = 0, mt = 0, pc = 0;
-  for (int i = 0; i < a.n_comp; ++i) { l1 += a.comp_partial[2 * i]; mt += a.comp_partial[2 * i + 1]; }
-  for (int i = 0; i < a.n_perc; ++i) pc += a.perc_partial[i];
-  const double content = pc / 2.0 / a.n_feat;
-  const double gl1 = l1 / a.n_out + mt / a.n_out + content;
+__global__ __launch_bounds__(256) void loss_final_kernel(const LossFinalArgs a) {
+  double v[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < a.n_comp; i += 256) { v[0] += a.comp_partial[2 * i]; v[1] += a.comp_partial[2 * i + 1]; }
+  for (int i = threadIdx.x; i < a.n_perc; i += 256) v[2] += a.perc_partial[i];
+  __shared__ double sm[64];
+  block_sum<3>(v, sm);
+  if (threadIdx.x != 0) return;
+  const double content = v[2] / 2.0 / a.n_feat;
+  const double gl1 = v[0] / a.n_out + v[1] / a.n_out + content;
   a.losses[2] = (float)gl1;
   a.losses[3] = (float)((double)a.losses[1] * a.gan_weight + gl1 * a.l1_weight);
   a.losses[4] = (float)content;
@@ -617,7 +619,7 @@ hipError_t launch_perceptual(const PerceptualArgs& a, int is_bf16, hipStream_t s
 }
 
 hipError_t launch_loss_final(const LossFinalArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
