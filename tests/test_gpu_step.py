@@ -172,3 +172,45 @@ def test_sample22_fixture_forward_and_step_vs_golden():
   # N=1: batch-norm over a single 1x1 bottleneck pixel kills the gradient of the deepest layers (norm ~ 0); compare the rest
   big = ok & (d["grad_norms"] > 1e-6 * d["grad_norms"].max())
   np.testing.assert_allclose(norms[big], d["grad_norms"][big], rtol=2e-2)
+
+
+def test_step_parity_bf16_against_rounding_aware_oracle(oracle_step):
+  """bf16 device path vs the device-dataflow oracle with bf16 rounding at every storage point
+  (oracle/pixrefer_lowp_ref.py): ReLU / leaky-ReLU masks agree by construction, so gradients are compared tightly.
+  The generator's N=2 bottleneck batch-norm turns one-ulp differences into sign flips (conditioning of the test problem,
+  not of the kernels), so the oracle is teacher-forced: every generator layer is recomputed from the device's stored
+  tensors of the layers before it (checked per layer), and the backward then runs on identical activations."""
+  from oracle import pixrefer_lowp_ref as lowp
+  o = oracle_step
+  eng = run_engine(o, "bf16")
+  out4 = eng.tensor("gen_out4").cpu().numpy()
+  p64 = {k: v.astype(np.float64) for k, v in o["params"].items()}
+  g_dev = {sc: eng.tensor("g/" + sc).float().cpu().numpy() for sc, *_ in ref.generator_spec(o["ngf"])}
+  nodes = lowp.forward_backward(p64, *[b.astype(np.float64) for b in o["batch"]], ngf=o["ngf"], ndf=o["ndf"], q=lowp.round_bf16,
+                                out4_override=out4, g_override=g_dev)
+  # layer-by-layer forward parity of the generator: each layer recomputed from the device's own previous tensors
+  fwd = nodes["G"].fwd_err
+  print("\n[bf16 generator forward, per layer from device inputs] worst:", sorted(((v, k) for k, v in fwd.items()), reverse=True)[:4])
+  assert max(fwd.values()) < 4e-3, fwd
+  got = eng.losses()
+  for k in ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss"):
+    assert got[k] == pytest.approx(nodes[k], rel=1e-4), k
+  assert gu.rel_l2(eng.tensor("Outputs_raw").cpu().numpy(), nodes["Outputs_raw"]) < 1e-5
+  T = lambda name: eng.tensor(name).float().cpu().numpy()
+  mid = {"d_din": gu.rel_l2(T("d_din")[..., 3:6], nodes["d_din"]), "d_vin": gu.rel_l2(T("d_vin")[..., :3], nodes["d_vin"]),
+         "dy4": gu.rel_l2(T("d_gen_out4")[..., :4], nodes["dy4"])}
+  worst = {}
+  for which, key in ((1, "Discrim_grads"), (0, "Gen_grads")):
+    grads = eng.get_params(which, src=eng.grads_d if which == 1 else eng.grads_g)
+    for name, g in grads.items():
+      r = nodes[key][name]
+      if np.all(r == 0):
+        continue
+      worst[name] = gu.rel_l2(g, r)
+  top = sorted(((v, k) for k, v in worst.items()), reverse=True)[:6]
+  print("\n[bf16 vs rounding-aware oracle] intermediates %s\n worst gradient rel-L2: %s" % (mid, top))
+  # residual: f32 accumulation order differs from the oracle's, which flips the bf16 rounding (1 ulp = 0.4 %) of a few
+  # per cent of the elements at each of the ~8 backward stages
+  assert max(mid.values()) < 2e-2, mid
+  bad = {k: v for k, v in worst.items() if v > 5e-2}   # measured worst: 3.0e-2 (a bias gradient), typical 1e-2
+  assert not bad, bad
