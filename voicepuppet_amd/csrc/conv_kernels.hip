@@ -339,7 +339,14 @@ struct LinearPix {
   }
 };
 
-template <typename T, int TC, int TP, int BC, int BP, int NPASS, typename PixFn>
+// number of epilogue passes so that the f32 tile of one pass (+ its offset table) fits the ring's LDS; a wave's rows stay in one pass
+constexpr int epi_passes(int BC, int BP, int WP, int ring_bytes) {
+  for (int np = 1; np <= WP; np *= 2)
+    if ((BP / np) * (BC * 4 + 16) + (BP / np) * 8 <= ring_bytes) return np;
+  return WP;
+}
+
+template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, typename PixFn>
 __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn& pixfn, int c_base, int blkA0, int blkB0,
                                                 f32x4 (&acc)[TC][TP], char* smem) {
   constexpr int PITCH = BC * 4 + 16;                 // bytes per pixel row (+16: conflict-free b128 writes)
@@ -364,7 +371,7 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < RP * CG; idx += 256) {
+    for (int idx = tid; idx < RP * CG; idx += NT) {
       const int p = idx / CG, cgp = idx - p * CG;
       const long long ot = otab[p];
       const int c0 = c_base + cgp * 8;
@@ -423,15 +430,16 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
 }
 
 template <typename T, int WC, int WP, int TC, int TP, bool STAGED>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int NW = WC * WP, NT = NW * 64;             // 4 waves (256 threads) or 8 waves (512 threads: 128x256 / 256x256 tiles)
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
   constexpr int NBA = BC / 16, NBB = BP / 16;          // 16-row blocks per operand tile
-  constexpr int JA = (NBA + 3) / 4, JB = (NBB + 3) / 4; // DMA instructions per wave per chunk
+  constexpr int JA = (NBA + NW - 1) / NW, JB = (NBB + NW - 1) / NW; // DMA instructions per wave per chunk
   constexpr int BUF = 4 * (BC + BP);
   // every wave issues the same number of DMAs per chunk -> a counted vmcnt can keep one chunk in flight
   // across the barrier (3-deep LDS ring); otherwise 2 buffers and a full drain per chunk
-  constexpr bool RING = (NBA % 4 == 0) && (NBB % 4 == 0);
+  constexpr bool RING = (NBA % NW == 0) && (NBB % NW == 0);
   constexpr int NST = RING ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
@@ -441,7 +449,17 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cls = blockIdx.z / a.splitk, split = blockIdx.z - cls * a.splitk;
   const int P = a.N * a.Hg * a.Wg;
-  const int p_base = blockIdx.x * BP, c_base = blockIdx.y * BC;
+  // XCD-aware tile order (speed only): workgroup b is observed to run on XCD b % 8, each XCD has a private 4 MiB L2.
+  // Give every XCD a contiguous range of logical tiles, ordered pixel-tile major / channel-tile minor, so the channel
+  // tiles that re-read one activation tile run back to back on the same L2 and the weight slabs stay resident.
+  int pt, ct;
+  {
+    const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7, slot = id >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    ct = logical % (int)gridDim.y; pt = logical / (int)gridDim.y;
+  }
+  const int p_base = pt * BP, c_base = ct * BC;
   const int r = lane >> 2, g = (lane & 3) ^ rb_swz(lane >> 2);   // row in the 16-row block, k-piece fetched
 
   if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
@@ -450,13 +468,13 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
   const T* wrow[JA];
 #pragma unroll
   for (int j = 0; j < JA; ++j)
-    wrow[j] = reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad + ((size_t)c_base + (wave + 4 * j) * 16 + r) * KC + g * E;
+    wrow[j] = reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad + ((size_t)c_base + (wave + NW * j) * 16 + r) * KC + g * E;
   int pn[JB], pbh[JB], pbw[JB];
   bool pok[JB];
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
-    const int pidx = p_base + (wave + 4 * j) * 16 + r;
-    pok[j] = (wave + 4 * j < NBB) && (pidx < P);
+    const int pidx = p_base + (wave + NW * j) * 16 + r;
+    pok[j] = (wave + NW * j < NBB) && (pidx < P);
     const int hw = a.Hg * a.Wg;
     const int pc = pok[j] ? pidx : 0;
     const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
@@ -481,7 +499,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
     uint4* lb = la + 4 * BC;
 #pragma unroll
     for (int j = 0; j < JA; ++j)
-      if (NBA % 4 == 0 || wave + 4 * j < NBA) dma16(wrow[j] + (size_t)kc * a.wp_rows * KC, la + (wave + 4 * j) * 64);
+      if (NBA % NW == 0 || wave + NW * j < NBA) dma16(wrow[j] + (size_t)kc * a.wp_rows * KC, la + (wave + NW * j) * 64);
     const int k0 = kc * KC + g * E;
     const int tap = k0 >> a.log2Cin;
     const int ci = k0 & a.cin_mask;
@@ -494,11 +512,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
     const int cl = s1 ? ci - C0 : ci;
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-      if (NBB % 4 == 0 || wave + 4 * j < NBB) {
+      if (NBB % NW == 0 || wave + NW * j < NBB) {
         const int ih = pbh[j] + dh, iw = pbw[j] + dw;
         const bool ok = pok[j] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
         const void* src = ok ? (const void*)(xb + ((size_t)(pn[j] + ih) * a.Win + iw) * Cs + cl) : a.zeros;
-        dma16(src, lb + (wave + 4 * j) * 64);
+        dma16(src, lb + (wave + NW * j) * 64);
       }
     }
   };
@@ -542,8 +560,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
 
   if (STAGED) {
     constexpr int RINGB = NST * BUF * 16;
-    constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : ((WP >= 2 && BP / 2 * (BC * 4 + 16) + BP * 4 <= RINGB) ? 2 : (WP >= 4 ? 4 : 2));
-    staged_epilogue<T, TC, TP, BC, BP, NPASS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem);
+    constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
+    staged_epilogue<T, TC, TP, BC, BP, NPASS, NT>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem);
     return;
   }
 #pragma unroll
@@ -695,7 +713,7 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const IgemmArgs a) {
 
   constexpr int RINGB = (3 * ABUF + 2 * PBUF) * 16;
   constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : 2;
-  staged_epilogue<T, TC, TP, BC, BP, NPASS>(a, PatchPix{a, n, y0, x0}, c_base, blkA0, rowB0, acc, smem);
+  staged_epilogue<T, TC, TP, BC, BP, NPASS, 256>(a, PatchPix{a, n, y0, x0}, c_base, blkA0, rowB0, acc, smem);
 }
 
 // sums the split-K slabs in a fixed order (deterministic) and applies the igemm epilogue
@@ -1023,12 +1041,12 @@ size_t profile_collect(char* out, size_t cap) {
 // ------------------------------------------------------------------------------------------------
 template <typename T, int WC, int WP, int TC, int TP>
 static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
-  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16, NW = WC * WP;
   const int P = a.N * a.Hg * a.Wg;
   dim3 grid((P + BP - 1) / BP, a.CoutPad / BC, a.nclass * a.splitk);
-  constexpr bool RING = ((BC / 16) % 4 == 0) && ((BP / 16) % 4 == 0);
+  constexpr bool RING = ((BC / 16) % NW == 0) && ((BP / 16) % NW == 0);
   constexpr int RINGB = (RING ? 3 : 2) * 4 * (BC + BP) * 16;
-  constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : ((WP >= 2 && BP / 2 * (BC * 4 + 16) + BP * 4 <= RINGB) ? 2 : (WP >= 4 ? 4 : 2));
+  constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
   size_t smem = RINGB + 64;
   const size_t smem_epi = (size_t)(BP / NPASS) * (BC * 4 + 16) + (BP / NPASS) * 8;
   if (smem_epi > smem) smem = smem_epi;
@@ -1037,11 +1055,12 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   if (plain) {
     IgemmArgs b = a;
     b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
-    if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(256), smem, st, b);
-    else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(256), smem, st, b);
+    if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
+    else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(NW * 64), smem, st, b);
     return hipGetLastError();
   }
-  else hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, a);
+  if constexpr (NW == 4) hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), 2 * 4 * (BC + BP) * 16 + 64, st, a);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
@@ -1088,6 +1107,8 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     case 3: e = launch_igemm_cfg<T, 4, 1, 2, 2>(a, st); break;   // 128 ch x  32 px
     case 4: e = launch_igemm_cfg<T, 4, 1, 2, 1>(a, st); break;   // 128 ch x  16 px
     case 5: e = launch_igemm_cfg<T, 2, 2, 2, 1>(a, st); break;   //  64 ch x  32 px
+    case 6: e = launch_igemm_cfg<T, 2, 4, 4, 4>(a, st); break;   // 128 ch x 256 px, 8 waves
+    case 7: e = launch_igemm_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 ch x 256 px, 8 waves
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -1106,7 +1127,7 @@ hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st
 }
 
 void igemm_tile(int cfg, int* bc, int* bp) {
-  static const int t[6][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}};
+  static const int t[8][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}, {128, 256}, {256, 256}};
   *bc = t[cfg][0]; *bp = t[cfg][1];
 }
 

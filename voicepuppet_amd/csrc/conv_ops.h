@@ -5,6 +5,7 @@
 //   deconv : tf.layers.conv2d_transpose k4 s2 "same", kernel HWOI [4,4,Cout,Cin] (pixrefer.py:85)
 //            out[n,2i+kh-1,2j+kw-1,co] += in[n,i,j,ci] * W[kh,kw,co,ci]
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include "launch.h"
@@ -30,7 +31,10 @@ inline int kc_elems(int is_bf16) { return is_bf16 ? 32 : 16; }
 
 // tile choice for an igemm producing `rows` channels over P pixels
 inline int pick_igemm_cfg(int rows, int P) {
+  static const int big = getenv("VP_BIGTILE") ? atoi(getenv("VP_BIGTILE")) : 1;   // bit 0: 128x256, bit 1: 256x256 (8-wave tiles)
   if (P >= 96) {
+    if ((big & 2) && rows % 256 == 0 && P >= 256 * 512) return 7;
+    if ((big & 1) && rows % 128 == 0 && P >= 256 * 512) return 6;
     if (rows % 128 == 0) return 0;
     if (rows % 64 == 0) return 1;
     if (rows <= 16) return 2;
