@@ -21,6 +21,9 @@
 #include "conv_args.h"
 #include "vp_common.h"
 
+#ifndef VP_RING
+#define VP_RING 3      // LDS ring depth of the DMA GEMM loop (stages); 3 = one chunk in flight across the barrier
+#endif
 #ifndef VP_ABLATE
 #define VP_ABLATE 0   // build-time ablation of the LDS-DMA GEMM loop: 1 = no MFMA, 2 = no DMA in the loop
 #endif
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
   // every wave issues the same number of DMAs per chunk -> a counted vmcnt can keep one chunk in flight
   // across the barrier (3-deep LDS ring); otherwise 2 buffers and a full drain per chunk
   constexpr bool RING = (NBA % NW == 0) && (NBB % NW == 0);
-  constexpr int NST = RING ? 3 : 2;
+  constexpr int NST = RING ? VP_RING : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
   int* ltap = reinterpret_cast<int*>(lds + NST * BUF);
@@ -527,24 +530,24 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
   __syncthreads();   // tap table visible
   if (kc0 < kc1) {
     if (RING) {
-      issue(kc0, 0);
-      if (kc0 + 1 < kc1) issue(kc0 + 1, 1);
+      // NST-deep ring: chunks kc+1 .. kc+NST-2 stay in flight across the barrier while chunk kc is consumed
+#pragma unroll
+      for (int d = 0; d < NST - 1; ++d) if (kc0 + d < kc1) issue(kc0 + d, d);
       int st = 0;
       for (int kc = kc0; kc < kc1; ++kc) {
-        // chunk kc has landed once at most the newest batch (chunk kc+1) is still outstanding
-        if (kc + 1 < kc1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA + JB) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kc + NST - 2 < kc1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (JA + JB)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: fewer batches outstanding than the constant assumes
         __builtin_amdgcn_s_barrier();   // every wave's DMA of chunk kc landed; every wave is done reading chunk kc-1
         asm volatile("" ::: "memory");
-        const int st2 = st == 0 ? 2 : st - 1;   // == (st + 2) % 3, the buffer chunk kc-1 used
+        const int stn = st == 0 ? NST - 1 : st - 1;   // the buffer chunk kc-1 used
 #if !(VP_ABLATE & 2)
-        if (kc + 2 < kc1) issue(kc + 2, st2);
+        if (kc + NST - 1 < kc1) issue(kc + NST - 1, stn);
 #endif
         const uint4* la = lds + st * BUF;
 #if !(VP_ABLATE & 1)
         mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
 #endif
-        st = st == 2 ? 0 : st + 1;
+        st = st == NST - 1 ? 0 : st + 1;
       }
     } else {
       issue(kc0, 0);
@@ -960,6 +963,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
   }
 }
 
+// many splits, few outputs (the 3/6/4/1-channel layers): one wave per output element, lanes stride over the slabs
+__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const WgradArgs a) {
+  const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal;
+  const int lane = threadIdx.x & 63;
+  for (size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (size_t)gridDim.x * 4) {
+    const int d = (int)(i % a.Dreal);
+    const size_t t = i / a.Dreal;
+    const int gc = (int)(t % a.Greal);
+    const int tap = (int)(t / a.Greal);
+    const size_t m = (size_t)tap * a.Gc + gc;
+    float s = 0.f;
+    for (int k = lane; k < a.splitk; k += 64) s += a.partial[((size_t)k * a.Mpad + m) * a.Dpad + d];
+    s = wave_sum(s);
+    if (lane == 0) a.dW[i] = s + (a.accumulate ? a.dW[i] : 0.f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // optional per-launch timing (HIP events on the launch stream) for bench.py's roofline line
 // ------------------------------------------------------------------------------------------------
@@ -1045,7 +1065,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   const int P = a.N * a.Hg * a.Wg;
   dim3 grid((P + BP - 1) / BP, a.CoutPad / BC, a.nclass * a.splitk);
   constexpr bool RING = ((BC / 16) % NW == 0) && ((BP / 16) % NW == 0);
-  constexpr int RINGB = (RING ? 3 : 2) * 4 * (BC + BP) * 16;
+  constexpr int RINGB = (RING ? VP_RING : 2) * 4 * (BC + BP) * 16;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
   size_t smem = RINGB + 64;
   const size_t smem_epi = (size_t)(BP / NPASS) * (BC * 4 + 16) + (BP / NPASS) * 8;
@@ -1158,6 +1178,13 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess || a.splitk == 1) return e;
+  if (a.splitk >= 32) {
+    const size_t outs = (size_t)a.ntaps * a.Greal * a.Dreal;
+    int wb = (int)((outs + 3) / 4);
+    if (wb > 8192) wb = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3(wb), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal / ((a.Dreal & 3) ? 1 : 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;

@@ -212,11 +212,18 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16) {
   const int kiter = kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of wgrad_kernel
   const int nchunk = (P + kiter - 1) / kiter;
   const int tiles = (a.Mpad / bm) * (a.Dpad / bn);
-  int s = (768 + tiles - 1) / tiles;     // ~3 blocks per CU
-  if (tiles >= 384) s = 1;               // enough tiles already: write dW directly, no slab
-  if (s > nchunk / 4) s = nchunk / 4;
-  if (s > 512) s = 512;
-  if (s < 1) s = 1;
+  // K split: minimise (rounds of the ~512 resident blocks) x (iterations per block + fixed per-block cost),
+  // plus a small penalty per slab for the reduce pass
+  int s = 1;
+  {
+    const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
+    double best = 1e30;
+    for (int c = 1; c <= smax; ++c) {
+      const int rounds = (tiles * c + 511) / 512;
+      const double cost = rounds * ((double)nchunk / c + 8.0) + 0.15 * c;
+      if (cost < best - 1e-9) { best = cost; s = c; }
+    }
+  }
   a.splitk = s;
   p.partial_bytes = (size_t)s * a.Mpad * a.Dpad * sizeof(float);
   return p;
