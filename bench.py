@@ -27,21 +27,16 @@ F32_MFMA_PEAK = 157.3
 HBM_PEAK = 8000.0         # GB/s
 
 # bench kernel name -> substring of the rocprofv3 kernel name (for the offline PMC traffic numbers)
-PMC_NAMES = {"igemm_bf16_128x128": "igemm_dma_kernelIDF16bLi2ELi2ELi4ELi4ELb1", "igemm_bf16_64x128": "igemm_dma_kernel<bool _Accum, int, E, 4, 4, 2, true>",
-             "wgrad_bf16_128x128": "wgrad_kernelIDF16bLi2ELi2ELi4ELi4ELi2ELb1"}
-
-
 def pmc_traffic(name):
-  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
-  separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'); None when not collected."""
+  """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+  separate runs of this same command, folded by scripts/pmc_summary.py; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM');
+  launch-weighted over the template variants of the class; None when not collected."""
   path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-  key = PMC_NAMES.get(name)
-  if key is None or not os.path.exists(path):
+  if not os.path.exists(path):
     return None
-  for r in json.load(open(path)):
-    if key in r["kernel"]:
-      return r["hbm_bytes_per_launch"]
-  return None
+  rows = [r for r in json.load(open(path)) if r.get("class") == name]
+  n = sum(r["launches"] for r in rows)
+  return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
 
 
 def synth_batch(n, h, seed, device):

@@ -175,6 +175,52 @@ int vp_bfmnet_forward(vp_bfmnet_t* h, const float* ears, const float* mfccs, con
 /* "MfccEncoder" [B,T,256], "RNNModule" [B,T,256] of the last forward */
 int vp_bfmnet_tensor(vp_bfmnet_t* h, const char* name, void** ptr, int64_t shape[4]);
 
+/* ------------------------------------------------------------------------------------------------
+ * Rasteriser ("next" row): replaces mesh_core_cython.render_colors_core ->
+ * _render_colors_core(image, face_mask, vertices, triangles, colors, depth_buffer, ntri, h, w, c)
+ * (utils/cython/mesh_core.h:63, mesh_core.cpp:169-231; caller infer_bfmvid.py:100-108).  Same argument order and
+ * in-place convention (image / face_mask / depth_buffer are read-modify-write), plus nver, a batch of frames that share
+ * `triangles` (vertices [batch,nver,3], colors [batch,nver,c], outputs [batch,h,w,...]), a workspace and a stream.
+ * Bit-exact with the reference: deepest mean-depth triangle wins, ties go to the lowest index, colour (int)(c0+c1+c2)/3.
+ * ---------------------------------------------------------------------------------------------- */
+size_t vp_render_colors_workspace_bytes(int batch, int h, int w);
+int vp_render_colors(unsigned char* image, unsigned char* face_mask, const float* vertices, const int* triangles,
+                     const float* colors, float* depth_buffer, int ntri, int nver, int h, int w, int c, int batch,
+                     void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BFM reconstruction for a clip ("next" row): replaces the per-frame numpy of
+ * utils/reconstruct_mesh.py Reconstruction_rotation(coeff, facemodel, angles) (:198-223) and the float32 / integer packing
+ * of infer_bfmvid.py:92-99.  All pointers are device pointers.  The model is the reference's `BFM` object
+ * (utils/bfm_load_data.py:9-21) promoted to float64 with 0-based indices: tri [ntri,3]; point_buf [nver,8] with `ntri`
+ * marking "no face" (the reference's appended zero normal, reconstruct_mesh.py:47-49).  `center` = column means of
+ * meanshape (:27), `sh` = {a0c0, a1c1, a2c2, a2c2/2/sqrt(3), a2c2/2} of Illumination_layer (:138-155), both evaluated
+ * by the host in double; focal / image_center are Projection_layer's 1015 / 112 (:100-101).
+ * coeff [frames,257] float32; rotation [frames,9] = Compute_rotation_matrix(angles) (:68-93) row-major, float64.
+ * Outputs: vertices [frames,nver,3] = (x, 224-y, z_buffer) float32 and colors [frames,nver,3] = float(int(clip(c,0,255))),
+ * i.e. exactly the arrays infer_bfmvid.py:101-103 passes to render_colors_core; the float64 intermediates the reference
+ * returns (face_shape, face_texture, face_color, face_projection [.,.,2], z_buffer) are written when non-NULL.
+ * shared_texture != 0: the texture coefficients are constant over the clip, computed once from frame 0
+ * (face_texture then holds 1 frame).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vp_bfm_model {
+  int nver, ntri;
+  const double* meanshape; /* [3*nver] */
+  const double* idBase;    /* [3*nver,80] */
+  const double* exBase;    /* [3*nver,64] */
+  const double* meantex;   /* [3*nver] */
+  const double* texBase;   /* [3*nver,80] */
+  const int* tri;          /* [ntri,3] */
+  const int* point_buf;    /* [nver,8] */
+  double center[3];
+  double focal, image_center;
+  double sh[5];
+} vp_bfm_model;
+size_t vp_bfm_reconstruct_workspace_bytes(int nver, int ntri, int frames);
+int vp_bfm_reconstruct(const vp_bfm_model* m, const float* coeff, const double* rotation, int frames, int shared_texture,
+                       double* face_shape, double* face_texture, double* face_color, double* face_projection, double* z_buffer,
+                       float* vertices, float* colors, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Folds two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs of the same bench command, as
+MI355X_MICROARCH.md 'HBM' prescribes) into per-kernel HBM bytes per launch:
+
+    hbm_bytes = 2 * FETCH_SIZE[KB] * 1024  +  WRITE_SIZE[KB] * 1024        (gfx950: FETCH_SIZE under-reports by 2x)
+
+usage: pmc_summary.py <fetch_dir> <write_dir> <out_prefix>     -> <out_prefix>_hbm_traffic.json, _fetch_per_kernel.csv, _write_per_kernel.csv
+Kernel classes are decoded from the template arguments so bench.py can look a tile shape up by name."""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+IGEMM_TILES = {(2, 2, 4, 4): "128x128", (1, 4, 4, 2): "64x128", (1, 4, 1, 2): "16x128", (4, 1, 2, 2): "128x32", (4, 1, 2, 1): "128x16",
+               (2, 2, 2, 1): "64x32", (2, 4, 4, 4): "128x256", (2, 4, 8, 4): "256x256", (1, 4, 4, 4): "64x256"}
+WGRAD_TILES = {(2, 2, 4, 4): "128x128", (2, 2, 4, 2): "128x64", (4, 1, 2, 1): "128x16"}
+
+
+def classify(name):
+  """'igemm_bf16_128x256' style class of a vp:: conv kernel, from either the mangled name or rocprofv3's (sometimes
+  garbled: bf16 'DF16b' confuses its demangler and swallows the first int) demangled one; None for other kernels."""
+  for fam, tiles in (("igemm_dma_kernel", IGEMM_TILES), ("wgrad_kernel", WGRAD_TILES)):
+    if fam not in name:
+      continue
+    m = re.search(fam + r"I(DF16b|f)((?:Li\d+E)+)", name)
+    if m:
+      dt = "bf16" if m.group(1) == "DF16b" else "f32"
+      ints = tuple(int(x) for x in re.findall(r"Li(\d+)E", m.group(2)))[:4]
+    else:
+      m = re.search(fam + r"<(.*?)>\(", name)
+      if not m:
+        return None
+      args = [a.strip() for a in m.group(1).split(",")]
+      nums = [int(a) for a in args if a.isdigit()]
+      dt = "f32" if args[0] == "float" else "bf16"
+      want = 4 if fam == "igemm_dma_kernel" else 5
+      ints = tuple(nums[:4]) if len(nums) >= want else tuple([1] + nums[:3])     # garbled form lost WC=1
+    t = tiles.get(ints)
+    return "%s_%s_%s" % ("igemm" if fam.startswith("igemm") else "wgrad", dt, t) if t else None
+  return None
+
+
+def load(d, counter):
+  rows = defaultdict(lambda: [0, 0.0, 0.0])
+  for f in glob.glob(d + "/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+      if r["Counter_Name"] != counter:
+        continue
+      e = rows[r["Kernel_Name"]]
+      e[0] += 1
+      e[1] += float(r["Counter_Value"])
+      e[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+  return rows
+
+
+def main():
+  fdir, wdir, prefix = sys.argv[1:4]
+  fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+  out = []
+  for k, (n, kb, us) in fetch.items():
+    wn, wkb, _ = write.get(k, [0, 0.0, 0.0])
+    if "vp::" not in k and "_ZN2vp" not in k:
+      continue
+    f, w = kb / n, (wkb / wn if wn else 0.0)
+    out.append({"kernel": k, "class": classify(k), "launches": n, "fetch_kb_raw": f, "write_kb": w,
+                "hbm_bytes_per_launch": (2 * f + w) * 1024, "avg_us_under_pmc": us / n})
+  out.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
+  json.dump(out, open(prefix + "_hbm_traffic.json", "w"), indent=1)
+  for tag, rows in (("fetch", fetch), ("write", write)):
+    with open("%s_%s_per_kernel.csv" % (prefix, tag), "w") as fo:
+      cw = csv.writer(fo)
+      cw.writerow(["kernel", "launches", "avg_kb_per_launch", "avg_us"])
+      for k, (n, kb, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        cw.writerow([k, n, "%.3f" % (kb / n), "%.3f" % (us / n)])
+  for r in out[:12]:
+    print("%-22s n=%4d hbm %.1f MB/launch  %.1f us" % (r["class"] or r["kernel"][:22], r["launches"], r["hbm_bytes_per_launch"] / 1e6, r["avg_us_under_pmc"]))
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Collects the round's judged evidence on the GPU box into gpurun_out/<tag>_*: the bench line, the rocprofv3 kernel
+# stats of the same command, and the two PMC passes (FETCH_SIZE, WRITE_SIZE; counters only with --kernel-trace).
+# usage (via gpurun):  bash scripts/profile_round.sh r01e
+tag=${1:-r01}
+out=gpurun_out
+mkdir -p $out
+export TMPDIR=/tmp
+python3 bench.py --steps 30 --warmup 10 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats -d $out/${tag}_prof -o ${tag} --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $out/${tag}_prof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $out/${tag}_pmc_write.log 2>&1
+python3 scripts/pmc_summary.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc > $out/${tag}_pmc_summary.txt 2>&1
+# keep the merge-back small: the raw traces are large
+rm -f $out/${tag}_prof/*kernel_trace.csv $out/${tag}_pmc_fetch/*kernel_trace.csv $out/${tag}_pmc_write/*kernel_trace.csv $out/${tag}_pmc_fetch/*counter_collection.csv $out/${tag}_pmc_write/*counter_collection.csv
+tail -c 600 $out/${tag}_bench.json; cat $out/${tag}_pmc_summary.txt | head -8

@@ -9,6 +9,11 @@
                      crop, per-tensor gradient norms, post-Adam parameter checksums
   logmel.npz         log-mel of a seeded 4096-sample chirp+noise, and the 257x80 mel matrix
   bfmnet.npz         BFMNet coefficients for a seeded 5-frame clip (parameters regenerated from the seed)
+  bfm_recon.npz      outputs of the REFERENCE's own utils/reconstruct_mesh.py (pure numpy, imported from /root/reference here)
+                     for a seeded synthetic face model and a 5-frame clip, the float32 / integer packing of
+                     infer_bfmvid.py:92-99, and the frames the compiled reference rasteriser drew from them: reference-captured
+  raster.npz         a synthetic mesh (oracle.raster_ref.synthetic_mesh) and the image / mask / depth the REFERENCE's own
+                     compiled mesh_core.cpp (oracle/_ref, built by oracle/Makefile) rasterised from it: reference-captured
 
 The reference itself cannot produce vectors for this path (TF1.x is not installable: SURVEY.md 8c), so these
 pin the ORACLE against drift and give the GPU tests fixed inputs; they are not reference-captured outputs.
@@ -104,10 +109,58 @@ def audio():
   np.savez_compressed(os.path.join(HERE, "bfmnet.npz"), seed=21, pcm=pcm5, ears=ears, mfcc=mf, coeff=out["BFMCoeffDecoder"], enc=out["MfccEncoder"])
 
 
+def raster():
+  from oracle import raster_ref as rr
+  assert rr.have_compiled_reference(), "run `make -C oracle` first"
+  d = {}
+  for tag, (seed, nlat, nlon, h, w) in {"a": (3, 40, 60, 224, 224), "b": (5, 12, 16, 96, 128)}.items():
+    v, t, c = rr.synthetic_mesh(seed, nlat, nlon, h, w)
+    img, mask, depth = rr.render_colors_ref(v, t, c, h, w)
+    d.update({tag + "_vertices": v, tag + "_triangles": t, tag + "_colors": c, tag + "_image": img, tag + "_mask": mask, tag + "_depth": depth})
+  np.savez_compressed(os.path.join(HERE, "raster.npz"), **d)
+
+
+def bfm_recon():
+  from oracle import bfm_ref as br
+  from oracle import raster_ref as rr
+  sys.path.insert(0, os.path.join(REF, "utils"))
+  import reconstruct_mesh as rm                        # the reference module itself (numpy only)
+  assert rr.have_compiled_reference(), "run `make -C oracle` first"
+  d = {"model_seed": 3, "coeff_seed": 5}
+  fm = br.synthetic_facemodel(3)
+  coeff, angles = br.synthetic_coeffs(5, 5)
+  d["coeff"], d["angles"] = coeff, angles
+  d["model_checksum"] = np.array([fm.idBase.sum(), fm.exBase.sum(), fm.texBase.sum(), fm.meanshape.sum(), fm.meantex.sum(),
+                                  float(fm.tri.sum()), float(fm.point_buf.sum()), float(fm.keypoints.sum())])
+  names = ["face_shape", "face_texture", "face_color", "face_projection", "z_buffer", "landmarks_2d"]
+  outs = {n: [] for n in names}
+  verts, cols, imgs, masks = [], [], [], []
+  for t in range(coeff.shape[0]):
+    res = rm.Reconstruction_rotation(coeff[t:t + 1], fm, angles[t:t + 1])
+    for n, r in zip(names, res):
+      outs[n].append(r[0])
+    # infer_bfmvid.py:92-108
+    shape = np.squeeze(np.concatenate([res[3], res[4]], axis=2), (0))
+    color = np.clip(np.squeeze(res[2], (0)), 0, 255).astype(np.int32)
+    v, c = shape.reshape(-1).astype(np.float32).copy(), color.reshape(-1).astype(np.float32).copy()
+    img, mask, _ = rr.render_colors_ref(v, (fm.tri - 1).reshape(-1).astype(np.int32), c, 224, 224)
+    verts.append(v.reshape(-1, 3)); cols.append(c.reshape(-1, 3)); imgs.append(img); masks.append(mask)
+  for n in names:
+    d[n] = np.stack(outs[n])
+  d["vertices"], d["colors"], d["images"], d["masks"] = np.stack(verts), np.stack(cols), np.stack(imgs), np.stack(masks)
+  np.savez_compressed(os.path.join(HERE, "bfm_recon.npz"), **d)
+
+
 if __name__ == "__main__":
+  if sys.argv[1:] == ["raster"]:
+    raster()
+    bfm_recon()
+    sys.exit(0)
   panels, bg = sample22()
   toy_ops()
   mini_step(panels, bg)
   audio()
+  raster()
+  bfm_recon()
   for f in sorted(os.listdir(HERE)):
     print(f, os.path.getsize(os.path.join(HERE, f)))

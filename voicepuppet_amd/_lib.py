@@ -31,6 +31,13 @@ class BfmNetDesc(ctypes.Structure):
   _fields_ = [("batch", ctypes.c_int), ("frames", ctypes.c_int), ("num_mel_bins", ctypes.c_int)]
 
 
+class BfmModel(ctypes.Structure):
+  _fields_ = [("nver", ctypes.c_int), ("ntri", ctypes.c_int), ("meanshape", ctypes.c_void_p), ("idBase", ctypes.c_void_p),
+              ("exBase", ctypes.c_void_p), ("meantex", ctypes.c_void_p), ("texBase", ctypes.c_void_p), ("tri", ctypes.c_void_p),
+              ("point_buf", ctypes.c_void_p), ("center", ctypes.c_double * 3), ("focal", ctypes.c_double),
+              ("image_center", ctypes.c_double), ("sh", ctypes.c_double * 5)]
+
+
 _P = ctypes.c_void_p
 _SIGNATURES = {
     "vp_version": (ctypes.c_int, []),
@@ -74,6 +81,11 @@ _SIGNATURES = {
     "vp_bfmnet_params_changed": (ctypes.c_int, [_P]),
     "vp_bfmnet_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "vp_bfmnet_tensor": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
+    "vp_bfm_reconstruct_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vp_bfm_reconstruct": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "vp_render_colors_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vp_render_colors": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, _P, _P]),
     "vp_bn_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P]),
 }
 

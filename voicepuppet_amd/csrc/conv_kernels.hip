@@ -1129,6 +1129,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     case 5: e = launch_igemm_cfg<T, 2, 2, 2, 1>(a, st); break;   //  64 ch x  32 px
     case 6: e = launch_igemm_cfg<T, 2, 4, 4, 4>(a, st); break;   // 128 ch x 256 px, 8 waves
     case 7: e = launch_igemm_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 ch x 256 px, 8 waves
+    case 8: e = launch_igemm_cfg<T, 1, 4, 4, 4>(a, st); break;   //  64 ch x 256 px, 4 waves
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -1147,7 +1148,7 @@ hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st
 }
 
 void igemm_tile(int cfg, int* bc, int* bp) {
-  static const int t[8][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}, {128, 256}, {256, 256}};
+  static const int t[9][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}, {128, 256}, {256, 256}, {64, 256}};
   *bc = t[cfg][0]; *bp = t[cfg][1];
 }
 

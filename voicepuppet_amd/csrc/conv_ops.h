@@ -36,6 +36,7 @@ inline int pick_igemm_cfg(int rows, int P) {
     if ((big & 2) && rows % 256 == 0 && P >= 256 * 512) return 7;
     if ((big & 1) && rows % 128 == 0 && P >= 256 * 512) return 6;
     if (rows % 128 == 0) return 0;
+    if ((big & 4) && rows % 64 == 0 && P >= 256 * 512) return 8;
     if (rows % 64 == 0) return 1;
     if (rows <= 16) return 2;
     return rows > 64 ? 0 : 1;
