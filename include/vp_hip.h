@@ -206,10 +206,10 @@ int vp_render_colors(unsigned char* image, unsigned char* face_mask, const float
 typedef struct vp_bfm_model {
   int nver, ntri;
   const double* meanshape; /* [3*nver] */
-  const double* idBase;    /* [3*nver,80] */
-  const double* exBase;    /* [3*nver,64] */
+  const double* idBase;    /* [80,3*nver]  K-MAJOR: the reference's [3*nver,80] transposed once at model load */
+  const double* exBase;    /* [64,3*nver] */
   const double* meantex;   /* [3*nver] */
-  const double* texBase;   /* [3*nver,80] */
+  const double* texBase;   /* [80,3*nver] */
   const int* tri;          /* [ntri,3] */
   const int* point_buf;    /* [nver,8] */
   double center[3];

@@ -18,8 +18,10 @@ class FaceModel:
     self.point_buf, self.tri, self.keypoints = point_buf, tri, keypoints
 
 
-def synthetic_facemodel(seed=0, nlat=14, nlon=18, dtype=np.float64):
-  """A front half-ellipsoid 'face' of nlat*nlon vertices at the BFM's scale (decimetres, |x|,|y| <~ 1), random bases."""
+def synthetic_facemodel(seed=0, nlat=14, nlon=18, dtype=np.float64, smooth=False):
+  """A front half-ellipsoid 'face' of nlat*nlon vertices at the BFM's scale (decimetres, |x|,|y| <~ 1).  Bases: white noise
+  per vertex (default; fine for the small parity fixtures) or, with smooth=True, low-frequency deformation fields like the
+  real PCA bases, so that a BFM-sized mesh keeps sub-pixel triangles (the benchmark geometry)."""
   rng = np.random.default_rng(seed)
   th = np.linspace(0.25, np.pi - 0.25, nlat)
   ph = np.linspace(0.2, np.pi - 0.2, nlon)
@@ -39,9 +41,18 @@ def synthetic_facemodel(seed=0, nlat=14, nlon=18, dtype=np.float64):
     for v in tri[f] - 1:
       point_buf[v, fill[v]] = f + 1
       fill[v] += 1
-  return FaceModel(meanshape=xyz.reshape(1, -1).astype(dtype), idBase=(0.02 * rng.normal(size=(3 * n, 80))).astype(dtype),
-                   exBase=(0.03 * rng.normal(size=(3 * n, 64))).astype(dtype),
-                   meantex=rng.uniform(90, 200, size=(1, 3 * n)).astype(dtype), texBase=(4.0 * rng.normal(size=(3 * n, 80))).astype(dtype),
+  def field(k, amp):
+    if not smooth:
+      return amp * rng.normal(size=(3 * n, k))
+    a, c = rng.integers(1, 5, size=k), rng.integers(1, 5, size=k)
+    b, d = rng.uniform(0, 2 * np.pi, size=k), rng.uniform(0, 2 * np.pi, size=k)
+    wave = np.sin(T.reshape(-1, 1) * a + b) * np.cos(P.reshape(-1, 1) * c + d)          # [n,k]
+    return (amp * wave[:, None, :] * rng.normal(size=(1, 3, k))).reshape(3 * n, k)
+  idb, exb = field(80, 0.02), field(64, 0.03)
+  meantex = rng.uniform(90, 200, size=(1, 3 * n))
+  texb = field(80, 4.0)
+  return FaceModel(meanshape=xyz.reshape(1, -1).astype(dtype), idBase=idb.astype(dtype), exBase=exb.astype(dtype),
+                   meantex=meantex.astype(dtype), texBase=texb.astype(dtype),
                    point_buf=point_buf, tri=tri, keypoints=rng.choice(n, 68, replace=False).astype(np.int32))
 
 

@@ -48,6 +48,13 @@ def test_float32_model_follows_reference_dtype_promotion():
     assert _rel(a[n], b[n]) < 5e-6, n
 
 
+def test_host_rotation_matrices_bit_identical_to_per_frame_form():
+  # the clip-wide numpy form the host wrapper uploads == the reference's one-frame-at-a-time construction (oracle restates it)
+  from voicepuppet_amd.utils.reconstruct_mesh import Compute_rotation_matrix
+  ang = np.random.default_rng(0).normal(0, 0.5, size=(300, 3)).astype(np.float32)
+  assert np.array_equal(Compute_rotation_matrix(ang), br.rotation_matrices(ang))
+
+
 @pytest.mark.gpu
 def test_gpu_reconstruct_matches_reference_golden():
   from voicepuppet_amd.utils import reconstruct_mesh as vrm

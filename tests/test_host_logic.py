@@ -135,3 +135,14 @@ def test_missing_config_exits_with_status_zero(tmp_path):
   with pytest.raises(SystemExit) as e:
     train_pixrefer.main([])
   assert e.value.code == 0
+
+
+def test_angle_sequence_follows_render_face_state_machine():
+  # infer_bfmvid.py:76-90: +0.005 per frame on all three angles, direction flips once |angle_y| passes 0.03
+  from voicepuppet_amd.pixrefer.infer_bfmvid import angle_sequence
+  a = angle_sequence(40)
+  assert a.shape == (40, 3) and a.dtype == np.float32
+  assert np.array_equal(a[:, 0], a[:, 1]) and np.array_equal(a[:, 1], a[:, 2])
+  d = np.diff(np.concatenate([[0.0], a[:, 1]]))
+  assert np.allclose(np.abs(d), 0.005, atol=1e-6)
+  assert a[:, 1].max() < 0.0401 and a[:, 1].min() > -0.0401 and (d < 0).any() and (d[20:] > 0).any()

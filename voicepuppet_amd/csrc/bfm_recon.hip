@@ -4,7 +4,7 @@
 // float64 once, at model load), so the float32 vertices / integer colours handed to the rasteriser agree with the
 // reference's; the work is HBM-bound on the three basis matrices, which are read ONCE per clip instead of once per frame.
 //
-//   linear  : shape/texture = base[3N,K] . coeff[T,K] + mean   (64 rows per block staged through LDS, coalesced)
+//   linear  : shape/texture = base[3N,K] . coeff[T,K] + mean   (thread per row over K-MAJOR bases, 32 frames per pass)
 //   fnormal : per (frame, triangle) cross product              (:43-46)
 //   vertex  : per (frame, vertex) one-ring normal, rotate, project, SH lighting, pack   (:50-52, :208-221, :100-169)
 #include <hip/hip_runtime.h>
@@ -16,12 +16,11 @@
 
 namespace vp {
 
-constexpr int BFM_ROWS = 64;      // rows of a basis matrix per block
-constexpr int BFM_FT = 8;         // frames per thread
-constexpr int BFM_FRAMES = 32;    // frames per block pass = 4 waves x BFM_FT
+constexpr int BFM_FT = 32;        // frames per thread (one pass of the bases serves 32 frames)
+constexpr int BFM_LIN_THREADS = 128;
 
 struct LinearArgs {
-  const double* b1; int k1; int o1;      // base [rows,k1], coefficient offset into the 257 vector
+  const double* b1; int k1; int o1;      // K-MAJOR base [k1][rows] (transposed once at model load), coefficient offset into the 257 vector
   const double* b2; int k2; int o2;      // optional second base
   const double* mean;                    // [rows]
   double sub[3];                         // subtracted per coordinate (the mean-shape centre, :27)
@@ -30,42 +29,44 @@ struct LinearArgs {
   int rows, frames;
 };
 
-__global__ __launch_bounds__(256) void bfm_linear_kernel(LinearArgs a) {
-  extern __shared__ double smem[];
+// out[f][row] = sum_k base[k][row] * coeff[f][k] + mean[row] - sub[row % 3].  One thread per row: the k-major base makes
+// every load a coalesced 512-byte wave request and the 144 loads of a thread are independent (deep HBM pipelining);
+// the clip's coefficients sit in LDS as [k][frame] and are read as wave-uniform broadcasts, two frames per ds_read_b128.
+__global__ __launch_bounds__(BFM_LIN_THREADS) void bfm_linear_kernel(LinearArgs a) {
+  __shared__ double sc[144 * BFM_FT];
   const int K = a.k1 + a.k2;
-  const int ldb = K + 1;                                   // odd stride in doubles: conflict-free column reads
-  double* sb = smem;                                       // [BFM_ROWS][ldb]
-  double* sc = smem + BFM_ROWS * ldb;                      // [BFM_FRAMES][K]
-  const int row0 = blockIdx.x * BFM_ROWS;
-  const int nrow = min(BFM_ROWS, a.rows - row0);
-  for (int i = threadIdx.x; i < nrow * a.k1; i += 256) sb[(i / a.k1) * ldb + i % a.k1] = a.b1[(size_t)row0 * a.k1 + i];
-  for (int i = threadIdx.x; i < nrow * a.k2; i += 256) sb[(i / a.k2) * ldb + a.k1 + i % a.k2] = a.b2[(size_t)row0 * a.k2 + i];
-  const int r = threadIdx.x & 63, fg = threadIdx.x >> 6;
-  for (int f0 = 0; f0 < a.frames; f0 += BFM_FRAMES) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < BFM_FRAMES * K; i += 256) {
-      const int f = f0 + i / K, k = i % K;
-      sc[i] = (f < a.frames) ? (double)a.coeff[(size_t)f * 257 + (k < a.k1 ? a.o1 + k : a.o2 + k - a.k1)] : 0.0;
-    }
-    __syncthreads();
-    double acc[BFM_FT];
-#pragma unroll
-    for (int j = 0; j < BFM_FT; ++j) acc[j] = 0.0;
-    if (r < nrow) {
-      for (int k = 0; k < K; ++k) {
-        const double b = sb[r * ldb + k];
-#pragma unroll
-        for (int j = 0; j < BFM_FT; ++j) acc[j] = fma(b, sc[(fg * BFM_FT + j) * K + k], acc[j]);
-      }
-      const int row = row0 + r;
-      const double add = a.mean[row], sub = a.sub[row % 3];
-#pragma unroll
-      for (int j = 0; j < BFM_FT; ++j) {
-        const int f = f0 + fg * BFM_FT + j;
-        if (f < a.frames) a.out[(size_t)f * a.rows + row] = (acc[j] + add) - sub;
-      }
-    }
+  const int f0 = blockIdx.y * BFM_FT;
+  for (int i = threadIdx.x; i < K * BFM_FT; i += BFM_LIN_THREADS) {
+    const int k = i / BFM_FT, f = f0 + i % BFM_FT;
+    sc[i] = (f < a.frames) ? (double)a.coeff[(size_t)f * 257 + (k < a.k1 ? a.o1 + k : a.o2 + k - a.k1)] : 0.0;
   }
+  __syncthreads();
+  const int row = blockIdx.x * BFM_LIN_THREADS + threadIdx.x;
+  if (row >= a.rows) return;
+  double acc[BFM_FT];
+#pragma unroll
+  for (int j = 0; j < BFM_FT; ++j) acc[j] = 0.0;
+  const int nf = min(BFM_FT, a.frames - f0);
+  auto accumulate = [&](const double* __restrict__ base, int kn, int kofs) {
+#pragma unroll 4
+    for (int k = 0; k < kn; ++k) {
+      const double b = __builtin_nontemporal_load(base + (size_t)k * a.rows + row);
+      const double2* c = reinterpret_cast<const double2*>(sc + (kofs + k) * BFM_FT);
+      if (nf <= 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double2 v = c[j]; acc[2 * j] = fma(b, v.x, acc[2 * j]); acc[2 * j + 1] = fma(b, v.y, acc[2 * j + 1]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < BFM_FT / 2; ++j) { const double2 v = c[j]; acc[2 * j] = fma(b, v.x, acc[2 * j]); acc[2 * j + 1] = fma(b, v.y, acc[2 * j + 1]); }
+      }
+    }
+  };
+  accumulate(a.b1, a.k1, 0);
+  if (a.k2) accumulate(a.b2, a.k2, a.k1);
+  const double add = a.mean[row], sub = a.sub[row % 3];
+#pragma unroll
+  for (int j = 0; j < BFM_FT; ++j)
+    if (j < nf) a.out[(size_t)(f0 + j) * a.rows + row] = (acc[j] + add) - sub;
 }
 
 __global__ __launch_bounds__(256) void bfm_fnormal_kernel(const double* __restrict__ shape, const int* __restrict__ tri, double* __restrict__ fn,
@@ -184,14 +185,12 @@ int vp_bfm_reconstruct(const vp_bfm_model* m, const float* coeff, const double* 
   la.b1 = m->idBase; la.k1 = 80; la.o1 = 0; la.b2 = m->exBase; la.k2 = 64; la.o2 = 80;
   la.mean = m->meanshape; la.sub[0] = m->center[0]; la.sub[1] = m->center[1]; la.sub[2] = m->center[2];
   la.coeff = coeff; la.out = shape; la.rows = rows; la.frames = frames;
-  const int nb = (rows + vp::BFM_ROWS - 1) / vp::BFM_ROWS;
-  size_t smem = ((size_t)vp::BFM_ROWS * (144 + 1) + (size_t)vp::BFM_FRAMES * 144) * sizeof(double);
-  VP_HIP_CHECK(hipFuncSetAttribute((const void*)vp::bfm_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(vp::bfm_linear_kernel, dim3(nb), dim3(256), smem, st, la);
+  const int nb = (rows + vp::BFM_LIN_THREADS - 1) / vp::BFM_LIN_THREADS;
+  hipLaunchKernelGGL(vp::bfm_linear_kernel, dim3(nb, (frames + vp::BFM_FT - 1) / vp::BFM_FT), dim3(vp::BFM_LIN_THREADS), 0, st, la);
   vp::LinearArgs lt{};
   lt.b1 = m->texBase; lt.k1 = 80; lt.o1 = 144; lt.b2 = nullptr; lt.k2 = 0; lt.o2 = 0; lt.mean = m->meantex;
   lt.coeff = coeff; lt.out = tex; lt.rows = rows; lt.frames = tex_frames;
-  hipLaunchKernelGGL(vp::bfm_linear_kernel, dim3(nb), dim3(256), smem, st, lt);
+  hipLaunchKernelGGL(vp::bfm_linear_kernel, dim3(nb, (tex_frames + vp::BFM_FT - 1) / vp::BFM_FT), dim3(vp::BFM_LIN_THREADS), 0, st, lt);
   hipLaunchKernelGGL(vp::bfm_fnormal_kernel, dim3((m->ntri + 1 + 255) / 256, frames), dim3(256), 0, st, shape, m->tri, fn, m->nver, m->ntri);
   vp::VertexArgs va{};
   va.shape = shape; va.tex = tex; va.fn = fn; va.point_buf = m->point_buf; va.rot = rotation; va.coeff = coeff;

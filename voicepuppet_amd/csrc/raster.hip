@@ -42,27 +42,56 @@ __global__ __launch_bounds__(256) void raster_init_kernel(const float* __restric
   if (i < n) keys[i] = ((unsigned long long)depth_bits(depth[i]) << 32) | 0xFFFFFFFFull;   // beats every triangle of equal depth
 }
 
+// bounding boxes up to this many pixels are scanned by the triangle's own lane; larger ones by the whole wave
+constexpr int RASTER_LANE_AREA = 32;
+
 __global__ __launch_bounds__(256) void raster_tri_kernel(const float* __restrict__ vertices, const int* __restrict__ triangles,
                                                          unsigned long long* __restrict__ keys, int ntri, int nver, int h, int w, int batch) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
-  if (t >= ntri || b >= batch) return;
+  const int lane = threadIdx.x & 63;
   const float* V = vertices + (size_t)b * nver * 3;
-  const int i0 = triangles[3 * t], i1 = triangles[3 * t + 1], i2 = triangles[3 * t + 2];
-  const float p0x = V[3 * i0], p0y = V[3 * i0 + 1], d0 = V[3 * i0 + 2];
-  const float p1x = V[3 * i1], p1y = V[3 * i1 + 1], d1 = V[3 * i1 + 2];
-  const float p2x = V[3 * i2], p2y = V[3 * i2 + 1], d2 = V[3 * i2 + 2];
-  const int x_min = max((int)ceilf(fminf(p0x, fminf(p1x, p2x))), 0);
-  const int x_max = min((int)floorf(fmaxf(p0x, fmaxf(p1x, p2x))), w - 1);
-  const int y_min = max((int)ceilf(fminf(p0y, fminf(p1y, p2y))), 0);
-  const int y_max = min((int)floorf(fmaxf(p0y, fmaxf(p1y, p2y))), h - 1);
-  if (x_max < x_min || y_max < y_min) return;
-  const float pd = ((d0 + d1) + d2) / 3.f;
-  const unsigned long long key = ((unsigned long long)depth_bits(pd) << 32) | (unsigned long long)(0xFFFFFFFEu - (unsigned)t);
   unsigned long long* K = keys + (size_t)b * h * w;
-  for (int y = y_min; y <= y_max; ++y)
-    for (int x = x_min; x <= x_max; ++x)
-      if (point_in_tri((float)x, (float)y, p0x, p0y, p1x, p1y, p2x, p2y)) atomicMax(K + (size_t)y * w + x, key);
+  float p0x = 0, p0y = 0, p1x = 0, p1y = 0, p2x = 0, p2y = 0;
+  int x_min = 0, x_max = -1, y_min = 0, y_max = -1;
+  unsigned int khi = 0, klo = 0;
+  if (t < ntri) {
+    const int i0 = triangles[3 * t], i1 = triangles[3 * t + 1], i2 = triangles[3 * t + 2];
+    p0x = V[3 * i0]; p0y = V[3 * i0 + 1];
+    p1x = V[3 * i1]; p1y = V[3 * i1 + 1];
+    p2x = V[3 * i2]; p2y = V[3 * i2 + 1];
+    const float d0 = V[3 * i0 + 2], d1 = V[3 * i1 + 2], d2 = V[3 * i2 + 2];
+    x_min = max((int)ceilf(fminf(p0x, fminf(p1x, p2x))), 0);
+    x_max = min((int)floorf(fmaxf(p0x, fmaxf(p1x, p2x))), w - 1);
+    y_min = max((int)ceilf(fminf(p0y, fminf(p1y, p2y))), 0);
+    y_max = min((int)floorf(fmaxf(p0y, fmaxf(p1y, p2y))), h - 1);
+    khi = depth_bits(((d0 + d1) + d2) / 3.f);
+    klo = 0xFFFFFFFEu - (unsigned)t;
+  }
+  const bool covers = x_max >= x_min && y_max >= y_min;
+  const int bw = x_max - x_min + 1;
+  const int area = covers ? bw * (y_max - y_min + 1) : 0;
+  if (area > 0 && area <= RASTER_LANE_AREA) {
+    const unsigned long long key = ((unsigned long long)khi << 32) | klo;
+    for (int y = y_min; y <= y_max; ++y)
+      for (int x = x_min; x <= x_max; ++x)
+        if (point_in_tri((float)x, (float)y, p0x, p0y, p1x, p1y, p2x, p2y)) atomicMax(K + (size_t)y * w + x, key);
+  }
+  // triangles with a large box: one at a time, pixels across the 64 lanes (a BFM frame has none; meshes with
+  // slivers or close-ups do, and a single lane walking a 10^4-pixel box would stall its whole wave)
+  unsigned long long big = __ballot(area > RASTER_LANE_AREA);
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const float q0x = __shfl(p0x, src), q0y = __shfl(p0y, src), q1x = __shfl(p1x, src), q1y = __shfl(p1y, src);
+    const float q2x = __shfl(p2x, src), q2y = __shfl(p2y, src);
+    const int xm = __shfl(x_min, src), ym = __shfl(y_min, src), qw = __shfl(bw, src), qa = __shfl(area, src);
+    const unsigned long long key = ((unsigned long long)__shfl(khi, src) << 32) | __shfl(klo, src);
+    for (int i = lane; i < qa; i += 64) {
+      const int y = ym + i / qw, x = xm + i % qw;
+      if (point_in_tri((float)x, (float)y, q0x, q0y, q1x, q1y, q2x, q2y)) atomicMax(K + (size_t)y * w + x, key);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ vertices,

@@ -7,10 +7,13 @@
 wav -> log-mel -> BFMNet -> 64 expression coefficients per video frame -> (3-D face conditioning image) ->
 PixReferNet -> output/<i>.jpg (-> ffmpeg mux when ffmpeg exists).
 
-The per-frame conditioning image needs the BFM reconstruction + rasteriser (utils/reconstruct_mesh.py,
-utils/cython/mesh_core.cpp) and their external assets (BFM_model_front.mat, FaceReconModel.pb, the dlib/MXNet
-aligners).  Those are the "next" rows of SURVEY.md 8f; without them every frame is conditioned on the 3-D face
-panel of the input image (a warning is printed), which still exercises audio -> coefficients -> generator.
+The per-frame conditioning image is the BFM reconstruction + rasteriser (utils/reconstruct_mesh.py,
+utils/cython/mesh_core.cpp), which run on the device for the whole clip at once (voicepuppet_amd.utils.reconstruct_mesh.
+ClipRenderer).  They need external assets: BFM/BFM_model_front.mat and the photo's own 257 coefficients + alignment, which
+the reference obtains from FaceReconModel.pb and the dlib/MXNet aligners (infer_bfmvid.py:47-74; out of scope).  Pass those
+as `--bfmcoeff <npz with bfmcoeff[1,257], transform_params[5], center_x, center_y, ratio>`; without them every frame is
+conditioned on the 3-D face panel of the input image (a warning is printed), which still exercises audio -> coefficients
+-> generator.
 Frames are batched on the device with per-sample batch-norm statistics, which is arithmetically the
 reference's batch-1 loop (infer_bfmvid.py:231-243).
 """
@@ -50,10 +53,46 @@ def splice_coeff(bfmcoeff, expr_seq):
   return np.concatenate([tiled[:, :, :80], expr_seq, tiled[:, :, 144:]], axis=2)
 
 
+def angle_sequence(frames, start=(0.0, 0.0, 0.0), shift=0.005):
+  """The head-sway state machine of render_face (infer_bfmvid.py:76-90), unrolled for a clip: all three angles advance by
+  `shift` per frame (float32 accumulation, like the reference's global array) and the direction flips after |angle_y| > 0.03."""
+  angles = np.array([start], dtype=np.float32)
+  out = np.zeros((frames, 3), np.float32)
+  for i in range(frames):
+    angles[0][0] += shift
+    angles[0][1] += shift
+    angles[0][2] += shift
+    if (angles[0][1] > 0.03 or angles[0][1] < -0.03):
+      shift = -shift
+    out[i] = angles[0]
+  return out
+
+
+def render_faces(renderer, center_x, center_y, ratio, bfm_coeff_seq, img_shape, transform_params):
+  """render_face (infer_bfmvid.py:79-122) for every frame of the clip: one device pass for reconstruction + rasterisation,
+  then the reference's per-frame channel swap / resize / paste on the host (PIL bilinear standing in for cv2.resize)."""
+  from PIL import Image
+  ratio = ratio * transform_params[2]
+  tx = -int((transform_params[3] / ratio))
+  ty = -int((transform_params[4] / ratio))
+  T = bfm_coeff_seq.shape[0]
+  images, _ = renderer(bfm_coeff_seq.astype(np.float32), angle_sequence(T))
+  images = images.cpu().numpy()[..., ::-1]                                       # cv2.cvtColor(BGR2RGB), :110
+  side = int(round(224 / ratio))
+  out = np.zeros((T,) + tuple(img_shape), np.uint8)
+  for i in range(T):
+    face = np.asarray(Image.fromarray(np.ascontiguousarray(images[i])).resize((side, side), Image.BILINEAR))
+    cx, cy = face.shape[1] // 2, face.shape[0] // 2
+    out[i, center_y - cy - ty:center_y - cy + face.shape[0] - ty, center_x - cx - tx:center_x - cx + face.shape[1] - tx, :] = face
+  return out
+
+
 def main(argv=None):
   cmd_parser = OptionParser(usage="usage: %prog [options] --config_path <> image audio")
   cmd_parser.add_option('--config_path', type="string", dest="config_path", help='the config yaml file')
   cmd_parser.add_option('--frame_batch', type="int", dest="frame_batch", default=8, help='frames per device batch')
+  cmd_parser.add_option('--bfmcoeff', type="string", dest="bfmcoeff", default=None,
+                        help='npz with the photo\'s bfmcoeff [1,257], transform_params [5], center_x, center_y, ratio')
   opts, argv = cmd_parser.parse_args(argv)
 
   if (opts.config_path is None):
@@ -121,7 +160,23 @@ def main(argv=None):
 
     ### Run inference
     bfm_coeff_seq = sess.run(bfmnet_nodes['BFMCoeffDecoder'])
-    logger.warning('BFM assets unavailable: conditioning every frame on the reference 3-D face panel')
+    face3d_seq = None
+    if opts.bfmcoeff and os.path.exists(os.path.join('BFM', 'BFM_model_front.mat')):
+      from scipy.io import loadmat
+      from voicepuppet_amd.utils.reconstruct_mesh import ClipRenderer
+
+      class _BFM(object):      # utils/bfm_load_data.py:9-21
+        def __init__(self, model):
+          for k in ('meanshape', 'idBase', 'exBase', 'meantex', 'texBase', 'point_buf', 'tri'):
+            setattr(self, k, model[k])
+          self.keypoints = np.squeeze(model['keypoints']).astype(np.int32) - 1
+      photo = np.load(opts.bfmcoeff)
+      coeff_seq = splice_coeff(photo['bfmcoeff'].reshape(1, 257), bfm_coeff_seq)[0]
+      face3d_seq = render_faces(ClipRenderer(_BFM(loadmat(os.path.join('BFM', 'BFM_model_front.mat')))), int(photo['center_x']),
+                                int(photo['center_y']), float(photo['ratio']), coeff_seq, (img_size, img_size, 3),
+                                photo['transform_params'])
+    else:
+      logger.warning('BFM assets unavailable: conditioning every frame on the reference 3-D face panel')
 
     T = bfm_coeff_seq.shape[1]
     inputs = np.zeros([nb, img_size, img_size, 6], dtype=np.float32)
@@ -133,7 +188,8 @@ def main(argv=None):
     for i0 in range(0, T, nb):
       for k in range(nb):
         i = min(i0 + k, T - 1)
-        inputs[k, ..., 3:6] = face3d_refer
+        # render_face returns a BGR canvas that the caller swaps again (infer_bfmvid.py:233): net effect = rasteriser order
+        inputs[k, ..., 3:6] = face3d_refer if face3d_seq is None else face3d_seq[i][..., ::-1].astype(np.float32) / 255.0
         bg = 'background/{}.jpg'.format(i % 100 + 1)
         targets[k] = (ImageLoader(resize=(img_size, img_size)).get_data(bg)[:, :, ::-1] if os.path.exists(bg) else 0.5)
       frames, last = sess.run([vid2vid_nodes['Outputs'], vid2vid_nodes['Outputs_FG']],

@@ -28,16 +28,15 @@ def Split_coeff(coeff):
 
 
 def Compute_rotation_matrix(angles):
-  """reconstruct_mesh.py:68-93 for [T,3] angles (the reference takes T=1): float64 [T,3,3] = (Rz Ry Rx)^T."""
+  """reconstruct_mesh.py:68-93 for [T,3] angles (the reference takes T=1): float64 [T,3,3] = (Rz Ry Rx)^T, all frames at once."""
   angles = np.asarray(angles)
-  out = np.empty((angles.shape[0], 3, 3), np.float64)
-  for t in range(angles.shape[0]):
-    ax, ay, az = angles[t, 0], angles[t, 1], angles[t, 2]
-    rx = np.array([1.0, 0, 0, 0, np.cos(ax), -np.sin(ax), 0, np.sin(ax), np.cos(ax)]).reshape(3, 3)
-    ry = np.array([np.cos(ay), 0, np.sin(ay), 0, 1, 0, -np.sin(ay), 0, np.cos(ay)]).reshape(3, 3)
-    rz = np.array([np.cos(az), -np.sin(az), 0, np.sin(az), np.cos(az), 0, 0, 0, 1]).reshape(3, 3)
-    out[t] = np.matmul(np.matmul(rz, ry), rx).T
-  return out
+  T = angles.shape[0]
+  c, s = np.cos(angles), np.sin(angles)                      # same dtype promotion as the reference's scalar calls
+  one, zero = np.ones(T), np.zeros(T)
+  rx = np.stack([one, zero, zero, zero, c[:, 0], -s[:, 0], zero, s[:, 0], c[:, 0]], 1).reshape(T, 3, 3)
+  ry = np.stack([c[:, 1], zero, s[:, 1], zero, one, zero, -s[:, 1], zero, c[:, 1]], 1).reshape(T, 3, 3)
+  rz = np.stack([c[:, 2], -s[:, 2], zero, s[:, 2], c[:, 2], zero, zero, zero, one], 1).reshape(T, 3, 3)
+  return np.ascontiguousarray(np.transpose(np.matmul(np.matmul(rz, ry), rx), (0, 2, 1)))
 
 
 class DeviceFaceModel:
@@ -51,11 +50,14 @@ class DeviceFaceModel:
     self.device = dev
     self.meanshape = f64(np.asarray(facemodel.meanshape).reshape(-1))
     self.nver = self.meanshape.numel() // 3
-    self.idBase, self.exBase, self.texBase = f64(facemodel.idBase), f64(facemodel.exBase), f64(facemodel.texBase)
+    for k, width in (("idBase", 80), ("exBase", 64), ("texBase", 80)):
+      if tuple(np.shape(getattr(facemodel, k))) != (3 * self.nver, width):
+        raise ValueError("face model shapes must be idBase [3N,80], exBase [3N,64], texBase [3N,80], meanshape/meantex [1,3N]")
+    # k-major copies ([K,3N]): every basis load of the device kernel is then a coalesced wave request
+    self.idBase, self.exBase, self.texBase = (f64(np.asarray(getattr(facemodel, k)).T) for k in ("idBase", "exBase", "texBase"))
     self.meantex = f64(np.asarray(facemodel.meantex).reshape(-1))
-    if tuple(self.idBase.shape) != (3 * self.nver, 80) or tuple(self.exBase.shape) != (3 * self.nver, 64) or \
-        tuple(self.texBase.shape) != (3 * self.nver, 80) or self.meantex.numel() != 3 * self.nver:
-      raise ValueError("face model shapes must be idBase [3N,80], exBase [3N,64], texBase [3N,80], meanshape/meantex [1,3N]")
+    if self.meantex.numel() != 3 * self.nver:
+      raise ValueError("meantex must be [1,3N]")
     tri = np.ascontiguousarray((np.asarray(facemodel.tri) - 1).astype(np.int32))
     pb = np.ascontiguousarray((np.asarray(facemodel.point_buf) - 1).astype(np.int32))
     self.ntri = tri.shape[0]
