@@ -24,6 +24,8 @@ hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate, int is_bf16, hipStream_t st);
 hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int C, int Pg, size_t npix,
                             void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st);
+hipError_t launch_tap_gather(const TapArgs& a, hipStream_t st);
+hipError_t launch_tap_spread(const TapArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_pack_inputs(const PackInputsArgs& a, int is_bf16, hipStream_t st);
 int composite_nblocks(int N, int HW);
 hipError_t launch_composite_fwd(const CompositeArgs& a, int is_bf16, hipStream_t st);

@@ -74,6 +74,10 @@ struct Layer {
   bool need_bwd[2] = {false, false};
   IgemmPlan fwd, bwd[2], bwd_alt[2];   // bwd_alt: discriminator G-loss pass (batch N)
   WgradPlan wg;
+  // one-output-channel stride-1 conv (D layer_5) run as a GEMM over taps (TapArgs): x is read once per pass, not 16 times
+  bool tapgemm = false;
+  float* tap_S = nullptr;    // [N,Hin,Win,16] f32
+  void* tap_dyS = nullptr;   // [N,Hin,Win,16] T
 };
 
 struct ParamInfo { std::string name; size_t off; int ndim; int64_t shape[4]; };
@@ -236,8 +240,18 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
     n.descs.push_back(p.pack);
     if (p.partial_bytes > *scratch_max) *scratch_max = p.partial_bytes;
   };
+  static const bool tap_on = !getenv("VP_NO_TAPGEMM");
   for (Layer& L : n.l) {
-    L.fwd = plan_fwd(L.g, L.w_off, bf16);
+    L.tapgemm = tap_on && training && L.g.kind == 0 && L.g.stride == 1 && L.g.ks == 4 && L.g.Cout == 1 && L.nsrc == 1 && !L.has_bn &&
+                L.g.Cin == L.g.Cin_real;
+    if (L.tapgemm) {
+      // S = x . W^T as a 1x1 conv with 16 output channels: row t of the packed matrix is W[kh,kw,:,0] (HWIO, Cout = 1)
+      ConvGeomX g1 = make_geom(0, 1, 1, 0, L.g.N, L.g.Hin, L.g.Win, L.g.Cin, L.g.Cin, 16);
+      L.fwd = plan_fwd(g1, L.w_off, bf16);
+      L.fwd.pack.s_row = L.g.Cin; L.fwd.pack.s_ch = 1; L.fwd.pack.s_kh = 0; L.fwd.pack.s_kw = 0;
+    } else {
+      L.fwd = plan_fwd(L.g, L.w_off, bf16);
+    }
     take(L.fwd);
     L.pk_fwd = L.fwd.pack.dst_off;
     if (!training) continue;
@@ -264,7 +278,13 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       row0 += rows;
     }
     if (want_wgrad) {
-      L.wg = plan_wgrad(L.g, bf16);
+      if (L.tapgemm) {
+        // dW[t][c] = sum_q dyS[q][t] x[q][c]: a 1x1 weight gradient with G = dyS (16 "channels") and D = x
+        ConvGeomX gw = make_geom(0, 1, 1, 0, L.g.N, L.g.Hin, L.g.Win, 16, 16, L.g.Cin);
+        L.wg = plan_wgrad(gw, bf16);
+      } else {
+        L.wg = plan_wgrad(L.g, bf16);
+      }
       if (L.wg.partial_bytes > *scratch_max) *scratch_max = L.wg.partial_bytes;
     }
   }
@@ -285,6 +305,12 @@ static void carve_net(Net& n, Arena& ar, int es, bool training) {
       t.bn.mu = (float*)ar.alloc(gc); t.bn.rstd = (float*)ar.alloc(gc);
       t.bn.c1 = (float*)ar.alloc(gc); t.bn.c2 = (float*)ar.alloc(gc);
     }
+  }
+  for (Layer& L : n.l) {
+    if (!L.tapgemm) continue;
+    const size_t q = (size_t)L.g.N * L.g.Hin * L.g.Win * 16;
+    L.tap_S = (float*)ar.alloc(q * sizeof(float));
+    L.tap_dyS = ar.alloc(q * es);
   }
   n.packed = (char*)ar.alloc(n.packed_elems * es);
   n.d_descs = (PackDesc*)ar.alloc(n.descs.size() * sizeof(PackDesc));
@@ -412,8 +438,16 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
   a.out_act = L.out_act;
   a.partial = (float*)h->scratch;
   a.zeros = h->zeros;
+  if (L.tapgemm) { a.Y = L.tap_S; a.y_f32 = 1; a.ldY = 16; a.bias = nullptr; }
   profile_tag((L.scope + ":fwd").c_str());
   VP_HIP_CHECK(launch_igemm(a, h->bf16, L.fwd.cfg, st));
+  if (L.tapgemm) {
+    TapArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.S = L.tap_S; ta.bias = n.params + L.b_off; ta.y = (float*)to.y;
+    ta.N = L.g.N; ta.Hin = L.g.Hin; ta.Win = L.g.Win; ta.Hout = L.g.Hout; ta.Wout = L.g.Wout; ta.ks = L.g.ks; ta.pad = L.g.pad;
+    VP_HIP_CHECK(launch_tap_gather(ta, st));
+  }
   if (L.has_bn) { const int rc = run_bn_stats(h, n, L, st); if (rc) return rc; }
   if (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) {
     VP_HIP_CHECK(launch_act_apply(to.y, L.has_bn ? to.bn.a : nullptr, L.has_bn ? to.bn.b : nullptr, to.C,
@@ -437,6 +471,15 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     PixSrc ds;
     set_single_src(ds, dy, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
     if (L.g.kind == 0) { w.g = xs; w.d = ds; } else { w.g = ds; w.d = xs; }
+    if (L.tapgemm) {
+      TapArgs ta;
+      memset(&ta, 0, sizeof(ta));
+      ta.dy = dy; ta.dyS = L.tap_dyS; ta.ld_dy = L.g.CoutT;
+      ta.N = nb; ta.Hin = L.g.Hin; ta.Win = L.g.Win; ta.Hout = L.g.Hout; ta.Wout = L.g.Wout; ta.ks = L.g.ks; ta.pad = L.g.pad;
+      VP_HIP_CHECK(launch_tap_spread(ta, h->bf16, st));
+      set_single_src(w.g, L.tap_dyS, 16, nullptr, nullptr, ACT_NONE, 0);
+      w.d = xs;
+    }
     w.partial = (float*)h->scratch;
     w.dW = n.grads + L.w_off;
     w.accumulate = 0;

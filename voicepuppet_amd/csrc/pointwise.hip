@@ -241,6 +241,52 @@ __global__ __launch_bounds__(256) void act_apply_kernel(const T* __restrict__ y,
 }
 
 // ------------------------------------------------------------------------------------------------
+// "GEMM over taps" helpers for the one-channel stride-1 conv (see TapArgs)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tap_gather_kernel(TapArgs a) {
+  const size_t total = (size_t)a.N * a.Hout * a.Wout;
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= total) return;
+  const int j = (int)(p % a.Wout), i = (int)((p / a.Wout) % a.Hout), n = (int)(p / ((size_t)a.Wout * a.Hout));
+  float acc = 0.f;
+  for (int kh = 0; kh < a.ks; ++kh) {
+    const int qi = i + kh - a.pad;
+    if (qi < 0 || qi >= a.Hin) continue;
+    for (int kw = 0; kw < a.ks; ++kw) {
+      const int qj = j + kw - a.pad;
+      if (qj < 0 || qj >= a.Win) continue;
+      acc += a.S[(((size_t)n * a.Hin + qi) * a.Win + qj) * 16 + kh * a.ks + kw];
+    }
+  }
+  a.y[p] = acc + a.bias[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tap_spread_kernel(TapArgs a) {
+  constexpr int E = Elem<T>::E;
+  const size_t total = (size_t)a.N * a.Hin * a.Win;
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= total) return;
+  const int qj = (int)(q % a.Win), qi = (int)((q / a.Win) % a.Hin), n = (int)(q / ((size_t)a.Win * a.Hin));
+  const T* dy = (const T*)a.dy;
+  float f[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = qi - t / 4 + a.pad, j = qj - t % 4 + a.pad;       // ks == 4
+    const bool ok = i >= 0 && i < a.Hout && j >= 0 && j < a.Wout;
+    f[t] = ok ? Elem<T>::ld(dy + (((size_t)n * a.Hout + i) * a.Wout + j) * a.ld_dy) : 0.f;
+  }
+  T* o = (T*)a.dyS + q * 16;
+#pragma unroll
+  for (int e = 0; e < 16; e += E) {
+    float g[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) g[k] = f[e + k];
+    *reinterpret_cast<uint4*>(o + e) = Elem<T>::pack(g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // input packing: [0,1] -> [-1,1] (pixrefer.py:373-375), channel padding to 8, the real halves of the
 // discriminator and VGG batches (pixrefer.py:295-306, 321)
 // ------------------------------------------------------------------------------------------------
@@ -586,6 +632,16 @@ hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int
   const size_t work = npix * (C / (is_bf16 ? 8 : 4));
   if (is_bf16) hipLaunchKernelGGL((act_apply_kernel<bf16>), dim3(nblocks(work)), dim3(256), 0, st, (const bf16*)y, sc, sh, C, Pg, npix, (bf16*)out_lrelu, (bf16*)out_relu);
   else hipLaunchKernelGGL((act_apply_kernel<float>), dim3(nblocks(work)), dim3(256), 0, st, (const float*)y, sc, sh, C, Pg, npix, (float*)out_lrelu, (float*)out_relu);
+  return hipGetLastError();
+}
+
+hipError_t launch_tap_gather(const TapArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(tap_gather_kernel, dim3((unsigned)(((size_t)a.N * a.Hout * a.Wout + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_tap_spread(const TapArgs& a, int is_bf16, hipStream_t st) {
+  VP_DISPATCH(is_bf16, tap_spread_kernel, dim3((unsigned)(((size_t)a.N * a.Hin * a.Win + 255) / 256)), dim3(256), st, a);
   return hipGetLastError();
 }
 

@@ -95,6 +95,19 @@ struct LossFinalArgs {
   float l1_weight, gan_weight;
 };
 
+// Single-output-channel stride-1 convolution as "GEMM over taps" (discriminator layer_5, pixrefer.py:128-131):
+//   S[q][t] = sum_c x[q][c] * W[t][c]      one 1x1 GEMM over the INPUT pixels q (x is read once instead of once per tap)
+//   y[p]    = bias + sum_t S[p + tap_t][t] gather of ks*ks = 16 partial sums
+// and for the weight gradient  dW[t][c] = sum_q dyS[q][t] * x[q][c]  with  dyS[q][t] = dy[q - tap_t].
+struct TapArgs {
+  const float* S;           // [N,Hin,Win,16] f32 partial sums (fwd)
+  const float* bias;        // [1]
+  float* y;                 // [N,Hout,Wout] (fwd)
+  const void* dy;           // [N,Hout,Wout,ld_dy] channel 0 (bwd)
+  void* dyS;                // [N,Hin,Win,16] (bwd)
+  int N, Hin, Win, Hout, Wout, ks, pad, ld_dy;
+};
+
 struct AdamArgs {
   float* p; const float* g; float* m; float* v;
   size_t n;
