@@ -52,6 +52,7 @@ struct IgemmArgs {
   int splitk;
   float* partial;           // [nclass][splitk][P][CoutPad] when splitk > 1
   int vec_epi;              // staged (LDS) epilogue with 16-byte row stores (set by the launcher)
+  int fastk;                // buffer-descriptor loader with scalar K stepping (set by the launcher)
   const void* zeros;        // >= 16 bytes of zeros (padding source of the LDS-DMA loader); null: register loader
 };
 

@@ -323,6 +323,18 @@ __device__ __forceinline__ void dma16(const void* src, uint4* lds_dst_wave_unifo
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
 }
 
+// Buffer-descriptor form of the same DMA (buffer_load_dwordx4 ... offen lds): address = descriptor base + per-lane
+// 32-bit byte offset + SCALAR offset.  Two things the flat form cannot do: an out-of-range offset returns zeros
+// (padding pixels need no zero page and no per-lane select), and the per-chunk advance along K is a scalar add,
+// so a K chunk costs no vector ALU at all once the per-tap lane offsets exist.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x27000);
+}
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, uint4* lds_dst_wave_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, (int)voff, (int)soff, 0, 0);
+}
+constexpr unsigned DMA_OOB = 0xF0000000u;     // lane offset beyond every descriptor's range -> the DMA writes zeros
+
 // ------------------------------------------------------------------------------------------------
 // Staged epilogue: the accumulators go through LDS as an f32 [pixel][channel] tile, then every thread
 // finishes 8 consecutive channels of one pixel (bias, activation, act'(ref) product, accumulate) and
@@ -524,6 +536,66 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
     }
   };
 
+  // ---- fast loader (a.fastk: every 64-byte K chunk lies inside one tap and one source tensor) -------------------
+  // K is walked as segments (tap, source); per segment each lane computes ONE byte offset per pixel row (or DMA_OOB for
+  // padding), inside a segment a chunk only bumps a scalar offset.  The weight stream is chunk-major: scalar bump too.
+  const unsigned es = sizeof(T);
+  __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
+  __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
+  __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(x1 ? (const void*)x1 : (const void*)x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * es));
+  unsigned wvo[JA];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) wvo[j] = (unsigned)(((c_base + (wave + NW * j) * 16 + r) * KC + g * E) * es);
+  const unsigned wstep = (unsigned)(a.wp_rows * KC * es);
+  unsigned f_wso = (unsigned)kc0 * wstep;          // scalar: weight chunk offset
+  unsigned f_xso = 0;                              // scalar: channel offset inside the segment (bytes)
+  int f_left = 0;                                  // chunks left in the current segment
+  int f_tap = 0, f_src = 0;                        // next segment to open
+  unsigned f_xvo[JB];
+  bool f_use1 = false;
+  if (a.fastk) {
+    const int k0 = kc0 * KC;
+    f_tap = k0 >> a.log2Cin;
+    const int ci = k0 & a.cin_mask;
+    f_src = ci >= C0 ? 1 : 0;
+    // a split that starts inside a segment: open it now and skip the consumed chunks
+    const int cl = f_src ? ci - C0 : ci;
+    f_xso = (unsigned)cl * es;
+    f_left = -(cl / KC);                            // negative: corrected when the segment opens below
+  }
+  auto open_segment = [&]() {
+    const bool tok = f_tap < a.ntaps;
+    const int tv = ltap[tok ? f_tap : 0];
+    const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
+    f_use1 = f_src != 0;
+    const int Cs = f_use1 ? C1 : C0;
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int ih = pbh[j] + dh, iw = pbw[j] + dw;
+      const bool ok = pok[j] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      f_xvo[j] = ok ? (unsigned)((((pn[j] + ih) * a.Win + iw) * Cs + g * E) * es) : DMA_OOB;
+    }
+    f_left += Cs / KC;
+    // next segment: the other source of the same tap, or the next tap
+    if (!f_use1 && C1 > 0) f_src = 1; else { f_src = 0; ++f_tap; }
+  };
+  auto issue_fast = [&](int buf) {
+    uint4* la = lds + buf * BUF;
+    uint4* lb = la + 4 * BC;
+    if (f_left <= 0) { const int skipped = -f_left; f_left = 0; open_segment(); f_left -= skipped; if (skipped == 0) f_xso = 0; }
+#pragma unroll
+    for (int j = 0; j < JA; ++j)
+      if (NBA % NW == 0 || wave + NW * j < NBA) dma16_buf(rsW, wvo[j], f_wso, la + (wave + NW * j) * 64);
+    const __amdgpu_buffer_rsrc_t rx = f_use1 ? rsX1 : rsX0;
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+      if (NBB % NW == 0 || wave + NW * j < NBB) dma16_buf(rx, f_xvo[j], f_xso, lb + (wave + NW * j) * 64);
+    f_wso += wstep;
+    f_xso += KC * es;
+    --f_left;
+  };
+  auto issue_any = [&](int kc, int buf) { if (a.fastk) issue_fast(buf); else issue(kc, buf); };
+
   const int wc = wave / WP, wpi = wave - wc * WP;
   const int blkA0 = wc * TC, blkB0 = wpi * TP;
 
@@ -532,7 +604,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
     if (RING) {
       // NST-deep ring: chunks kc+1 .. kc+NST-2 stay in flight across the barrier while chunk kc is consumed
 #pragma unroll
-      for (int d = 0; d < NST - 1; ++d) if (kc0 + d < kc1) issue(kc0 + d, d);
+      for (int d = 0; d < NST - 1; ++d) if (kc0 + d < kc1) issue_any(kc0 + d, d);
       int st = 0;
       for (int kc = kc0; kc < kc1; ++kc) {
         if (kc + NST - 2 < kc1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (JA + JB)) : "memory");
@@ -541,7 +613,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
         asm volatile("" ::: "memory");
         const int stn = st == 0 ? NST - 1 : st - 1;   // the buffer chunk kc-1 used
 #if !(VP_ABLATE & 2)
-        if (kc + NST - 1 < kc1) issue(kc + NST - 1, stn);
+        if (kc + NST - 1 < kc1) issue_any(kc + NST - 1, stn);
 #endif
         const uint4* la = lds + st * BUF;
 #if !(VP_ABLATE & 1)
@@ -550,11 +622,11 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
         st = st == NST - 1 ? 0 : st + 1;
       }
     } else {
-      issue(kc0, 0);
+      issue_any(kc0, 0);
       for (int kc = kc0; kc < kc1; ++kc) {
         const int buf = (kc - kc0) & 1;
         __syncthreads();   // waits for this wave's DMA (vmcnt) and for every wave's reads of the other buffer
-        if (kc + 1 < kc1) issue(kc + 1, buf ^ 1);
+        if (kc + 1 < kc1) issue_any(kc + 1, buf ^ 1);
         const uint4* la = lds + buf * BUF;
         mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
       }
@@ -1075,6 +1147,12 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   if (plain) {
     IgemmArgs b = a;
     b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
+    // scalar-stepped loader: every 64-byte K chunk inside one tap and one source tensor, sources below the 2 GiB lane-offset range
+    constexpr int KCE = 16 * 4 / (int)sizeof(T);
+    const size_t xb0 = (size_t)a.N * a.Hin * a.Win * a.x.C[0] * sizeof(T), xb1 = (size_t)a.N * a.Hin * a.Win * a.x.C[1] * sizeof(T);
+    static const bool fast_on = !getenv("VP_NO_FASTK");
+    b.fastk = (fast_on && a.Cin % KCE == 0 && a.x.C[0] % KCE == 0 && a.x.C[1] % KCE == 0 && a.x.C[0] + a.x.C[1] == a.Cin &&
+               xb0 < 0x70000000ull && xb1 < 0x70000000ull) ? 1 : 0;
     if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(NW * 64), smem, st, b);
     return hipGetLastError();

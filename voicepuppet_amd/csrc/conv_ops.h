@@ -32,6 +32,12 @@ inline int kc_elems(int is_bf16) { return is_bf16 ? 32 : 16; }
 // tile choice for an igemm producing `rows` channels over P pixels
 inline int pick_igemm_cfg(int rows, int P) {
   static const int big = getenv("VP_BIGTILE") ? atoi(getenv("VP_BIGTILE")) : 1;   // bit 0: 128x256, bit 1: 256x256 (8-wave tiles)
+  static const int force = getenv("VP_FORCE_CFG") ? atoi(getenv("VP_FORCE_CFG")) : -1;   // experiments only
+  if (force >= 0 && P >= 96) {
+    int bc, bp;
+    igemm_tile(force, &bc, &bp);
+    if (rows % bc == 0) return force;
+  }
   if (P >= 96) {
     if ((big & 2) && rows % 256 == 0 && P >= 256 * 512) return 7;
     if ((big & 1) && rows % 128 == 0 && P >= 256 * 512) return 6;
