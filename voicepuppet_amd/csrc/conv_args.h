@@ -74,6 +74,8 @@ struct WgradArgs {
   float* dW;                // [ntaps][Greal][Dreal]
   int Greal, Dreal, accumulate;
   const void* zeros;        // >= 16 zero bytes: enables the branch-free loader for prologue-free operands
+  int lw, lh;               // log2 of Wb, Hb rounded up to powers of two
+  int fastw;                // K walks the padded grid [N][2^lh][2^lw] (division-free loader)
 };
 
 }  // namespace vp

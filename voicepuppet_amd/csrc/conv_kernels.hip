@@ -881,6 +881,52 @@ __device__ __forceinline__ void wg_stage_load(const WgradArgs& a, const WgTask<T
   }
 }
 
+// Padded-grid K walk (a.fastw): K runs over slots of the grid [N][2^lh][2^lw] (Hb, Wb rounded up to powers of two), SL slots per
+// iteration, so a slot's (n, q, r) are bit fields of its index - no divisions - and, because 2^lw divides SL, the column r of each of a
+// thread's E pixels never changes: column validity and the column part of the address are computed ONCE (WgFix); an iteration only
+// adds its row offset.  Slots outside the real grid, and padding taps, load the zero page.
+template <int E> struct WgFix {
+  int coff[E];        // (r*s + dw) * C for the thread's E pixels (element offset inside a row), valid columns only
+  unsigned okmask;    // bit e: column r < Wb and r*s + dw inside [0, Ws)
+  int fq, fn;         // fixed (low) part of the row / image index of the thread's pixel group
+};
+
+template <typename T, int E, int SL>
+__device__ __forceinline__ void wg_fix_init(const WgradArgs& a, const WgTask<T>& t, int kq, WgFix<E>& f) {
+  const int mw = (1 << a.lw) - 1, mh = (1 << a.lh) - 1;
+  const int l0 = kq * E;                         // slot inside the iteration; 2^lw >= E: the E pixels share one row
+  f.fq = (l0 >> a.lw) & mh;
+  f.fn = l0 >> (a.lw + a.lh);
+  f.okmask = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = (l0 + e) & mw;
+    const int iw = r * t.s + t.dw;
+    const bool ok = r < a.Wb && (unsigned)iw < (unsigned)t.Ws;
+    f.coff[e] = ok ? iw * t.C : 0;
+    f.okmask |= ok ? (1u << e) : 0u;
+  }
+}
+
+template <typename T, int E, int SL>
+__device__ __forceinline__ void wg_stage_load_fast(const WgradArgs& a, const WgTask<T>& t, const WgFix<E>& f, int it, uint4 (&rin)[E]) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  // uniform part of the slot index: it * SL supplies the high bits of (q, n); the thread's fixed low bits add without carries
+  const int hi = it * SL;
+  const int q = ((hi >> a.lw) & ((1 << a.lh) - 1)) + f.fq;
+  const int n = (hi >> (a.lw + a.lh)) + f.fn;
+  const int ih = q * t.s + t.dh;
+  const bool rowok = t.ok && n < a.N && q < a.Hb && (unsigned)ih < (unsigned)t.Hs;
+  const int rowoff = (n * t.Hs + ih) * t.Ws * t.C;          // elements; every tensor here is far below 2^31 elements
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const bool ok = rowok && ((f.okmask >> e) & 1u);
+    const T* p = t.base + (rowoff + f.coff[e]);
+    const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(ok ? (const void*)p : a.zeros);
+    rin[e] = make_uint4(v.x, v.y, v.z, v.w);
+  }
+}
+
 template <typename T, int WC, int WP, int TC, int TP, int KCH, bool PLAIN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;           // KC pixels per 64-byte chunk; KCH chunks per iteration
@@ -895,7 +941,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m_base = blockIdx.x * BC, d_base = blockIdx.y * BP, split = blockIdx.z;
   const int P = a.N * a.Hb * a.Wb;
-  const int niter = (P + KC * KCH - 1) / (KC * KCH);
+  const bool fastw = PLAIN && a.fastw;
+  const int Pk = fastw ? (a.N << (a.lw + a.lh)) : P;    // K extent: padded slots or real pixels
+  const int niter = (Pk + KC * KCH - 1) / (KC * KCH);
   const int per = (niter + a.splitk - 1) / a.splitk;
   const int it0 = split * per, it1 = min(niter, it0 + per);
 
@@ -927,6 +975,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     if (!task.ok) { task.base = reinterpret_cast<const T*>(a.zeros); task.C = 0; }
   }
   const PixSrc& psrc = isA ? a.g : a.d;
+  WgFix<E> fix;
+  if (fastw) wg_fix_init<T, E, KC * KCH>(a, task, kq, fix);
+  auto stage_load = [&](int it, uint4 (&rin)[E]) {
+    if (PLAIN && fastw) wg_stage_load_fast<T, E, KC * KCH>(a, task, fix, it, rin);
+    else wg_stage_load<T, E, KCH, PLAIN>(a, task, psrc, it, kq, P, rin);
+  };
 
   f32x4 acc[TC][TP];
 #pragma unroll
@@ -940,7 +994,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int store_off = (kq >> 2) * CH + (isA ? 0 : 4 * BC) + (kq & 3) * (isA ? BC : BP);
 
   if (it0 < it1) {
-    wg_stage_load<T, E, KCH, PLAIN>(a, task, psrc, it0, kq, P, rin);
+    stage_load(it0, rin);
     Transposer<T>::run(rin, rout);
     if (active) {
 #pragma unroll
@@ -950,7 +1004,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     for (int it = it0; it < it1; ++it) {
       const int buf = (it - it0) & 1;
       const bool more = it + 1 < it1;
-      if (more) wg_stage_load<T, E, KCH, PLAIN>(a, task, psrc, it + 1, kq, P, rin);
+      if (more) stage_load(it + 1, rin);
 #pragma unroll
       for (int c = 0; c < KCH; ++c) {
         const uint4* la = lds + buf * BUF + c * CH;

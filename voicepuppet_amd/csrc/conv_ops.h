@@ -215,8 +215,12 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16) {
   wgrad_tile(p.cfg, &bm, &bn);
   a.Mpad = round_up(a.ntaps * a.Gc, bm);
   a.Dpad = round_up(a.Dc, bn);
-  const int P = a.N * a.Hb * a.Wb;
+  a.lw = ilog2(a.Wb); a.lh = ilog2(a.Hb);
   const int kiter = kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of wgrad_kernel
+  // padded-grid K walk: rows of 2^lw slots, at least one 16-byte pixel group and at most one iteration long
+  static const bool fastw_on = !getenv("VP_NO_FASTW");
+  a.fastw = (fastw_on && (1 << a.lw) >= (is_bf16 ? 8 : 4) && (1 << a.lw) <= kiter) ? 1 : 0;
+  const int P = a.fastw ? (a.N << (a.lw + a.lh)) : a.N * a.Hb * a.Wb;
   const int nchunk = (P + kiter - 1) / kiter;
   const int tiles = (a.Mpad / bm) * (a.Dpad / bn);
   // K split: minimise (rounds of the ~512 resident blocks) x (iterations per block + fixed per-block cost),
