@@ -33,6 +33,7 @@ FWD_CASES = [
     (0, 2, 24, 40, 64, 128, 3, 1, 1, 0, 2, False),    # patch kernel: 3x3 s1, ragged 8x16 tiles
     (0, 3, 17, 19, 32, 64, 4, 1, 1, 0, 0, False),     # patch kernel: 4x4 s1 (D layer_4 geometry), odd sizes
     (0, 1, 32, 32, 256, 256, 3, 1, 1, 0, 2, False),   # patch kernel: many channel chunks
+    (0, 1, 256, 256, 32, 256, 3, 1, 1, 0, 2, False),  # 65536 pixels x 256 channels: the 256x256 wave-specialised tile
 ]
 
 

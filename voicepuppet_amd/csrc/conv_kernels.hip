@@ -24,6 +24,9 @@
 #ifndef VP_RING
 #define VP_RING 3      // LDS ring depth of the DMA GEMM loop (stages); 3 = one chunk in flight across the barrier
 #endif
+#ifndef VP_REGB_EPI_BYTES
+#define VP_REGB_EPI_BYTES (36 * 1024)   // LDS budget of igemm_regb_kernel's staged epilogue (its weight ring is far smaller)
+#endif
 #ifndef VP_ABLATE
 #define VP_ABLATE 0   // build-time ablation of the LDS-DMA GEMM loop: 1 = no MFMA, 2 = no DMA in the loop
 #endif
@@ -658,6 +661,327 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// igemm_regb_kernel: the same GEMM with the two operands on two different paths into the CU.  Every tile shape of the
+// LDS-DMA kernel above tops out at the same ~13 TB/s of aggregate LDS fill (whatever the tile, DMA bytes/s are constant),
+// so here only the WEIGHT tile (shared by the block's waves) rides the LDS-DMA ring; each wave fetches the MFMA B fragments
+// of ITS OWN pixels straight into registers with buffer_load_dwordx4 (lane (i, g) needs the 16 bytes k = 8g..8g+7 of pixel
+// row i: exactly one piece, four lanes cover a contiguous 64-byte segment) - no LDS round trip for the pixel operand at all.
+// Out-of-range offsets return zeros (padding), K steps by scalar offsets (the fastk scheme).  Order per K chunk:
+//   wait(vmcnt: this chunk's fragments + weight stage) -> barrier -> load fragments kc+1 -> DMA weights kc+2 -> MFMA kc.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WC, int WP, int TC, int TP>
+__global__ __launch_bounds__(WC * WP * 64) void igemm_regb_kernel(const IgemmArgs a) {
+  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int NW = WC * WP, NT = NW * 64;
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  constexpr int NBA = BC / 16;
+  static_assert(NBA % NW == 0, "every wave issues the same number of weight DMAs");
+  constexpr int JA = NBA / NW;
+  constexpr int BUF = 4 * BC;                          // 16-byte slots of one weight stage
+  constexpr int NST = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  int* ltap = reinterpret_cast<int*>(lds + NST * BUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cls = blockIdx.z;
+  const int P = a.N * a.Hg * a.Wg;
+  int pt, ct;
+  {
+    const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7, slot = id >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    ct = logical % (int)gridDim.y; pt = logical / (int)gridDim.y;
+  }
+  const int p_base = pt * BP, c_base = ct * BC;
+  const int wc = wave / WP, wpi = wave - wc * WP;
+  const int blkA0 = wc * TC, blkB0 = wpi * TP;
+  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
+
+  const unsigned es = sizeof(T);
+  const T* x0 = reinterpret_cast<const T*>(a.x.ptr[0]);
+  const T* x1 = reinterpret_cast<const T*>(a.x.ptr[1]);
+  const int C0 = a.x.C[0], C1 = a.x.C[1];
+  __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
+  __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
+  __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(x1 ? (const void*)x1 : (const void*)x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * es));
+
+  // weight DMA lanes: 16-row block (wave + NW*j), row r, piece g (rb_swz image, as in igemm_dma_kernel)
+  unsigned wvo[JA];
+  {
+    const int r = lane >> 2, g = (lane & 3) ^ rb_swz(lane >> 2);
+#pragma unroll
+    for (int j = 0; j < JA; ++j) wvo[j] = (unsigned)(((c_base + (wave + NW * j) * 16 + r) * KC + g * E) * es);
+  }
+  const unsigned wstep = (unsigned)(a.wp_rows * KC * es);
+  unsigned wso = 0;
+  // this lane's pixel rows: tile t -> row (blkB0 + t)*16 + (lane & 15), piece lane >> 4
+  const int fi = lane & 15, fg = lane >> 4;
+  int pn[TP], pbh[TP], pbw[TP];
+  bool pok[TP];
+#pragma unroll
+  for (int t = 0; t < TP; ++t) {
+    const int pidx = p_base + (blkB0 + t) * 16 + fi;
+    pok[t] = pidx < P;
+    const int hw = a.Hg * a.Wg;
+    const int pc = pok[t] ? pidx : 0;
+    const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
+    pn[t] = n * a.Hin; pbh[t] = q * a.sh; pbw[t] = (rem - q * a.Wg) * a.sw;
+  }
+  const int nchunk = a.Kpad / KC;
+
+  // segment walker of the pixel operand (tap, source), see igemm_dma_kernel
+  unsigned xso = 0;
+  int left = 0, tap = 0, src = 0;
+  bool use1 = false;
+  unsigned xvo[TP];
+  auto open_segment = [&]() {
+    const bool tok = tap < a.ntaps;
+    const int tv = ltap[tok ? tap : 0];
+    const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
+    use1 = src != 0;
+    const int Cs = use1 ? C1 : C0;
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      const int ih = pbh[t] + dh, iw = pbw[t] + dw;
+      const bool ok = pok[t] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      xvo[t] = ok ? (unsigned)((((pn[t] + ih) * a.Win + iw) * Cs + fg * E) * es) : DMA_OOB;
+    }
+    left = Cs / KC;
+    xso = 0;
+    if (!use1 && C1 > 0) src = 1; else { src = 0; ++tap; }
+  };
+  auto load_x = [&](uint4 (&f)[TP]) {
+    if (left == 0) open_segment();
+    const __amdgpu_buffer_rsrc_t rx = use1 ? rsX1 : rsX0;
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xvo[t], (int)xso, 0);
+      f[t] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    xso += KC * es;
+    --left;
+  };
+  auto issue_w = [&](int buf) {
+    uint4* la = lds + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) dma16_buf(rsW, wvo[j], wso, la + (wave + NW * j) * 64);
+    wso += wstep;
+  };
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int so = fi * 4 + (fg ^ rb_swz(fi));            // LDS slot of this lane's A fragment inside a 16-row block
+  uint4 fb0[TP], fb1[TP];
+  __syncthreads();   // tap table visible
+
+  // one K chunk: kc is consumed from ring stage st with fragments `cur`; fragments of kc+1 go to `nxt`.
+  // hipcc puts a full vmcnt(0) in front of the first MFMA that reads `cur` (its scoreboard does not count through the
+  // LDS-DMAs of the loop), so the next loads are issued AFTER the first row of MFMAs: the wait then finds nothing new
+  // in flight and the loads overlap the remaining MFMAs, the barrier and the other resident blocks.
+  auto step = [&](int kc, int st, uint4 (&cur)[TP], uint4 (&nxt)[TP]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const uint4* la = lds + st * BUF;
+    uint4 fa[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) fa[t] = la[(blkA0 + t) * 64 + so];
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) acc[0][tp] = mma16<T>(fa[0], cur[tp], acc[0][tp]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kc + 1 < nchunk) load_x(nxt);
+    if (kc + 2 < nchunk) issue_w(st == 0 ? 2 : st - 1);                                // the stage chunk kc-1 used
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tc = 1; tc < TC; ++tc)
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], cur[tp], acc[tc][tp]);
+  };
+
+  issue_w(0);
+  load_x(fb0);
+  if (nchunk > 1) issue_w(1);
+  int st = 0;
+  for (int kc = 0; kc < nchunk; kc += 2) {
+    step(kc, st, fb0, fb1);
+    st = st == 2 ? 0 : st + 1;
+    if (kc + 1 < nchunk) {
+      step(kc + 1, st, fb1, fb0);
+      st = st == 2 ? 0 : st + 1;
+    }
+  }
+
+  constexpr int NPASS = epi_passes(BC, BP, WP, VP_REGB_EPI_BYTES);
+  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// igemm_ws_kernel: wave-specialised form of igemm_dma_kernel.  An LDS-DMA costs its issuing wave 60-185 cycles of issue
+// time (MI355X_MICROARCH.md), comparable to the 16 MFMAs of a K chunk, so in the kernels above the DMA issue and the
+// matrix pipe take turns inside every wave.  Here NPW = 4 producer waves (one per SIMD) issue ALL the DMAs of a stage and
+// the WC x WP consumer waves only do barrier -> ds_read -> MFMA; the producers' issue stalls overlap the consumers' MFMAs
+// on the same SIMD.  One barrier per K chunk, NST-deep ring:
+//   producer kc: wait vmcnt (its share of chunk kc landed) -> barrier kc -> issue chunk kc+NST-1 into the stage chunk kc-1 used
+//   consumer kc: barrier kc -> fragments + MFMAs of chunk kc
+// fastk operands only (scalar K stepping, hardware zero fill); epilogue = the staged 16-byte row stores, all waves storing.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WC, int WP, int TC, int TP, int NST>
+__global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const IgemmArgs a) {
+  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int NPW = 4;
+  constexpr int NW = WC * WP, NT = (NW + NPW) * 64;
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  constexpr int NBA = BC / 16, NBB = BP / 16, NB = NBA + NBB;
+  static_assert(NB % NPW == 0, "every producer issues the same number of DMAs per chunk");
+  constexpr int J = NB / NPW;
+  constexpr int BUF = 4 * (BC + BP);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  int* ltap = reinterpret_cast<int*>(lds + NST * BUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= NW;
+  const int cls = blockIdx.z;
+  const int P = a.N * a.Hg * a.Wg;
+  int pt, ct;
+  {
+    const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7, slot = id >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    ct = logical % (int)gridDim.y; pt = logical / (int)gridDim.y;
+  }
+  const int p_base = pt * BP, c_base = ct * BC;
+  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
+  const int nchunk = a.Kpad / KC;
+  const int wc = producer ? 0 : wave / WP, wpi = producer ? 0 : wave - wc * WP;
+  const int blkA0 = wc * TC, blkB0 = producer ? (1 << 20) : wpi * TP;     // producers stage nothing in the epilogue
+
+  f32x4 acc[TC][TP];   // consumers only: left undefined on the producer path so it holds no registers there
+
+  __syncthreads();   // tap table visible
+
+  if (producer) {
+    const int pw = wave - NW;
+    const unsigned es = sizeof(T);
+    const T* x0 = reinterpret_cast<const T*>(a.x.ptr[0]);
+    const T* x1 = reinterpret_cast<const T*>(a.x.ptr[1]);
+    const int C0 = a.x.C[0], C1 = a.x.C[1];
+    __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
+    __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
+    __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(x1 ? (const void*)x1 : (const void*)x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * es));
+    const int r = lane >> 2, g = (lane & 3) ^ rb_swz(lane >> 2);
+    // row block b = pw + NPW*j: weight block b (b < NBA) or pixel block b - NBA
+    unsigned wvo[J];
+    int pn[J], pbh[J], pbw[J];
+    bool pok[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int b = pw + NPW * j;
+      wvo[j] = (unsigned)(((c_base + b * 16 + r) * KC + g * E) * es);
+      const int pidx = p_base + (b - NBA) * 16 + r;
+      pok[j] = b >= NBA && pidx < P;
+      const int hw = a.Hg * a.Wg;
+      const int pc = pok[j] ? pidx : 0;
+      const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
+      pn[j] = n * a.Hin; pbh[j] = q * a.sh; pbw[j] = (rem - q * a.Wg) * a.sw;
+    }
+    const unsigned wstep = (unsigned)(a.wp_rows * KC * es);
+    unsigned wso = 0, xso = 0;
+    int left = 0, tap = 0, src = 0;
+    bool use1 = false;
+    unsigned xvo[J];
+    auto open_segment = [&]() {
+      const bool tok = tap < a.ntaps;
+      const int tv = ltap[tok ? tap : 0];
+      const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
+      use1 = src != 0;
+      const int Cs = use1 ? C1 : C0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int ih = pbh[j] + dh, iw = pbw[j] + dw;
+        const bool ok = pok[j] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+        xvo[j] = ok ? (unsigned)((((pn[j] + ih) * a.Win + iw) * Cs + g * E) * es) : DMA_OOB;
+      }
+      left = Cs / KC;
+      xso = 0;
+      if (!use1 && C1 > 0) src = 1; else { src = 0; ++tap; }
+    };
+    auto issue = [&](int buf) {
+      uint4* la = lds + buf * BUF;
+      uint4* lb = la + 4 * BC;
+      if (left == 0) open_segment();
+      const __amdgpu_buffer_rsrc_t rx = use1 ? rsX1 : rsX0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int b = pw + NPW * j;
+        if (b < NBA) dma16_buf(rsW, wvo[j], wso, la + b * 64);
+        else dma16_buf(rx, xvo[j], xso, lb + (b - NBA) * 64);
+      }
+      wso += wstep;
+      xso += KC * es;
+      --left;
+    };
+#pragma unroll
+    for (int d = 0; d < NST - 1; ++d) if (d < nchunk) issue(d);
+    int st = 0;
+    for (int kc = 0; kc < nchunk; ++kc) {
+      if (kc + NST - 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * J) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int stn = st == 0 ? NST - 1 : st - 1;
+      if (kc + NST - 1 < nchunk) issue(stn);
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+      for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int st = 0;
+    for (int kc = 0; kc < nchunk; ++kc) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const uint4* la = lds + st * BUF;
+      if constexpr (TC <= 4) {
+        mma_chunk_rb<T, TC, TP, BC, BP>(la, la + 4 * BC, blkA0, blkB0, lane, acc);
+      } else {
+        // 128-row wave tiles: channel fragments in groups of four (the 128 accumulator registers leave room for no more)
+        const uint4* lb = la + 4 * BC;
+        const int i = lane & 15, g = lane >> 4;
+        const int so = i * 4 + (g ^ rb_swz(i));
+        uint4 fb[TP];
+#pragma unroll
+        for (int t = 0; t < TP; ++t) fb[t] = lb[(blkB0 + t) * 64 + so];
+#pragma unroll
+        for (int h = 0; h < TC; h += 4) {
+          uint4 fa[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fa[t] = la[(blkA0 + h + t) * 64 + so];
+#pragma unroll
+          for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) acc[h + tc][tp] = mma16<T>(fa[tc], fb[tp], acc[h + tc][tp]);
+        }
+      }
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+  }
+
+  constexpr int RINGB = NST * BUF * 16;
+  constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
+  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
 // igemm_patch_kernel: stride-1 convolutions (VGG 3x3, discriminator 4x4 s1, their backward-data) with the
 // input tile staged ONCE per channel chunk.  The 128 output pixels of a block are an 8 x 16 patch of one
 // image; the (8+k-1) x (16+k-1) input patch of a 64-byte channel chunk is DMA'd into LDS once and every tap
@@ -1207,6 +1531,33 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
     static const bool fast_on = !getenv("VP_NO_FASTK");
     b.fastk = (fast_on && a.Cin % KCE == 0 && a.x.C[0] % KCE == 0 && a.x.C[1] % KCE == 0 && a.x.C[0] + a.x.C[1] == a.Cin &&
                xb0 < 0x70000000ull && xb1 < 0x70000000ull) ? 1 : 0;
+    // wave-specialised kernel, per tile shape (bit = launch_igemm cfg index): measured gains for 128x128 (cfg 0), 64x128 (cfg 1), 256x256 (cfg 7); 128x256 is faster without
+    static const int ws_cfgs = getenv("VP_WS_CFG") ? atoi(getenv("VP_WS_CFG")) : ((1 << 0) | (1 << 1) | (1 << 7));
+    constexpr int my_cfg = (BC == 128 && BP == 128) ? 0 : (BC == 64 && BP == 128) ? 1 : (BC == 128 && BP == 256) ? 6 : (BC == 256 && BP == 256) ? 7 :
+                           (BC == 64 && BP == 256) ? 8 : 31;
+    if constexpr (((BC + BP) / 16) % 4 == 0 && NW <= 8) {
+      if (((ws_cfgs >> my_cfg) & 1) && b.vec_epi && b.fastk && a.splitk == 1) {
+        constexpr int NSTW = (NW == 8) ? 4 : 4;
+        constexpr int RB = NSTW * 4 * (BC + BP) * 16;
+        constexpr int NPE = epi_passes(BC, BP, WP, RB);
+        size_t sm = RB + 64;
+        const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
+        if (se > sm) sm = se;
+        hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW>), grid, dim3((NW + 4) * 64), sm, st, b);
+        return hipGetLastError();
+      }
+    }
+    static const int regb_on = getenv("VP_REGB") ? atoi(getenv("VP_REGB")) : 0;   // measured slower (round 1): opt-in experiment
+    if constexpr ((BC / 16) % NW == 0) {
+      if (regb_on && b.vec_epi && b.fastk && a.splitk == 1) {
+        constexpr int NPE = epi_passes(BC, BP, WP, VP_REGB_EPI_BYTES);
+        size_t sm = 3 * 4 * BC * 16 + 64;
+        const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
+        if (se > sm) sm = se;
+        hipLaunchKernelGGL((igemm_regb_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), sm, st, b);
+        return hipGetLastError();
+      }
+    }
     if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(NW * 64), smem, st, b);
     return hipGetLastError();

@@ -30,8 +30,8 @@ inline ConvGeomX make_geom(int kind, int ks, int stride, int pad, int N, int Hin
 inline int kc_elems(int is_bf16) { return is_bf16 ? 32 : 16; }
 
 // tile choice for an igemm producing `rows` channels over P pixels
-inline int pick_igemm_cfg(int rows, int P) {
-  static const int big = getenv("VP_BIGTILE") ? atoi(getenv("VP_BIGTILE")) : 1;   // bit 0: 128x256, bit 1: 256x256 (8-wave tiles)
+inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
+  static const int big = getenv("VP_BIGTILE") ? atoi(getenv("VP_BIGTILE")) : 3;   // bit 0: 128x256, bit 1: 256x256 (8-wave tiles)
   static const int force = getenv("VP_FORCE_CFG") ? atoi(getenv("VP_FORCE_CFG")) : -1;   // experiments only
   if (force >= 0 && P >= 96) {
     int bc, bp;
@@ -39,7 +39,8 @@ inline int pick_igemm_cfg(int rows, int P) {
     if (rows % bc == 0) return force;
   }
   if (P >= 96) {
-    if ((big & 2) && rows % 256 == 0 && P >= 256 * 512) return 7;
+    // 256x256 runs one block per CU: its prologue / epilogue are exposed, only long K loops amortise them
+    if ((big & 2) && rows % 256 == 0 && P >= 256 * 256 && Kpad >= 4096) return 7;
     if ((big & 1) && rows % 128 == 0 && P >= 256 * 512) return 6;
     if (rows % 128 == 0) return 0;
     if ((big & 4) && rows % 64 == 0 && P >= 256 * 512) return 8;
@@ -79,11 +80,11 @@ struct IgemmPlan {
 inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   IgemmArgs& a = p.a;
   const int P = a.N * a.Hg * a.Wg;
-  p.cfg = pick_igemm_cfg(rows, P);
+  a.Kpad = round_up(a.ntaps * a.Cin, kc_elems(is_bf16));
+  p.cfg = pick_igemm_cfg(rows, P, a.Kpad);
   int bc, bp;
   igemm_tile(p.cfg, &bc, &bp);
   a.CoutPad = round_up(rows, bc);
-  a.Kpad = round_up(a.ntaps * a.Cin, kc_elems(is_bf16));
   if (a.ntaps == 1) { a.log2Cin = 30; a.cin_mask = 0x3fffffff; }   // 1x1: any channel count
   else { a.log2Cin = ilog2(a.Cin); a.cin_mask = a.Cin - 1; }
   const int blocks = ((P + bp - 1) / bp) * (a.CoutPad / bc) * a.nclass;
