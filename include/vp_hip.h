@@ -86,6 +86,12 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream);
  * discriminator gradients while the generator backward runs. */
 int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream);
 int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream);
+/* The same pass in vp_pixrefer_backward_g_stages() = 3 consecutive stages (stage < 0: all).  After stage s a contiguous
+ * range of the generator gradient arena is final (0: from generator/merged_decoder_5 to the end; 1: from
+ * generator/merged_encoder_2 up to merged_decoder_5; 2: the rest), so a data-parallel host can start that bucket's
+ * all-reduce while the next stage computes. */
+int vp_pixrefer_backward_g_stages(void);
+int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream);
 
 /* Named device buffers ("nodes" of pixrefer.py:356-438 and every intermediate):
  *   "Outputs_raw" [N,H,H,3] f32 in [-1,1], "Outputs_FG" [N,H,H,3] f32, "gen_out4" [N,H,H,4] f32,

@@ -36,8 +36,11 @@ def _worker(rank, world, port, n, out):
   gd = fake_grads(global_batch[lo:hi], n)
   gg = fake_grads(global_batch[lo:hi] * 2, 3 * n)
   wd = allreduce_mean(gd, dist.group.WORLD, async_op=True)      # started before the "generator backward" ...
-  wg = allreduce_mean(gg, dist.group.WORLD, async_op=True)
-  wd.wait(); wg.wait()                                           # ... both complete before Adam
+  # ... whose gradient arena travels as three contiguous buckets, last range first (engine.grad_buckets_g / train_step)
+  a, b = 2 * n, n // 2
+  works = [wd] + [allreduce_mean(gg[lo_:hi_], dist.group.WORLD, async_op=True) for lo_, hi_ in ((a, 3 * n), (b, a), (0, b))]
+  for w in works:
+    w.wait()                                                     # all complete before Adam
   if rank == 0:
     torch.save({"gd": gd, "gg": gg, "batch": torch.from_numpy(global_batch)}, out)
   dist.barrier()

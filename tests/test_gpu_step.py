@@ -214,3 +214,29 @@ def test_step_parity_bf16_against_rounding_aware_oracle(oracle_step):
   assert max(mid.values()) < 2e-2, mid
   bad = {k: v for k, v in worst.items() if v > 5e-2}   # measured worst: 3.0e-2 (a bias gradient), typical 1e-2
   assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_staged_generator_backward_equals_monolithic():
+  """backward_g in its three all-reduce stages == the single call, bit for bit; the buckets tile the gradient arena."""
+  import torch
+  from voicepuppet_amd.engine import PixReferEngine
+  ngf = ndf = 8
+  p = ref.init_params(ngf, ndf, seed=3, dtype=np.float32)
+  rng = np.random.default_rng(5)
+  batch = [torch.tensor(rng.uniform(size=(2, 256, 256, c)).astype(np.float32), device="cuda") for c in (6, 6, 3, 3)]
+  eng = PixReferEngine(2, 256, ngf, ndf, dtype="bf16", training=True)
+  eng.load_params(p)
+  eng.forward(*batch); eng.backward_d(); eng.backward_g()
+  torch.cuda.synchronize()
+  want = eng.grads_g.clone()
+  eng.grads_g.fill_(float("nan"))
+  eng.forward(*batch); eng.backward_d()
+  buckets = eng.grad_buckets_g()
+  assert buckets[0][1] == eng.grads_g.numel() and buckets[2][0] == 0
+  assert buckets[0][0] == buckets[1][1] and buckets[1][0] == buckets[2][1] and buckets[2][1] > 0
+  for stage, (lo, hi) in enumerate(buckets):
+    eng.backward_g_stage(stage)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grads_g[lo:hi], want[lo:hi]), stage        # this bucket is final after its stage
+  assert torch.equal(eng.grads_g, want)

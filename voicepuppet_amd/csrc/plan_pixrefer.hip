@@ -721,13 +721,33 @@ int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream) {
   return VP_OK;
 }
 
-int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream) {
+int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream) { return vp_pixrefer_backward_g_stage(h, -1, stream); }
+
+int vp_pixrefer_backward_g_stages(void) { return 3; }
+
+// Stage s of the generator-loss backward pass; stage boundaries are where a contiguous range of the generator's flat
+// gradient arena becomes final, so a data-parallel host can start that bucket's all-reduce while the next stage computes:
+//   0: D(fake) + VGG + composite, then decoder_1 .. merged_decoder_5   -> arena [merged_decoder_5 .. end) final
+//   1: merged_encoder_5 .. merged_encoder_2                              -> arena [merged_encoder_2 .. merged_decoder_5) final
+//   2: encoder_fg_4 .. encoder_1                                         -> arena [0 .. merged_encoder_2) final
+// stage < 0 runs all three.
+int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_g: needs a training plan"); return VP_ERR_STATE; }
+  if (stage > 2) { set_err("vp_pixrefer_backward_g_stage: stage must be < 3"); return VP_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const vp_pixrefer_desc& d = h->d;
   const int N = d.batch, H = d.height, bf = h->bf16, es = h->es;
   int rc;
   Net &G = h->G, &D = h->D, &V = h->V;
+  // generator layers are walked last to first; l_hi / l_lo = the layer range of this stage
+  int i_md5 = -1, i_me2 = -1;
+  for (int i = 0; i < (int)G.l.size(); ++i) {
+    if (G.l[i].scope == "merged_decoder_5") i_md5 = i;
+    if (G.l[i].scope == "merged_encoder_2") i_me2 = i;
+  }
+  const int l_hi = stage <= 0 ? (int)G.l.size() - 1 : (stage == 1 ? i_md5 - 1 : i_me2 - 1);
+  const int l_lo = stage < 0 ? 0 : (stage == 0 ? i_md5 : (stage == 1 ? i_me2 : 0));
+  if (stage <= 0) {
   // ---- Gen_loss -> generator* (pixrefer.py:402-407) ----
   // (a) GAN term through the fake application of the discriminator (dX only, pre-update weights)
   for (Tens& t : D.t) t.dz_written = false;
@@ -776,9 +796,10 @@ int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream) {
   ca.targets = h->in_targets; ca.masks = h->in_masks; ca.o4 = h->o4; ca.outputs = h->outputs;
   ca.d_din = h->d_din; ca.d_vin = h->d_vin; ca.dy4 = h->dy4; ca.N = N; ca.HW = H * H; ca.l1_weight = d.l1_weight;
   VP_HIP_CHECK(launch_composite_bwd(ca, bf, st));
-  // (d) generator, last layer first
   for (Tens& t : G.t) t.dz_written = false;
-  for (int i = (int)G.l.size() - 1; i >= 0; --i) {
+  }
+  // (d) generator, last layer first
+  for (int i = l_hi; i >= l_lo; --i) {
     Layer& L = G.l[i];
     Tens& to = G.t[L.out];
     if (L.has_bn) if ((rc = run_bn_bwd(h, G, L, true, 0, N, 0, 1, st))) return rc;

@@ -129,6 +129,19 @@ class PixReferEngine:
   def backward_g(self):
     _lib.check(self.L.vp_pixrefer_backward_g(self.h, _stream()), "vp_pixrefer_backward_g")
 
+  def backward_g_stage(self, stage):
+    """Stage `stage` of backward_g (0 .. backward_g_stages()-1); see grad_buckets_g."""
+    _lib.check(self.L.vp_pixrefer_backward_g_stage(self.h, int(stage), _stream()), "vp_pixrefer_backward_g_stage")
+
+  def grad_buckets_g(self):
+    """[(lo, hi)] float ranges of the generator gradient arena that are final after stage 0, 1, 2 of backward_g:
+    the arena is in TF variable order (encoders, merged encoders, merged decoders, decoders) and the backward pass
+    walks it from the end, so each stage completes a contiguous suffix."""
+    off = {name: o for name, o, _ in self.manifests[0]}
+    a = off["generator/merged_decoder_5/conv2d_transpose/kernel"]
+    b = off["generator/merged_encoder_2/conv2d/kernel"]
+    return [(a, self.grads_g.numel()), (b, a), (0, b)]
+
   def train_step(self, inputs, fg_inputs, targets, masks, lr, beta1=0.5, group=None):
     """One iteration of train_pixrefer.py:136-143 on this replica: forward, both backward passes,
     (data parallel: RCCL all-reduce-mean of the two gradient arenas, the discriminator's overlapped
@@ -136,12 +149,16 @@ class PixReferEngine:
     from .parallel import allreduce_mean
     self.forward(inputs, fg_inputs, targets, masks)
     self.backward_d()
-    wd = allreduce_mean(self.grads_d, group, async_op=True) if group is not None else None
-    self.backward_g()
-    if wd is not None:
-      wg = allreduce_mean(self.grads_g, group, async_op=True)
-      wd.wait()
-      wg.wait()
+    if group is None:
+      self.backward_g()
+    else:
+      # the discriminator bucket and the first two generator buckets travel while later stages still compute
+      works = [allreduce_mean(self.grads_d, group, async_op=True)]
+      for stage, (lo, hi) in enumerate(self.grad_buckets_g()):
+        self.backward_g_stage(stage)
+        works.append(allreduce_mean(self.grads_g[lo:hi], group, async_op=True))
+      for w in works:
+        w.wait()
     self.adam_step(lr, beta1)
 
   def adam_step(self, lr, beta1=0.5, beta2=0.999, eps=1e-8):
