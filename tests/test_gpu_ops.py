@@ -23,6 +23,7 @@ FWD_CASES = [
     (0, 3, 9, 9, 32, 64, 4, 1, 1, 1, 0, True),        # D layer_4-like: stride 1, odd size
     (0, 3, 9, 9, 64, 1, 4, 1, 1, 1, 0, True),         # D layer_5-like: one output channel
     (0, 2, 12, 12, 8, 64, 3, 1, 1, 0, 2, False),      # VGG conv1_1-like (K = 72 is padded)
+    (0, 3, 16, 32, 8, 64, 3, 1, 1, 0, 2, False),      # same with power-of-two sides: the direct 8-channel kernel (3 MFMA steps)
     (0, 2, 12, 12, 64, 64, 3, 1, 1, 0, 2, False),     # VGG conv + relu
     (0, 2, 2, 2, 512, 256, 4, 2, 1, 1, 0, True),      # bottleneck: 2 pixels, split-K
     (0, 5, 4, 4, 256, 128, 4, 2, 1, 1, 0, True),      # 20 pixels: 32-pixel tile

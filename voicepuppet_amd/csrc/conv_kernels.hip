@@ -982,6 +982,116 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_cin8_kernel: the first layers of the three nets (3- and 6-channel images padded to 8: VGG conv1_1, discriminator layer_1,
+// encoder_1, encoder_fg_1; all 64 output channels, bf16).  K = taps x 8 is only 3-4 MFMA steps, so a tiled GEMM is all
+// prologue and epilogue; these layers are bound by writing the output (8 channels in, 64 out).  Direct form, no LDS:
+//   * a tap of a padded pixel is exactly one 16-byte piece = the 8 k values one lane feeds to mfma 16x16x32; lane (pixel i,
+//     k group g) loads tap 4s+g of its pixel for MFMA step s straight from global memory (buffer load: padding reads zeros);
+//   * the whole weight matrix (64 x K) sits in registers as A fragments for the life of the wave (S x 4 x 4 VGPRs);
+//   * MFMA row (tile t, 4q+e) is channel 32*(t>>1) + 8q + 4*(t&1) + e, so after the 4 tiles a lane holds channels 8q..8q+7 and
+//     32+8q..32+8q+7 of its pixel: two 16-byte stores per lane, and the four lanes of a pixel write 64 contiguous bytes per store;
+//   * each wave walks 16-pixel tiles with the next tile's pieces in flight (double-buffered fragments).
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int lgW, int lgH) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, g = lane >> 4;
+  const int P = a.N << (lgW + lgH);
+  const int ntile = (P + 15) >> 4;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+
+  // A fragments: packed weights are [K chunk s][row][32 k]; this lane's row of tile t is channel 32*(t>>1) + 8*(i>>2) + 4*(t&1) + (i&3).
+  // They live in LDS in fragment order [s][t][lane] (each lane re-reads its own 16 bytes: conflict-free, 12-16 KB per block),
+  // which leaves the registers to occupancy and to the pixel pieces in flight.
+  __shared__ uint4 wfrag[S * 4 * 64];
+  {
+    const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
+    for (int idx = threadIdx.x; idx < S * 4 * 64; idx += 256) {
+      const int l = idx & 63, t = (idx >> 6) & 3, s = idx >> 8;
+      const int row = (t >> 1) * 32 + 8 * ((l & 15) >> 2) + (t & 1) * 4 + (l & 3);
+      wfrag[idx] = *reinterpret_cast<const uint4*>(wp + ((size_t)s * a.wp_rows + row) * 32 + (l >> 4) * 8);
+    }
+    __syncthreads();
+  }
+  float bias[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bias[e] = a.bias ? a.bias[(e >> 3) * 32 + 8 * g + (e & 7)] : 0.f;
+  // this lane's tap of step s
+  int tdh[S], tdw[S];
+  bool tok[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int tap = 4 * s + g;
+    tok[s] = tap < a.ntaps;
+    int dh = 0, dw = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) if (t == tap) { dh = a.taps[0].dh[t]; dw = a.taps[0].dw[t]; }
+    tdh[s] = dh; tdw[s] = dw;
+  }
+  __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * 16));
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+  auto load_tile = [&](int tile, uint4 (&fb)[S]) {
+    const int p = tile * 16 + i;
+    const int ow = p & ((1 << lgW) - 1), oh = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
+    const int bh = oh * a.sh, bw = ow * a.sw;
+    const bool pok = p < P;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int ih = bh + tdh[s], iw = bw + tdw[s];
+      const bool ok = pok && tok[s] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const unsigned off = ok ? (unsigned)(((n * a.Hin + ih) * a.Win + iw) * 16) : DMA_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
+      fb[s] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  auto finish_tile = [&](int tile, const uint4 (&fb)[S]) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int wl = lane;
+    asm volatile("" : "+v"(wl));      // opaque: keeps the weight fragments in LDS (hoisted into registers they cost 48-64 VGPRs)
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mma16<bf16>(wfrag[(s * 4 + t) * 64 + wl], fb[s], acc[t]);
+    const int p = tile * 16 + i;
+    if (p >= P) return;
+    float v[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * t + e] = act_apply(a.out_act, acc[t][e] + bias[4 * t + e]);
+    const int ow = p & ((1 << lgW) - 1), oh = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
+    bf16* yp = reinterpret_cast<bf16*>(a.Y) + ((size_t)(n * a.Hof + oh) * a.Wof + ow) * a.ldY + 8 * g;
+    float lo[8], hi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[8 + e]; }
+    reinterpret_cast<uint4*>(yp)[0] = Elem<bf16>::pack(lo);
+    reinterpret_cast<uint4*>(yp + 32)[0] = Elem<bf16>::pack(hi);
+  };
+
+  // three fragment sets: two tiles of loads stay in flight behind the tile being finished
+  uint4 fb0[S], fb1[S], fb2[S];
+  int tile = wave_global;
+  if (tile < ntile) load_tile(tile, fb0);
+  if (tile + nwave < ntile) load_tile(tile + nwave, fb1);
+  while (tile < ntile) {
+    if (tile + 2 * nwave < ntile) load_tile(tile + 2 * nwave, fb2);
+    finish_tile(tile, fb0);
+    tile += nwave;
+    if (tile >= ntile) break;
+    if (tile + 2 * nwave < ntile) load_tile(tile + 2 * nwave, fb0);
+    finish_tile(tile, fb1);
+    tile += nwave;
+    if (tile >= ntile) break;
+    if (tile + 2 * nwave < ntile) load_tile(tile + 2 * nwave, fb1);
+    finish_tile(tile, fb2);
+    tile += nwave;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // igemm_patch_kernel: stride-1 convolutions (VGG 3x3, discriminator 4x4 s1, their backward-data) with the
 // input tile staged ONCE per channel chunk.  The 128 output pixels of a block are an 8 x 16 patch of one
 // image; the (8+k-1) x (16+k-1) input patch of a 64-byte channel chunk is DMA'd into LDS once and every tap
@@ -1599,6 +1709,26 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   const double Pn = (double)a.N * a.Hg * a.Wg * a.nclass;
   const double kreal = (double)a.ntaps * a.cin_real;
   const double es = sizeof(T);
+  if constexpr (sizeof(T) == 2) {
+    // 8-channel (padded image) inputs, 64 outputs: the direct register-resident form (conv_cin8_kernel)
+    static const bool cin8_on = !getenv("VP_NO_CIN8");
+    const bool pow2 = (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0;
+    if (cin8_on && a.zeros && a.Cin == 8 && a.x.C[0] == 8 && a.x.C[1] == 0 && a.Cout == 64 && a.ldY == 64 && a.nclass == 1 && a.splitk == 1 &&
+        a.os == 1 && a.Hof == a.Hg && a.Wof == a.Wg && pow2 && !a.ref && !a.accumulate && !a.y_f32 && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
+        a.ntaps <= 16 && (a.Kpad == 96 || a.Kpad == 128) && (size_t)a.N * a.Hin * a.Win * 16 < 0x70000000ull) {
+      ProfScope prof("cin8", true, 64, 16, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.Cout + Pn * a.Cout), st);
+      const int ntile = (int)((Pn + 15) / 16);
+      int blocks = (ntile + 3) / 4;
+      if (blocks > 2048) blocks = 2048;
+      int lgW = 0, lgH = 0;
+      while ((1 << lgW) < a.Wg) ++lgW;
+      while ((1 << lgH) < a.Hg) ++lgH;
+      if (a.Kpad == 96) hipLaunchKernelGGL((conv_cin8_kernel<3>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+      else hipLaunchKernelGGL((conv_cin8_kernel<4>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+      return hipGetLastError();
+    }
+  }
   const bool use_patch = (cfg == 0 || cfg == 1) && patch_ok(a, 4 * Elem<T>::E);
   ProfScope prof(use_patch ? "patch" : "igemm", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
                  es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
