@@ -21,7 +21,9 @@ WGRAD_TILES = {(2, 2, 4, 4): "128x128", (2, 2, 4, 2): "128x64", (4, 1, 2, 1): "1
 def classify(name):
   """'igemm_bf16_128x256' style class of a vp:: conv kernel, from either the mangled name or rocprofv3's (sometimes
   garbled: bf16 'DF16b' confuses its demangler and swallows the first int) demangled one; None for other kernels."""
-  for fam, tiles in (("igemm_dma_kernel", IGEMM_TILES), ("wgrad_kernel", WGRAD_TILES)):
+  if "conv_cin8_kernel" in name:
+    return "cin8_bf16_64x16"
+  for fam, tiles in (("igemm_dma_kernel", IGEMM_TILES), ("igemm_ws_kernel", IGEMM_TILES), ("igemm_regb_kernel", IGEMM_TILES), ("wgrad_kernel", WGRAD_TILES)):
     if fam not in name:
       continue
     m = re.search(fam + r"I(DF16b|f)((?:Li\d+E)+)", name)
@@ -35,7 +37,7 @@ def classify(name):
       args = [a.strip() for a in m.group(1).split(",")]
       nums = [int(a) for a in args if a.isdigit()]
       dt = "f32" if args[0] == "float" else "bf16"
-      want = 4 if fam == "igemm_dma_kernel" else 5
+      want = 5 if fam in ("wgrad_kernel", "igemm_ws_kernel") else 4
       ints = tuple(nums[:4]) if len(nums) >= want else tuple([1] + nums[:3])     # garbled form lost WC=1
     t = tiles.get(ints)
     return "%s_%s_%s" % ("igemm" if fam.startswith("igemm") else "wgrad", dt, t) if t else None
