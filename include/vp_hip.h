@@ -13,6 +13,8 @@
  *                             batch_normalization: pixrefer.py:61-101), exported for parity tests
  *   vp_logmel_*     replaces  generator/generator.py:60-80              (DataGenerator.extract_mfcc)
  *   vp_bfmnet_*     replaces  voicepuppet/bfmnet/bfmnet.py:189-213,325-333 + tinynet.py:159-212
+ *   vp_render_colors   replaces  utils/cython/mesh_core.h:63 _render_colors_core (mesh_core.cpp:169-231)
+ *   vp_bfm_reconstruct replaces  utils/reconstruct_mesh.py:198-223 Reconstruction_rotation + infer_bfmvid.py:92-99
  *
  * Conventions: every function returns 0 on success and a negative vp_status otherwise (never throws);
  * all tensor pointers are DEVICE pointers owned by the caller (NHWC, row-major); nothing is allocated
