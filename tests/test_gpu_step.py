@@ -240,3 +240,28 @@ def test_staged_generator_backward_equals_monolithic():
     torch.cuda.synchronize()
     assert torch.equal(eng.grads_g[lo:hi], want[lo:hi]), stage        # this bucket is final after its stage
   assert torch.equal(eng.grads_g, want)
+
+
+@pytest.mark.gpu
+def test_decoder_1_four_channel_kernel_in_situ():
+  """decoder_1 at a width where the dedicated 4-channel transposed-conv kernel runs (Cin = 64 = 2 MFMA steps per tap):
+  its f32 output against the float64 deconvolution of the SAME bf16 inputs the device fed it (teacher forcing)."""
+  from oracle import nn_ops as ops
+  ngf = 32
+  p = ref.init_params(ngf, ngf, seed=11, dtype=np.float32)
+  rng = np.random.default_rng(2)
+  inputs, fg, tgt = [torch.tensor(rng.uniform(size=(1, 256, 256, c)).astype(np.float32), device="cuda") for c in (6, 3, 3)]
+  eng = PixReferEngine(1, 256, ngf, ngf, dtype="bf16", training=False)
+  eng.load_params(p)
+  eng.forward(inputs, fg, tgt)
+  torch.cuda.synchronize()
+  c2 = eng.tensor("g/merged2_decoder_2").float()
+  sc, sh = eng.tensor("g/merged2_decoder_2:scale").view(-1), eng.tensor("g/merged2_decoder_2:shift").view(-1)
+  x_c2 = torch.relu(torch.addcmul(sh, sc, c2)).to(torch.bfloat16).float()          # act_apply: relu(fma(scale, y, shift)) -> bf16
+  x_e1 = torch.relu(eng.tensor("g/encoder_1").float())
+  x = torch.cat([x_c2, x_e1], dim=-1).cpu().numpy().astype(np.float64)
+  w = gu.rounded(p["generator/decoder_1/conv2d_transpose/kernel"], "bf16")
+  want = ops.deconv4s2_fwd(x, w, p["generator/decoder_1/conv2d_transpose/bias"].astype(np.float64))
+  got = eng.tensor("g/decoder_1").cpu().numpy()
+  assert got.shape == want.shape == (1, 256, 256, 4)
+  assert gu.rel_l2(got, want) < 2e-3, gu.rel_l2(got, want)       # fma-vs-float64 activation rounding flips a few bf16 ulps

@@ -1092,6 +1092,108 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
 }
 
 // ------------------------------------------------------------------------------------------------
+// deconv_cout4_kernel: the generator's last layer (decoder_1: 4x4 stride-2 transposed conv, Cin -> 4 channels, f32 output).
+// A tiled GEMM wastes 15/16 of its rows on 4 channels and re-launches per parity class.  Here the 4 classes x 4 channels ARE the
+// 16 rows of one MFMA tile: K runs over the 3x3 input neighbourhood of a base pixel (the union of the four classes' 2x2 taps;
+// a class's unused taps are zero rows of the weight image), columns are 16 consecutive base pixels.  After the K loop lane
+// (pixel i, group g) holds the 4 channels of output pixel (2q + g/2, 2r + g%2): one 16-byte f32 store, the four groups of a
+// base-pixel run fill two contiguous 512-byte output rows.  Weights: fragment-ordered LDS image built once per block; pixel
+// pieces straight from global memory (buffer loads, zeros outside), three (tap) units in flight per wave.
+// ------------------------------------------------------------------------------------------------
+template <int SPT>   // MFMA steps (32 channels each) per tap = Cin / 32
+__global__ __launch_bounds__(256) void deconv_cout4_kernel(const IgemmArgs a, int lgW, int lgH) {
+  constexpr int S = 9 * SPT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* wfrag = reinterpret_cast<uint4*>(smem);       // [S][64]
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, g = lane >> 4;
+  const int Cin = SPT * 32;
+  {
+    const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
+    const int nchunk_c = a.Kpad / 32;
+    for (int idx = threadIdx.x; idx < S * 64; idx += 256) {
+      const int l = idx & 63, s = idx >> 6;
+      const int u = s / SPT, c0 = (s % SPT) * 32 + (l >> 4) * 8;
+      const int dy = u / 3 - 1, dx = u % 3 - 1;
+      const int cls = (l & 15) >> 2, co = l & 3;
+      uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int tdh = 0, tdw = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c == cls) { tdh = a.taps[c].dh[t]; tdw = a.taps[c].dw[t]; }
+        if (tdh == dy && tdw == dx) {
+          const int k = t * Cin + c0;
+          v = *reinterpret_cast<const uint4*>(wp + (((size_t)cls * nchunk_c + (k >> 5)) * a.wp_rows + co) * 32 + (k & 31));
+        }
+      }
+      wfrag[idx] = v;
+    }
+    __syncthreads();
+  }
+  const int P = a.N << (lgW + lgH);                     // base pixels (input grid)
+  const int ntile = (P + 15) >> 4;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+  const int C0 = a.x.C[0], C1 = a.x.C[1];
+  __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * 2));
+  __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.x.ptr[1] ? a.x.ptr[1] : a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * 2));
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  float bias[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bias[e] = a.bias ? a.bias[e] : 0.f;
+
+  // loads of unit (tile, u): SPT pieces of this lane's pixel at tap u
+  auto load_unit = [&](int tile, int u, uint4 (&f)[SPT]) {
+    const int p = tile * 16 + i;
+    const int r = p & ((1 << lgW) - 1), q = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
+    const int ih = q + u / 3 - 1, iw = r + u % 3 - 1;
+    const bool ok = p < P && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+    const int pix = (n * a.Hin + ih) * a.Win + iw;
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+      const int c = k * 32 + g * 8;
+      const bool s1 = c >= C0;                          // uniform per k when C0 is a multiple of 32
+      const unsigned off = ok ? (unsigned)((pix * (s1 ? C1 : C0) + (s1 ? c - C0 : c)) * 2) : DMA_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s1 ? rs1 : rs0, (int)off, 0, 0);
+      f[k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+
+  uint4 f0[SPT], f1[SPT], f2[SPT];
+  int tile = wave_global;
+  if (tile < ntile) { load_unit(tile, 0, f0); load_unit(tile, 1, f1); }
+  while (tile < ntile) {
+    const int nxt = tile + nwave;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int wl = lane;
+    asm volatile("" : "+v"(wl));                        // keep the weight image in LDS (no hoisting into registers)
+    auto consume = [&](int u, const uint4 (&f)[SPT]) {
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) acc = mma16<bf16>(wfrag[(u * SPT + k) * 64 + wl], f[k], acc);
+    };
+    // units 0..8 rotate through the three fragment sets; unit u+2 is loaded before unit u is consumed
+    load_unit(tile, 2, f2); consume(0, f0);
+    load_unit(tile, 3, f0); consume(1, f1);
+    load_unit(tile, 4, f1); consume(2, f2);
+    load_unit(tile, 5, f2); consume(3, f0);
+    load_unit(tile, 6, f0); consume(4, f1);
+    load_unit(tile, 7, f1); consume(5, f2);
+    load_unit(tile, 8, f2); consume(6, f0);
+    if (nxt < ntile) load_unit(nxt, 0, f0);
+    consume(7, f1);
+    if (nxt < ntile) load_unit(nxt, 1, f1);
+    consume(8, f2);
+    const int p = tile * 16 + i;
+    if (p < P) {
+      const int r = p & ((1 << lgW) - 1), q = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
+      float* yp = reinterpret_cast<float*>(a.Y) + ((size_t)(n * a.Hof + 2 * q + (g >> 1)) * a.Wof + 2 * r + (g & 1)) * 4;
+      *reinterpret_cast<float4*>(yp) = make_float4(acc[0] + bias[0], acc[1] + bias[1], acc[2] + bias[2], acc[3] + bias[3]);
+    }
+    tile = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // igemm_patch_kernel: stride-1 convolutions (VGG 3x3, discriminator 4x4 s1, their backward-data) with the
 // input tile staged ONCE per channel chunk.  The 128 output pixels of a block are an 8 x 16 patch of one
 // image; the (8+k-1) x (16+k-1) input patch of a 64-byte channel chunk is DMA'd into LDS once and every tap
@@ -1726,6 +1828,29 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       while ((1 << lgH) < a.Hg) ++lgH;
       if (a.Kpad == 96) hipLaunchKernelGGL((conv_cin8_kernel<3>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
       else hipLaunchKernelGGL((conv_cin8_kernel<4>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // 4-channel f32 transposed conv (decoder_1): the four parity classes x four channels as one MFMA tile (deconv_cout4_kernel)
+    static const bool co4_on = !getenv("VP_NO_COUT4");
+    const bool pow2 = (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0;
+    const int spt = a.Cin / 32;
+    if (co4_on && a.zeros && a.nclass == 4 && a.os == 2 && a.ntaps == 4 && a.Cout == 4 && a.y_f32 && a.ldY == 4 && a.splitk == 1 && pow2 &&
+        a.Cin % 32 == 0 && (spt == 2 || spt == 4) && a.x.C[0] % 32 == 0 && a.x.C[0] + a.x.C[1] == a.Cin && !a.ref && !a.accumulate &&
+        a.out_act == ACT_NONE && !a.x.aff_a[0] && !a.x.aff_a[1] && a.x.act == ACT_NONE && a.Hof == 2 * a.Hg && a.Wof == 2 * a.Wg &&
+        (size_t)a.N * a.Hin * a.Win * a.Cin * 2 < 0x70000000ull) {
+      ProfScope prof("cout4", true, 16, 16, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout) + 4.0 * Pn * a.Cout, st);
+      const int ntile = (a.N * a.Hg * a.Wg + 15) / 16;
+      int blocks = (ntile + 3) / 4;
+      if (blocks > 2048) blocks = 2048;
+      int lgW = 0, lgH = 0;
+      while ((1 << lgW) < a.Wg) ++lgW;
+      while ((1 << lgH) < a.Hg) ++lgH;
+      const size_t sm = (size_t)9 * spt * 64 * 16;
+      if (spt == 2) hipLaunchKernelGGL((deconv_cout4_kernel<2>), dim3(blocks), dim3(256), sm, st, a, lgW, lgH);
+      else hipLaunchKernelGGL((deconv_cout4_kernel<4>), dim3(blocks), dim3(256), sm, st, a, lgW, lgH);
       return hipGetLastError();
     }
   }
