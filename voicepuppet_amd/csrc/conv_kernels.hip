@@ -364,15 +364,21 @@ constexpr int epi_passes(int BC, int BP, int WP, int ring_bytes) {
   return WP;
 }
 
-template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, typename PixFn>
+// STATS (a batch-normalised layer): the epilogue also produces the layer's batch statistics.  While a pass's f32 tile sits in
+// LDS, thread t sums column (channel) t % BC over its share of the rows - of the values AS STORED, i.e. rounded to T - into two
+// registers; after the last pass the NT / BC threads of a channel fold through LDS and the block writes one [2][channels]
+// partial per pixel tile for bn_finalize_kernel.  The tensor is never re-read.
+template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, bool STATS = false, typename PixFn>
 __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn& pixfn, int c_base, int blkA0, int blkB0,
-                                                f32x4 (&acc)[TC][TP], char* smem) {
+                                                f32x4 (&acc)[TC][TP], char* smem, int pt = 0, int cls = 0) {
   constexpr int PITCH = BC * 4 + 16;                 // bytes per pixel row (+16: conflict-free b128 writes)
   constexpr int CG = BC / 8;                         // 8-channel groups per row
   constexpr int RP = BP / NPASS;                     // pixel rows staged per pass (keeps the tile inside the ring's LDS)
   static_assert(RP % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
   const int tid = threadIdx.x, lane = tid & 63;
   long long* otab = reinterpret_cast<long long*>(smem + RP * PITCH);
+  static_assert(!STATS || NT % BC == 0, "column sums: whole thread groups per channel");
+  float bsum = 0.f, bsq = 0.f;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     __syncthreads();                                 // ring (pass 0) / previous pass's tile no longer needed
@@ -389,6 +395,15 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
         }
     }
     __syncthreads();
+    if constexpr (STATS) {
+      const int col = tid % BC;
+      for (int rr = tid / BC; rr < RP; rr += NT / BC) {
+        if (otab[rr] < 0) continue;
+        float x = *reinterpret_cast<const float*>(smem + rr * PITCH + col * 4);
+        if (sizeof(T) == 2) x = bf16_bits_to_f32(f32_to_bf16_bits(x));
+        bsum += x; bsq = fmaf(x, x, bsq);
+      }
+    }
     for (int idx = tid; idx < RP * CG; idx += NT) {
       const int p = idx / CG, cgp = idx - p * CG;
       const long long ot = otab[p];
@@ -445,9 +460,25 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
       }
     }
   }
+  if constexpr (STATS) {
+    __syncthreads();                                   // the staged tile is dead: reuse its LDS
+    float* red = reinterpret_cast<float*>(smem);       // [NT / BC][2][BC]
+    red[(tid / BC) * 2 * BC + tid % BC] = bsum;
+    red[(tid / BC) * 2 * BC + BC + tid % BC] = bsq;
+    __syncthreads();
+    if (tid < 2 * BC || (NT < 2 * BC && tid < BC)) {
+      const int grp = pt / a.bn_tpg, chunk = cls * a.bn_tpg + (pt - grp * a.bn_tpg);
+      for (int j = tid; j < 2 * BC; j += NT) {
+        float t = 0.f;
+        for (int m = 0; m < NT / BC; ++m) t += red[m * 2 * BC + j];
+        const int c = c_base + (j % BC);
+        if (c < a.Cout) a.bn_part[((size_t)(grp * a.bn_nchunk + chunk) * 2 + j / BC) * a.Cout + c] = (double)t;
+      }
+    }
+  }
 }
 
-template <typename T, int WC, int WP, int TC, int TP, bool STAGED>
+template <typename T, int WC, int WP, int TC, int TP, bool STAGED, bool STATS = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NW = WC * WP, NT = NW * 64;             // 4 waves (256 threads) or 8 waves (512 threads: 128x256 / 256x256 tiles)
@@ -639,7 +670,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
   if (STAGED) {
     constexpr int RINGB = NST * BUF * 16;
     constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
-    staged_epilogue<T, TC, TP, BC, BP, NPASS, NT>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem);
+    staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
     return;
   }
 #pragma unroll
@@ -819,7 +850,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_regb_kernel(const IgemmArg
   }
 
   constexpr int NPASS = epi_passes(BC, BP, WP, VP_REGB_EPI_BYTES);
-  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem);
+  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -832,7 +863,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_regb_kernel(const IgemmArg
 //   consumer kc: barrier kc -> fragments + MFMAs of chunk kc
 // fastk operands only (scalar K stepping, hardware zero fill); epilogue = the staged 16-byte row stores, all waves storing.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int WC, int WP, int TC, int TP, int NST>
+template <typename T, int WC, int WP, int TC, int TP, int NST, bool STATS = false>
 __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NPW = 4;
@@ -978,7 +1009,7 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
 
   constexpr int RINGB = NST * BUF * 16;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
-  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem);
+  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1755,13 +1786,14 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         size_t sm = RB + 64;
         const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
         if (se > sm) sm = se;
-        hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW>), grid, dim3((NW + 4) * 64), sm, st, b);
+        if (b.bn_part) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, true>), grid, dim3((NW + 4) * 64), sm, st, b);
+        else hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, false>), grid, dim3((NW + 4) * 64), sm, st, b);
         return hipGetLastError();
       }
     }
     static const int regb_on = getenv("VP_REGB") ? atoi(getenv("VP_REGB")) : 0;   // measured slower (round 1): opt-in experiment
     if constexpr ((BC / 16) % NW == 0) {
-      if (regb_on && b.vec_epi && b.fastk && a.splitk == 1) {
+      if (regb_on && b.vec_epi && b.fastk && a.splitk == 1 && !b.bn_part) {
         constexpr int NPE = epi_passes(BC, BP, WP, VP_REGB_EPI_BYTES);
         size_t sm = 3 * 4 * BC * 16 + 64;
         const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
@@ -1770,7 +1802,8 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         return hipGetLastError();
       }
     }
-    if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
+    if (b.vec_epi && b.bn_part) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, true>), grid, dim3(NW * 64), smem, st, b);
+    else if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(NW * 64), smem, st, b);
     return hipGetLastError();
   }
@@ -1816,7 +1849,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     static const bool cin8_on = !getenv("VP_NO_CIN8");
     const bool pow2 = (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0;
     if (cin8_on && a.zeros && a.Cin == 8 && a.x.C[0] == 8 && a.x.C[1] == 0 && a.Cout == 64 && a.ldY == 64 && a.nclass == 1 && a.splitk == 1 &&
-        a.os == 1 && a.Hof == a.Hg && a.Wof == a.Wg && pow2 && !a.ref && !a.accumulate && !a.y_f32 && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
+        a.os == 1 && a.Hof == a.Hg && a.Wof == a.Wg && pow2 && !a.ref && !a.accumulate && !a.y_f32 && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
         a.ntaps <= 16 && (a.Kpad == 96 || a.Kpad == 128) && (size_t)a.N * a.Hin * a.Win * 16 < 0x70000000ull) {
       ProfScope prof("cin8", true, 64, 16, 2.0 * Pn * a.Cout * kreal,
                      es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.Cout + Pn * a.Cout), st);

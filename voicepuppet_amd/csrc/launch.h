@@ -20,6 +20,7 @@ hipError_t launch_pack_weights(const PackDesc* d_descs, int ndesc, const float* 
 hipError_t launch_pack_weights_one(const PackDesc& d, const float* master, void* packed, int is_bf16, hipStream_t st);
 int bn_nchunk(int Pg, int C, int G, int is_bf16);
 hipError_t launch_bn_stats(const BnArgs& a, int is_bf16, hipStream_t st);
+hipError_t launch_bn_finalize(const BnArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate, int is_bf16, hipStream_t st);
 hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int C, int Pg, size_t npix,

@@ -412,7 +412,8 @@ static int run_pack(vp_pixrefer* h, Net& n, hipStream_t st) {
   return VP_OK;
 }
 
-static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
+// fused_chunks > 0: the conv epilogue already wrote that many partial chunks per group; only the finalize pass runs
+static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, int fused_chunks, hipStream_t st) {
   Tens& t = n.t[L.out];
   BnArgs b;
   memset(&b, 0, sizeof(b));
@@ -422,6 +423,7 @@ static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
   b.gamma = n.params + L.gamma_off; b.beta = n.params + L.beta_off;
   b.aff_a = t.bn.a; b.aff_b = t.bn.b; b.mu = t.bn.mu; b.rstd = t.bn.rstd;
   b.eps = 1e-5f;   // pixrefer.py:100
+  if (fused_chunks > 0) { b.nchunk = fused_chunks; VP_HIP_CHECK(launch_bn_finalize(b, st)); return VP_OK; }
   VP_HIP_CHECK(launch_bn_stats(b, h->bf16, st));
   return VP_OK;
 }
@@ -439,6 +441,23 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
   a.partial = (float*)h->scratch;
   a.zeros = h->zeros;
   if (L.tapgemm) { a.Y = L.tap_S; a.y_f32 = 1; a.ldY = 16; a.bias = nullptr; }
+  // batch statistics from the conv epilogue (no re-read of the output) when every pixel tile lies inside one BN group
+  bool fused_stats = false;
+  int stat_chunks = 0;
+  static const bool fuse_on = !getenv("VP_NO_BNFUSE");
+  if (fuse_on && L.has_bn && a.splitk == 1 && L.g.Cout % 8 == 0 && a.ldY % 8 == 0 && !a.y_f32) {
+    int bc, bp;
+    igemm_tile(L.fwd.cfg, &bc, &bp);
+    const int pg = (n.batch / n.groups) * a.Hg * a.Wg;            // pixels of one group, per class
+    if (n.groups == 1 || pg % bp == 0) {
+      const int tpg = (pg + bp - 1) / bp;
+      stat_chunks = a.nclass * tpg;
+      if ((size_t)n.groups * stat_chunks * 2 * to.C <= (size_t)1024 * 2 * 512) {
+        a.bn_part = h->bn_partial; a.bn_tpg = tpg; a.bn_nchunk = stat_chunks;
+        fused_stats = true;
+      }
+    }
+  }
   profile_tag((L.scope + ":fwd").c_str());
   VP_HIP_CHECK(launch_igemm(a, h->bf16, L.fwd.cfg, st));
   if (L.tapgemm) {
@@ -448,7 +467,7 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
     ta.N = L.g.N; ta.Hin = L.g.Hin; ta.Win = L.g.Win; ta.Hout = L.g.Hout; ta.Wout = L.g.Wout; ta.ks = L.g.ks; ta.pad = L.g.pad;
     VP_HIP_CHECK(launch_tap_gather(ta, st));
   }
-  if (L.has_bn) { const int rc = run_bn_stats(h, n, L, st); if (rc) return rc; }
+  if (L.has_bn) { const int rc = run_bn_stats(h, n, L, fused_stats ? stat_chunks : 0, st); if (rc) return rc; }
   if (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) {
     VP_HIP_CHECK(launch_act_apply(to.y, L.has_bn ? to.bn.a : nullptr, L.has_bn ? to.bn.b : nullptr, to.C,
                                   (n.batch / n.groups) * to.H * to.W, (size_t)to.N * to.H * to.W,

@@ -596,6 +596,11 @@ hipError_t launch_bn_stats(const BnArgs& a, int is_bf16, hipStream_t st) {
   return hipGetLastError();
 }
 
+hipError_t launch_bn_finalize(const BnArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.G * a.C + 3) / 4), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st) {
   dim3 grid(a.nchunk, a.G);
   if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 1>), grid, dim3(256), 0, st, a);

@@ -59,12 +59,17 @@ template <> struct Elem<bf16> {
     f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
   }
+  // two floats -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {lo, hi};
+    const bf2 h = __builtin_convertvector(v, bf2);
+    return *reinterpret_cast<const uint32_t*>(&h);
+  }
   __device__ static __forceinline__ uint4 pack(const float* f) {
     uint4 v;
-    v.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
-    v.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
-    v.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16);
-    v.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+    v.x = pack2(f[0], f[1]); v.y = pack2(f[2], f[3]); v.z = pack2(f[4], f[5]); v.w = pack2(f[6], f[7]);
     return v;
   }
   __device__ static __forceinline__ float ld(const bf16* p) { return bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(p)); }
