@@ -30,22 +30,35 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* sm /* >= NV*4
 // ------------------------------------------------------------------------------------------------
 // weight packing (fp32 master, TF layouts HWIO / HWOI) -> [class][row][tap*C + c] in T
 // ------------------------------------------------------------------------------------------------
+// One thread per 16-byte output piece (E consecutive k of one row: always inside one tap, channels are padded to 8).
+// The thread order follows the SOURCE layout: HWIO convolution kernels are contiguous along the packed row (Cout), so
+// adjacent threads take adjacent rows; otherwise (HWOI, backward-data views) k is contiguous and adjacent threads take
+// adjacent pieces of one row.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ master, T* __restrict__ packed) {
+  constexpr int E = Elem<T>::E;
   const PackDesc& d = descs[blockIdx.y];
-  const size_t total = (size_t)d.nclass * d.rows_pad * d.Kpad;
+  const int npiece = d.Kpad / E;
+  const int total = d.nclass * d.rows_pad * npiece;
   T* dst = packed + d.dst_off;
   const float* src = master + d.src_off;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int k = (int)(i % d.Kpad);
-    const size_t t = i / d.Kpad;
-    const int row = (int)(t % d.rows_pad);
-    const int cls = (int)(t / d.rows_pad);
-    const int tap = k / d.C, c = k - tap * d.C;
-    float v = 0.f;
-    if (row < d.rows_real && tap < d.ntaps && c < d.C_real)
-      v = src[(size_t)d.kh[cls][tap] * d.s_kh + (size_t)d.kw[cls][tap] * d.s_kw + (size_t)row * d.s_row + (size_t)c * d.s_ch];
-    Elem<T>::st(dst + (((size_t)cls * (d.Kpad / d.kc) + k / d.kc) * d.rows_pad + row) * d.kc + k % d.kc, v);
+  const bool row_fast = d.s_row == 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int row, piece, cls;
+    if (row_fast) { row = i % d.rows_pad; const int t = i / d.rows_pad; piece = t % npiece; cls = t / npiece; }
+    else { piece = i % npiece; const int t = i / npiece; row = t % d.rows_pad; cls = t / d.rows_pad; }
+    const int k0 = piece * E;
+    const int tap = k0 / d.C, c0 = k0 - tap * d.C;
+    float v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = 0.f;
+    if (row < d.rows_real && tap < d.ntaps) {
+      const float* p = src + (size_t)d.kh[cls][tap] * d.s_kh + (size_t)d.kw[cls][tap] * d.s_kw + (size_t)row * d.s_row + (size_t)c0 * d.s_ch;
+#pragma unroll
+      for (int e = 0; e < E; ++e) if (c0 + e < d.C_real) v[e] = p[(size_t)e * d.s_ch];
+    }
+    T* o = dst + (((size_t)cls * (d.Kpad / d.kc) + k0 / d.kc) * d.rows_pad + row) * d.kc + k0 % d.kc;
+    *reinterpret_cast<uint4*>(o) = Elem<T>::pack(v);
   }
 }
 
