@@ -21,6 +21,9 @@ hipError_t launch_pack_weights_one(const PackDesc& d, const float* master, void*
 int bn_nchunk(int Pg, int C, int G, int is_bf16);
 hipError_t launch_bn_stats(const BnArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_bn_finalize(const BnArgs& a, hipStream_t st);
+bool bn_small(const BnArgs& a);     // few pixels per group: statistics + finalize + per-pixel pass in one launch
+hipError_t launch_bn_small_fwd(const BnArgs& a, void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st);
+hipError_t launch_bn_small_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate, int is_bf16, hipStream_t st);
 hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int C, int Pg, size_t npix,

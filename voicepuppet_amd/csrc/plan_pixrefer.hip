@@ -424,6 +424,10 @@ static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, int fused_chunks, hipS
   b.aff_a = t.bn.a; b.aff_b = t.bn.b; b.mu = t.bn.mu; b.rstd = t.bn.rstd;
   b.eps = 1e-5f;   // pixrefer.py:100
   if (fused_chunks > 0) { b.nchunk = fused_chunks; VP_HIP_CHECK(launch_bn_finalize(b, st)); return VP_OK; }
+  if (bn_small(b)) {   // also materialises the activations: tell the caller to skip act_apply
+    VP_HIP_CHECK(launch_bn_small_fwd(b, t.xa[ACT_LRELU], t.xa[ACT_RELU], h->bf16, st));
+    return 1;
+  }
   VP_HIP_CHECK(launch_bn_stats(b, h->bf16, st));
   return VP_OK;
 }
@@ -467,8 +471,13 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
     ta.N = L.g.N; ta.Hin = L.g.Hin; ta.Win = L.g.Win; ta.Hout = L.g.Hout; ta.Wout = L.g.Wout; ta.ks = L.g.ks; ta.pad = L.g.pad;
     VP_HIP_CHECK(launch_tap_gather(ta, st));
   }
-  if (L.has_bn) { const int rc = run_bn_stats(h, n, L, fused_stats ? stat_chunks : 0, st); if (rc) return rc; }
-  if (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) {
+  bool acts_done = false;
+  if (L.has_bn) {
+    const int rc = run_bn_stats(h, n, L, fused_stats ? stat_chunks : 0, st);
+    if (rc < 0) return rc;
+    acts_done = rc == 1;
+  }
+  if (!acts_done && (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU])) {
     VP_HIP_CHECK(launch_act_apply(to.y, L.has_bn ? to.bn.a : nullptr, L.has_bn ? to.bn.b : nullptr, to.C,
                                   (n.batch / n.groups) * to.H * to.W, (size_t)to.N * to.H * to.W,
                                   to.xa[ACT_LRELU], to.xa[ACT_RELU], h->bf16, st));
@@ -558,6 +567,7 @@ static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample
   b.mu = t.bn.mu + (size_t)group0 * t.C; b.rstd = t.bn.rstd + (size_t)group0 * t.C;
   b.c1 = t.bn.c1; b.c2 = t.bn.c2;
   if (want_dw) { b.dgamma = n.grads + L.gamma_off; b.dbeta = n.grads + L.beta_off; }
+  if (bn_small(b)) { VP_HIP_CHECK(launch_bn_small_bwd(b, h->bf16, st)); return VP_OK; }
   VP_HIP_CHECK(launch_bn_bwd(b, h->bf16, st));
   return VP_OK;
 }

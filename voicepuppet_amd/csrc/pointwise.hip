@@ -220,6 +220,138 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small tensors (the 1x1 .. 16x16 bottleneck of the generator): statistics, finalize and the per-pixel pass in ONE launch
+// per direction - these layers are launch-latency bound, three dependent kernels each.  One block per E-channel group walks
+// all pixels of a BN group twice (the tensor slice is a few tens of KB: second pass hits L2).
+//   forward : sum / sum^2 -> scale, shift, mean, rstd -> x~ = act(scale*y + shift) for the activations the consumers need
+//   backward: sum dz, sum dz*zhat -> c1, c2 (+ dgamma, dbeta over all groups) -> dy = gamma*rstd*(dz - c1 - zhat*c2) in place
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void block_sum2(double (&s0)[E], double (&s1)[E], double* sm /* [4][2E] */) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) { s0[e] = wave_sum(s0[e]); s1[e] = wave_sum(s1[e]); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) { sm[wave * 2 * E + e] = s0[e]; sm[wave * 2 * E + E + e] = s1[e]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    s0[e] = sm[e] + sm[2 * E + e] + sm[4 * E + e] + sm[6 * E + e];
+    s1[e] = sm[E + e] + sm[3 * E + e] + sm[5 * E + e] + sm[7 * E + e];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const BnArgs a, T* __restrict__ out_lrelu, T* __restrict__ out_relu) {
+  constexpr int E = Elem<T>::E;
+  __shared__ double sm[4 * 2 * E];
+  const int c0 = blockIdx.x * E, grp = blockIdx.y;
+  const T* y = reinterpret_cast<const T*>(a.y) + (size_t)grp * a.Pg * a.C + c0;
+  double s0[E], s1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { s0[e] = 0; s1[e] = 0; }
+  for (int p = threadIdx.x; p < a.Pg; p += 256) {
+    float f[E];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + (size_t)p * a.C), f);
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s0[e] += f[e]; s1[e] += (double)f[e] * f[e]; }
+  }
+  block_sum2<E>(s0, s1, sm);
+  float sc[E], sh[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const double mean = s0[e] / a.Pg;
+    double var = s1[e] / a.Pg - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float g = a.gamma[c0 + e], b = a.beta[c0 + e];
+    sc[e] = (var == 0.0) ? 0.f : g * rstd;                               // same zero-variance rule as bn_finalize_kernel
+    sh[e] = (var == 0.0) ? b : (float)((double)b - mean * (double)sc[e]);
+    if (threadIdx.x == 0) {
+      const int i = grp * a.C + c0 + e;
+      a.aff_a[i] = sc[e]; a.aff_b[i] = sh[e]; a.mu[i] = (float)mean; a.rstd[i] = rstd;
+    }
+  }
+  if (!out_lrelu && !out_relu) return;
+  const size_t base = (size_t)grp * a.Pg * a.C + c0;
+  for (int p = threadIdx.x; p < a.Pg; p += 256) {
+    float f[E], o[E];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + (size_t)p * a.C), f);
+#pragma unroll
+    for (int e = 0; e < E; ++e) f[e] = fmaf(sc[e], f[e], sh[e]);
+    if (out_lrelu) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = act_apply(ACT_LRELU, f[e]);
+      *reinterpret_cast<uint4*>(out_lrelu + base + (size_t)p * a.C) = Elem<T>::pack(o);
+    }
+    if (out_relu) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = act_apply(ACT_RELU, f[e]);
+      *reinterpret_cast<uint4*>(out_relu + base + (size_t)p * a.C) = Elem<T>::pack(o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const BnArgs a) {
+  constexpr int E = Elem<T>::E;
+  __shared__ double sm[4 * 2 * E];
+  const int c0 = blockIdx.x * E;
+  double dg[E], db[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { dg[e] = 0; db[e] = 0; }
+  for (int grp = 0; grp < a.G; ++grp) {
+    const size_t base = (size_t)grp * a.Pg * a.C + c0;
+    const T* y = reinterpret_cast<const T*>(a.y) + base;
+    const T* dz = reinterpret_cast<const T*>(a.dz) + base;
+    T* dy = reinterpret_cast<T*>(a.dy) + base;
+    float mu[E], rs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { mu[e] = a.mu[grp * a.C + c0 + e]; rs[e] = a.rstd[grp * a.C + c0 + e]; }
+    double s0[E], s1[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s0[e] = 0; s1[e] = 0; }
+    for (int p = threadIdx.x; p < a.Pg; p += 256) {
+      float fy[E], fd[E];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + (size_t)p * a.C), fy);
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(dz + (size_t)p * a.C), fd);
+#pragma unroll
+      for (int e = 0; e < E; ++e) { s0[e] += fd[e]; s1[e] += (double)fd[e] * ((fy[e] - mu[e]) * rs[e]); }
+    }
+    block_sum2<E>(s0, s1, sm);
+    float c1[E], c2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      c1[e] = (float)(s0[e] / a.Pg); c2[e] = (float)(s1[e] / a.Pg);
+      db[e] += s0[e]; dg[e] += s1[e];
+      if (threadIdx.x == 0) { a.c1[grp * a.C + c0 + e] = c1[e]; a.c2[grp * a.C + c0 + e] = c2[e]; }
+    }
+    for (int p = threadIdx.x; p < a.Pg; p += 256) {
+      float fy[E], fd[E];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + (size_t)p * a.C), fy);
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(dz + (size_t)p * a.C), fd);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float zh = (fy[e] - mu[e]) * rs[e];
+        fd[e] = a.gamma[c0 + e] * rs[e] * (fd[e] - c1[e] - zh * c2[e]);
+      }
+      *reinterpret_cast<uint4*>(dy + (size_t)p * a.C) = Elem<T>::pack(fd);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && a.dgamma) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      a.dgamma[c0 + e] = (float)dg[e] + (a.accumulate ? a.dgamma[c0 + e] : 0.f);
+      a.dbeta[c0 + e] = (float)db[e] + (a.accumulate ? a.dbeta[c0 + e] : 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // materialise the activated tensors the consumers read: x~ = act(scale*y + shift) (batch-norm affine of
 // the producer, per BN group).  One read of y, one write per needed activation.  The MFMA kernels then
 // move plain bytes (LDS-DMA) instead of re-doing this per tap and per consumer.
@@ -606,6 +738,26 @@ hipError_t launch_bn_stats(const BnArgs& a, int is_bf16, hipStream_t st) {
   if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 0>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), grid, dim3(256), 0, st, a);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.G * a.C + 3) / 4), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+bool bn_small(const BnArgs& a) {
+  static const bool on = !getenv("VP_NO_BNSMALL");
+  static const int lim = getenv("VP_BNSMALL_PG") ? atoi(getenv("VP_BNSMALL_PG")) : 2048;
+  return on && a.Pg <= lim;
+}
+
+hipError_t launch_bn_small_fwd(const BnArgs& a, void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st) {
+  const int E = is_bf16 ? 8 : 4;
+  if (is_bf16) hipLaunchKernelGGL((bn_small_fwd_kernel<bf16>), dim3(a.C / E, a.G), dim3(256), 0, st, a, (bf16*)out_lrelu, (bf16*)out_relu);
+  else hipLaunchKernelGGL((bn_small_fwd_kernel<float>), dim3(a.C / E, a.G), dim3(256), 0, st, a, (float*)out_lrelu, (float*)out_relu);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_small_bwd(const BnArgs& a, int is_bf16, hipStream_t st) {
+  const int E = is_bf16 ? 8 : 4;
+  if (is_bf16) hipLaunchKernelGGL((bn_small_bwd_kernel<bf16>), dim3(a.C / E), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bn_small_bwd_kernel<float>), dim3(a.C / E), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
