@@ -94,9 +94,8 @@ def main():
     group = dist.group.WORLD
 
   from voicepuppet_amd.engine import PixReferEngine
-  from oracle import pixrefer_ref as ref   # parameter initialisation only (host side, untimed)
   eng = PixReferEngine(args.batch, args.height, 64, 64, dtype=args.dtype, training=True)
-  eng.load_params(ref.init_params(64, 64, seed=0, dtype=np.float32))   # identical on every rank
+  eng.load_params(eng.random_params(seed=0))   # the reference's initialisers, identical on every rank
   batch = synth_batch(args.batch, args.height, 1000 + rank, device)
   lr = 3e-4
 

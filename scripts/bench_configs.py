@@ -4,7 +4,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
-from oracle import pixrefer_ref as ref, audio_ref as ar
+from oracle import audio_ref as ar   # pcm length helper + BFMNet initialiser only (scripts/ is not the product path)
 from voicepuppet_amd.engine import PixReferEngine
 from voicepuppet_amd.audio import LogMel, BFMNetEngine
 
@@ -14,16 +14,15 @@ def timed(fn, warm, steps):
   for _ in range(steps): fn()
   torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps
 
-p = ref.init_params(64, 64, seed=0, dtype=np.float32)
 for n, h in ((8, 256), (8, 512), (2, 512)):
-  eng = PixReferEngine(n, h, 64, 64, dtype="bf16", training=True); eng.load_params(p)
+  eng = PixReferEngine(n, h, 64, 64, dtype="bf16", training=True); eng.load_params(eng.random_params(0))
   b = bench.synth_batch(n, h, 1, torch.device("cuda"))
   dt = timed(lambda: eng.train_step(*b, lr=3e-4), 3, 10)
   print(json.dumps({"config": "G+D step bf16 bs=%d %dx%d 1 GPU" % (n, h, h), "ms_per_step": dt * 1e3, "frames_per_s": n / dt,
                     "tflops": 163.02e9 * (h / 256) ** 2 * n / dt / 1e12}))
   del eng; torch.cuda.empty_cache()
 for n, h in ((1, 512), (8, 512), (1, 256)):
-  eng = PixReferEngine(n, h, 64, 64, dtype="bf16", training=False, per_sample_bn=True); eng.load_params(p)
+  eng = PixReferEngine(n, h, 64, 64, dtype="bf16", training=False, per_sample_bn=True); eng.load_params(eng.random_params(0))
   b = bench.synth_batch(n, h, 1, torch.device("cuda"))
   dt = timed(lambda: eng.forward(b[0], b[1], b[2]), 5, 30)
   print(json.dumps({"config": "generator inference bf16 bs=%d %dx%d" % (n, h, h), "ms": dt * 1e3, "frames_per_s": n / dt}))

@@ -3,13 +3,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
-from oracle import pixrefer_ref as ref
 from voicepuppet_amd.engine import PixReferEngine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 h = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dt = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 eng = PixReferEngine(n, h, 64, 64, dtype=dt, training=True)
-eng.load_params(ref.init_params(64, 64, seed=0, dtype=np.float32))
+eng.load_params(eng.random_params(0))
 batch = bench.synth_batch(n, h, 1, torch.device("cuda"))
 for _ in range(2): eng.train_step(*batch, lr=3e-4)
 torch.cuda.synchronize()

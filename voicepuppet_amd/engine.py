@@ -98,6 +98,25 @@ class PixReferEngine:
       a.copy_(torch.from_numpy(host))
     self.params_changed()
 
+  def random_params(self, seed=0):
+    """The reference's variable initialisers (pixrefer.py:64,68,100-101: kernels N(0,0.02), gamma N(1,0.02), bias/beta 0)
+    plus He-normal stand-ins for the external vgg_16 checkpoint; {tf_variable_name: float32 array}, same on every rank."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for which in range(3):
+      if self.arena(which) is None:
+        continue
+      for name, _, shape in self.manifests[which]:
+        if name.endswith("kernel"):
+          p[name] = rng.normal(0, 0.02, shape).astype(np.float32)
+        elif name.endswith("gamma"):
+          p[name] = rng.normal(1.0, 0.02, shape).astype(np.float32)
+        elif name.endswith("weights"):
+          p[name] = rng.normal(0, np.sqrt(2.0 / (shape[0] * shape[1] * shape[2])), shape).astype(np.float32)
+        else:
+          p[name] = np.zeros(shape, np.float32)
+    return p
+
   def get_params(self, which, src=None):
     a = (self.arena(which) if src is None else src).cpu().numpy()
     return {name: a[off:off + int(np.prod(shape))].reshape(shape).copy() for name, off, shape in self.manifests[which]}
