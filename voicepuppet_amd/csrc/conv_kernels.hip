@@ -1656,20 +1656,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
   }
 }
 
-// many splits, few outputs (the 3/6/4/1-channel layers): one wave per output element, lanes stride over the slabs
+// many splits, few outputs (the 3/6/4/1-channel layers): one block per gradient row (tap, g).  Thread (k group, d quad) sums
+// float4s of slabs k = kg, kg + KG, ... - a wave reads whole 16-byte-aligned row segments of consecutive slabs (coalesced; one
+// wave per output element read 4 bytes per slab at a 32 KB stride) - and the KG partial sums fold through LDS in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const WgradArgs a) {
-  const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal;
-  const int lane = threadIdx.x & 63;
-  for (size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (size_t)gridDim.x * 4) {
-    const int d = (int)(i % a.Dreal);
-    const size_t t = i / a.Dreal;
-    const int gc = (int)(t % a.Greal);
-    const int tap = (int)(t / a.Greal);
-    const size_t m = (size_t)tap * a.Gc + gc;
-    float s = 0.f;
-    for (int k = lane; k < a.splitk; k += 64) s += a.partial[((size_t)k * a.Mpad + m) * a.Dpad + d];
-    s = wave_sum(s);
-    if (lane == 0) a.dW[i] = s + (a.accumulate ? a.dW[i] : 0.f);
+  __shared__ float4 sm[256];
+  const int row = blockIdx.x;                       // (tap, gc) with gc < Greal
+  const int tap = row / a.Greal, gc = row - tap * a.Greal;
+  const size_t m = (size_t)tap * a.Gc + gc;
+  const int dq = (a.Dreal + 3) >> 2;                // float4 columns (Dpad is a multiple of 16: reads stay inside the slab row)
+  int dqp = 1;
+  while (dqp < dq) dqp <<= 1;                       // threads per k group (power of two <= 256)
+  const int KG = 256 / dqp;
+  const int d4 = threadIdx.x % dqp, kg = threadIdx.x / dqp;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d4 < dq) {
+    for (int k = kg; k < a.splitk; k += KG) {
+      const float4 v = *reinterpret_cast<const float4*>(a.partial + ((size_t)k * a.Mpad + m) * a.Dpad + d4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (kg == 0 && d4 < dq) {
+    for (int j = 1; j < KG; ++j) { const float4 v = sm[j * dqp + d4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    float* o = a.dW + ((size_t)tap * a.Greal + gc) * a.Dreal + d4 * 4;
+    const float r[4] = {s.x, s.y, s.z, s.w};
+    for (int e = 0; e < 4; ++e)
+      if (d4 * 4 + e < a.Dreal) o[e] = r[e] + (a.accumulate ? o[e] : 0.f);
   }
 }
 
@@ -1950,11 +1964,8 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess || a.splitk == 1) return e;
-  if (a.splitk >= 32) {
-    const size_t outs = (size_t)a.ntaps * a.Greal * a.Dreal;
-    int wb = (int)((outs + 3) / 4);
-    if (wb > 8192) wb = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3(wb), dim3(256), 0, st, a);
+  if (a.splitk >= 32 && a.Dreal <= 1024) {
+    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3(a.ntaps * a.Greal), dim3(256), 0, st, a);
     return hipGetLastError();
   }
   const size_t total = (size_t)a.ntaps * a.Greal * a.Dreal / ((a.Dreal & 3) ? 1 : 4);
