@@ -1013,6 +1013,144 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
 }
 
 // ------------------------------------------------------------------------------------------------
+// igemm_wsr_kernel: 64-channel outputs with a short K (VGG conv1_2 and its backward, the backward-data of the 64-channel
+// stride-2 layers).  With a 64-row weight tile two thirds of what the tiled kernels move through the LDS-DMA path is pixels and one
+// third is the SAME 64 x K weight matrix, re-fetched by every block.  Here the whole matrix (K <= 576: <= 72 KB) is DMA'd into
+// LDS once per block and stays; the block is persistent and walks pixel tiles, so only the pixel operand streams through the
+// ring (4 producer waves, WP consumer waves as in igemm_ws_kernel, one barrier per K chunk, the pipeline runs across tiles).
+// The staged epilogue has its own LDS buffer because the producers already prefetch the next tile while a tile is stored.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WP, int TP, int NST, bool STATS = false>
+__global__ __launch_bounds__((WP + 4) * 64) void igemm_wsr_kernel(const IgemmArgs a) {
+  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int NPW = 4, TC = 4;
+  constexpr int NW = WP, NT = (NW + NPW) * 64;
+  constexpr int BC = 64, BP = WP * TP * 16;
+  constexpr int NBA = BC / 16, NBB = BP / 16;
+  static_assert(NBB % NPW == 0, "every producer issues the same number of pixel DMAs per chunk");
+  constexpr int J = NBB / NPW;
+  constexpr int BUFW = 4 * BC, BUFX = 4 * BP;
+  constexpr int NPASS = epi_passes(BC, BP, WP, VP_REGB_EPI_BYTES);
+  constexpr int EPIB = (BP / NPASS) * (BC * 4 + 16) + (BP / NPASS) * 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nchunk = a.Kpad / KC;
+  uint4* wres = reinterpret_cast<uint4*>(smem);                 // [nchunk][BUFW]
+  uint4* ring = wres + nchunk * BUFW;                           // [NST][BUFX]
+  char* epi = reinterpret_cast<char*>(ring + NST * BUFX);       // staged epilogue buffer
+  int* ltap = reinterpret_cast<int*>(epi + ((EPIB + 15) & ~15));
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= NW;
+  const int cls = blockIdx.z;
+  const int P = a.N * a.Hg * a.Wg;
+  const int ntile = (P + BP - 1) / BP;
+  const int c_base = blockIdx.y * BC;
+  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
+  const int blkB0 = producer ? (1 << 20) : wave * TP;           // producers stage nothing in the epilogue
+  const int my_tiles = ((int)blockIdx.x < ntile) ? (ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  f32x4 acc[TC][TP];                                            // consumers only
+  __syncthreads();   // tap table visible
+
+  if (producer) {
+    const int pw = wave - NW;
+    const unsigned es = sizeof(T);
+    const T* x0 = reinterpret_cast<const T*>(a.x.ptr[0]);
+    const T* x1 = reinterpret_cast<const T*>(a.x.ptr[1]);
+    const int C0 = a.x.C[0], C1 = a.x.C[1];
+    __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
+    __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
+    __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(x1 ? (const void*)x1 : (const void*)x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * es));
+    const int r = lane >> 2, g = (lane & 3) ^ rb_swz(lane >> 2);
+    // the weight matrix, once: 16-row block b of chunk kc -> wres[kc][b]
+    {
+      const unsigned wstep = (unsigned)(a.wp_rows * KC * es);
+      for (int idx = pw; idx < nchunk * NBA; idx += NPW) {
+        const int kc = idx / NBA, b = idx - kc * NBA;
+        dma16_buf(rsW, (unsigned)(((c_base + b * 16 + r) * KC + g * E) * es), (unsigned)kc * wstep, wres + kc * BUFW + b * 64);
+      }
+    }
+    // pixel stream: units u = tile_i * nchunk + kc, issued NST-1 ahead of the consumers, across tile boundaries
+    int it_tile = -1, it_kc = nchunk;                           // issue cursor (next unit to issue)
+    int pn[J], pbh[J], pbw[J];
+    bool pok[J];
+    unsigned xso = 0, xvo[J];
+    int left = 0, tap = 0, src = 0;
+    bool use1 = false;
+    const int total = my_tiles * nchunk;
+    int issued = 0;
+    auto next_tile = [&]() {
+      ++it_tile; it_kc = 0;
+      const int p_base = ((int)blockIdx.x + it_tile * (int)gridDim.x) * BP;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int pidx = p_base + (pw + NPW * j) * 16 + r;
+        pok[j] = pidx < P;
+        const int hw = a.Hg * a.Wg;
+        const int pc = pok[j] ? pidx : 0;
+        const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
+        pn[j] = n * a.Hin; pbh[j] = q * a.sh; pbw[j] = (rem - q * a.Wg) * a.sw;
+      }
+      left = 0; tap = 0; src = 0;
+    };
+    auto open_segment = [&]() {
+      const bool tok = tap < a.ntaps;
+      const int tv = ltap[tok ? tap : 0];
+      const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
+      use1 = src != 0;
+      const int Cs = use1 ? C1 : C0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int ih = pbh[j] + dh, iw = pbw[j] + dw;
+        const bool ok = pok[j] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+        xvo[j] = ok ? (unsigned)((((pn[j] + ih) * a.Win + iw) * Cs + g * E) * es) : DMA_OOB;
+      }
+      left = Cs / KC;
+      xso = 0;
+      if (!use1 && C1 > 0) src = 1; else { src = 0; ++tap; }
+    };
+    auto issue = [&]() {
+      if (it_kc == nchunk) next_tile();
+      if (left == 0) open_segment();
+      uint4* lb = ring + (issued % NST) * BUFX;
+      const __amdgpu_buffer_rsrc_t rx = use1 ? rsX1 : rsX0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) dma16_buf(rx, xvo[j], xso, lb + (pw + NPW * j) * 64);
+      xso += KC * es;
+      --left; ++it_kc; ++issued;
+    };
+    for (int d = 0; d < NST - 1; ++d) if (issued < total) issue();
+    int u = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      for (int kc = 0; kc < nchunk; ++kc, ++u) {
+        if (u + NST - 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * J) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < total) issue();
+      }
+      const int p_base = ((int)blockIdx.x + ti * (int)gridDim.x) * BP;
+      staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, 0, blkB0, acc, epi, p_base / BP, cls);
+    }
+  } else {
+    int u = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kc = 0; kc < nchunk; ++kc, ++u) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        mma_chunk_rb<T, TC, TP, BC, BP>(wres + kc * BUFW, ring + (u % NST) * BUFX, 0, blkB0, lane, acc);
+      }
+      const int p_base = ((int)blockIdx.x + ti * (int)gridDim.x) * BP;
+      staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, 0, blkB0, acc, epi, p_base / BP, cls);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_cin8_kernel: the first layers of the three nets (3- and 6-channel images padded to 8: VGG conv1_1, discriminator layer_1,
 // encoder_1, encoder_fg_1; all 64 output channels, bf16).  K = taps x 8 is only 3-4 MFMA steps, so a tiled GEMM is all
 // prologue and epilogue; these layers are bound by writing the output (8 channels in, 64 out).  Direct form, no LDS:
@@ -1788,6 +1926,31 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
     static const bool fast_on = !getenv("VP_NO_FASTK");
     b.fastk = (fast_on && a.Cin % KCE == 0 && a.x.C[0] % KCE == 0 && a.x.C[1] % KCE == 0 && a.x.C[0] + a.x.C[1] == a.Cin &&
                xb0 < 0x70000000ull && xb1 < 0x70000000ull) ? 1 : 0;
+    // resident-weight persistent kernel for 64-channel outputs with K <= 576 (conv1_2 and the 64-channel backward-data passes)
+    if constexpr (BC == 64 && BP == 128) {
+      static const bool wsr_on = getenv("VP_WSR") != nullptr;   // opt-in: measured SLOWER (conv1_2 0.66 vs 0.53 ms) - one 12-wave block per CU
+                                                                // leaves 8 MFMAs per wave between barriers, too little to hide the ds_read latency
+      constexpr int KCE2 = 16 * 4 / (int)sizeof(T);
+      const int nchunk = a.Kpad / KCE2;
+      if (wsr_on && b.vec_epi && b.fastk && !b.bn_part && a.splitk == 1 && a.CoutPad == 64 && nchunk * 4096 <= 72 * 1024 && P >= 64 * 256) {
+        constexpr int WPR = 8, TPR = 2, NSTR = 3, BPR = WPR * TPR * 16;
+        constexpr int NPE = epi_passes(64, BPR, WPR, VP_REGB_EPI_BYTES);
+        const size_t epib = (size_t)(BPR / NPE) * (64 * 4 + 16) + (BPR / NPE) * 8;
+        const size_t sm = (size_t)nchunk * 4096 + (size_t)NSTR * 4 * BPR * 16 + ((epib + 15) & ~(size_t)15) + 64;
+        const int ntile = (P + BPR - 1) / BPR;
+        int gx = 256 / a.nclass;
+        if (gx > ntile) gx = ntile;
+        dim3 g2(gx, 1, a.nclass);
+        auto kern = igemm_wsr_kernel<T, WPR, TPR, NSTR, false>;   // (tiles are 256 pixels here: the plan's statistics indexing assumes 128)
+        static bool attr_done = false;
+        if (!attr_done) {
+          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, g2, dim3((WPR + 4) * 64), sm, st, b);
+        return hipGetLastError();
+      }
+    }
     // wave-specialised kernel, per tile shape (bit = launch_igemm cfg index): measured gains for 128x128 (cfg 0), 64x128 (cfg 1), 256x256 (cfg 7); 128x256 is faster without
     static const int ws_cfgs = getenv("VP_WS_CFG") ? atoi(getenv("VP_WS_CFG")) : ((1 << 0) | (1 << 1) | (1 << 7));
     constexpr int my_cfg = (BC == 128 && BP == 128) ? 0 : (BC == 64 && BP == 128) ? 1 : (BC == 128 && BP == 256) ? 6 : (BC == 256 && BP == 256) ? 7 :
