@@ -35,6 +35,8 @@ FWD_CASES = [
     (0, 3, 17, 19, 32, 64, 4, 1, 1, 0, 0, False),     # patch kernel: 4x4 s1 (D layer_4 geometry), odd sizes
     (0, 1, 32, 32, 256, 256, 3, 1, 1, 0, 2, False),   # patch kernel: many channel chunks
     (0, 1, 256, 256, 32, 256, 3, 1, 1, 0, 2, False),  # 65536 pixels x 256 channels: the 256x256 wave-specialised tile
+    (0, 2, 128, 128, 64, 128, 4, 2, 1, 0, 0, False),  # encoder_2 geometry: weight gradient on the 256x128 8-wave tile
+    (0, 8, 64, 64, 64, 256, 4, 2, 1, 0, 0, False),    # weight gradient on the 256x256 8-wave tile
 ]
 
 

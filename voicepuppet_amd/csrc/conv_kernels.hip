@@ -509,7 +509,12 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
     ct = logical % (int)gridDim.y; pt = logical / (int)gridDim.y;
   }
   const int p_base = pt * BP, c_base = ct * BC;
+#if VP_ABLATE & 4
+  // bandwidth experiment (results are garbage): a DMA instruction fetches 8 rows x 128 contiguous bytes instead of 16 x 64
+  const int r = lane >> 3, g = lane & 7;
+#else
   const int r = lane >> 2, g = (lane & 3) ^ rb_swz(lane >> 2);   // row in the 16-row block, k-piece fetched
+#endif
 
   if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
 
@@ -1633,13 +1638,14 @@ __device__ __forceinline__ void wg_stage_load_fast(const WgradArgs& a, const WgT
 }
 
 template <typename T, int WC, int WP, int TC, int TP, int KCH, bool PLAIN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(WC * WP * 64) void wgrad_kernel(const WgradArgs a) {
+  constexpr int NT = WC * WP * 64;                    // 4 waves, or 8 for the 256-row tiles
   constexpr int E = Elem<T>::E, KC = 4 * E;           // KC pixels per 64-byte chunk; KCH chunks per iteration
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
   constexpr int CH = 4 * (BC + BP);                   // slots of one chunk (A planes then B planes)
   constexpr int BUF = KCH * CH;
   constexpr int TA = KCH * 4 * BC / E, TB = KCH * 4 * BP / E;   // loader tasks per iteration
-  static_assert(TA + TB <= 256, "one task per thread");
+  static_assert(TA + TB <= NT, "one task per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
 
@@ -2108,8 +2114,16 @@ static hipError_t launch_wgrad_cfg(const WgradArgs& a, hipStream_t st) {
   constexpr int KCH = (sizeof(T) == 2) ? 2 : 1;
   const size_t smem = 2 * KCH * 4 * (BC + BP) * 16;
   const bool plain = a.zeros && !a.g.aff_a[0] && !a.g.aff_a[1] && a.g.act == ACT_NONE && !a.d.aff_a[0] && !a.d.aff_a[1] && a.d.act == ACT_NONE;
-  if (plain) hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP, KCH, true>), grid, dim3(256), smem, st, a);
-  else hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP, KCH, false>), grid, dim3(256), smem, st, a);
+  if (smem > 64 * 1024) {
+    static bool done[2] = {false, false};
+    if (!done[plain ? 1 : 0]) {
+      if (plain) (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WC, WP, TC, TP, KCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      else (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WC, WP, TC, TP, KCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      done[plain ? 1 : 0] = true;
+    }
+  }
+  if (plain) hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP, KCH, true>), grid, dim3(WC * WP * 64), smem, st, a);
+  else hipLaunchKernelGGL((wgrad_kernel<T, WC, WP, TC, TP, KCH, false>), grid, dim3(WC * WP * 64), smem, st, a);
   return hipGetLastError();
 }
 
@@ -2123,6 +2137,8 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
   switch (cfg) {
     case 0: e = launch_wgrad_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 rows x 128 cols
     case 1: e = launch_wgrad_cfg<T, 2, 2, 4, 2>(a, st); break;   // 128 rows x  64 cols
+    case 3: e = launch_wgrad_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 rows x 256 cols, 8 waves
+    case 4: e = launch_wgrad_cfg<T, 2, 4, 8, 2>(a, st); break;   // 256 rows x 128 cols, 8 waves
     case 2: e = launch_wgrad_cfg<T, 4, 1, 2, 1>(a, st); break;   // 128 rows x  16 cols
     default: return hipErrorInvalidValue;
   }
@@ -2143,7 +2159,7 @@ hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st
 }
 
 void wgrad_tile(int cfg, int* bm, int* bn) {
-  static const int t[3][2] = {{128, 128}, {128, 64}, {128, 16}};
+  static const int t[5][2] = {{128, 128}, {128, 64}, {128, 16}, {256, 256}, {256, 128}};
   *bm = t[cfg][0]; *bn = t[cfg][1];
 }
 

@@ -212,6 +212,16 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16) {
   }
   a.log2Gc = ilog2(a.Gc);
   p.cfg = (a.Dc % 128 == 0) ? 0 : (a.Dc % 64 == 0 ? 1 : 2);
+  {
+    // 256-row tiles (half the operand bytes per MAC; one 8-wave block per CU) where the M and N extents allow; bf16 only
+    static const int big = getenv("VP_WGBIG") ? atoi(getenv("VP_WGBIG")) : 0;   // opt-in: measured no faster (one 240-register block per CU)
+    const int M = a.ntaps * a.Gc;
+    const long long Pall = (long long)a.N * a.Hb * a.Wb;
+    if (is_bf16 && M % 256 == 0 && Pall >= 8192) {
+      if ((big & 1) && a.Dc % 256 == 0) p.cfg = 3;
+      else if ((big & 2) && a.Dc % 128 == 0) p.cfg = 4;
+    }
+  }
   int bm, bn;
   wgrad_tile(p.cfg, &bm, &bn);
   a.Mpad = round_up(a.ntaps * a.Gc, bm);
