@@ -516,7 +516,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     VP_HIP_CHECK(launch_wgrad(w, h->bf16, L.wg.cfg, st));
     float* db = n.grads + L.b_off;
     if (L.has_bn) {
-      VP_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)L.g.Cout * sizeof(float), st));   // analytically zero
+      // analytically zero: written by this layer's batch-norm backward (run_bn_bwd, dbias_zero) - no separate memset launch
     } else {
       BnArgs b;
       memset(&b, 0, sizeof(b));
@@ -566,7 +566,7 @@ static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample
   b.gamma = n.params + L.gamma_off;
   b.mu = t.bn.mu + (size_t)group0 * t.C; b.rstd = t.bn.rstd + (size_t)group0 * t.C;
   b.c1 = t.bn.c1; b.c2 = t.bn.c2;
-  if (want_dw) { b.dgamma = n.grads + L.gamma_off; b.dbeta = n.grads + L.beta_off; }
+  if (want_dw) { b.dgamma = n.grads + L.gamma_off; b.dbeta = n.grads + L.beta_off; b.dbias_zero = n.grads + L.b_off; }
   if (bn_small(b)) { VP_HIP_CHECK(launch_bn_small_bwd(b, h->bf16, st)); return VP_OK; }
   VP_HIP_CHECK(launch_bn_bwd(b, h->bf16, st));
   return VP_OK;

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnArgs a) {
     a.dgamma[c] = (float)dg + (a.accumulate ? a.dgamma[c] : 0.f);
     a.dbeta[c] = (float)db + (a.accumulate ? a.dbeta[c] : 0.f);
   }
+  if (lane == 0 && a.dbias_zero) a.dbias_zero[c] = 0.f;
 }
 
 // dy = gamma*rstd*(dz - c1 - zhat*c2)
@@ -348,6 +349,10 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const BnArgs a) {
       a.dgamma[c0 + e] = (float)dg[e] + (a.accumulate ? a.dgamma[c0 + e] : 0.f);
       a.dbeta[c0 + e] = (float)db[e] + (a.accumulate ? a.dbeta[c0 + e] : 0.f);
     }
+  }
+  if (threadIdx.x == 0 && a.dbias_zero) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) a.dbias_zero[c0 + e] = 0.f;
   }
 }
 

@@ -38,6 +38,7 @@ struct BnArgs {
   float* dbeta;
   int accumulate;           // dgamma/dbeta +=
   float eps;
+  float* dbias_zero;        // bwd: [C] bias gradient of the conv in front of this BN, set to its analytic value 0 (may be null)
 };
 
 struct PackInputsArgs {
