@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     if (pidx >= P) continue;
 #pragma unroll
     for (int tc = 0; tc < TC; ++tc) {
-      const int c0 = c_base + rowA0 + tc * 16 + 4 * (lane >> 4);
+      const int c0 = c_base + tile_chan0(a.rowperm, rowA0 / 16 + tc, lane >> 4);
       float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
       if (a.splitk > 1) {
         float* pp = a.partial + (((size_t)(cls * a.splitk + split) * P + pidx) * a.CoutPad + c0);
@@ -389,7 +389,7 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc) {
           const int row = (blkB0 + tp) * 16 + (lane & 15) - ps * RP;
-          const int ch = (blkA0 + tc) * 16 + 4 * (lane >> 4);
+          const int ch = tile_chan0(a.rowperm, blkA0 + tc, lane >> 4);
           *reinterpret_cast<f32x4*>(smem + row * PITCH + ch * 4) = acc[tc][tp];
           __builtin_amdgcn_sched_barrier(0);   // keep the AGPR->VGPR copies 4 at a time (register budget of the K loop)
         }
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
     if (pidx >= P) continue;
 #pragma unroll
     for (int tc = 0; tc < TC; ++tc) {
-      const int c0 = c_base + (blkA0 + tc) * 16 + 4 * (lane >> 4);
+      const int c0 = c_base + tile_chan0(a.rowperm, blkA0 + tc, lane >> 4);
       float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
       if (a.splitk > 1) {
         float* pp = a.partial + (((size_t)(cls * a.splitk + split) * P + pidx) * a.CoutPad + c0);
@@ -1204,7 +1204,8 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
     const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
     for (int idx = threadIdx.x; idx < S * 4 * 64; idx += 256) {
       const int l = idx & 63, t = (idx >> 6) & 3, s = idx >> 8;
-      const int row = (t >> 1) * 32 + 8 * ((l & 15) >> 2) + (t & 1) * 4 + (l & 3);
+      // with the global row permutation this is simply packed row 16t + i
+      const int row = a.rowperm ? t * 16 + (l & 15) : (t >> 1) * 32 + 8 * ((l & 15) >> 2) + (t & 1) * 4 + (l & 3);
       wfrag[idx] = *reinterpret_cast<const uint4*>(wp + ((size_t)s * a.wp_rows + row) * 32 + (l >> 4) * 8);
     }
     __syncthreads();

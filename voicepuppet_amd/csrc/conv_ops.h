@@ -90,6 +90,13 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   const int blocks = ((P + bp - 1) / bp) * (a.CoutPad / bc) * a.nclass;
   a.splitk = pick_igemm_splitk(blocks, a.Kpad / kc_elems(is_bf16));
   p.partial_bytes = a.splitk > 1 ? (size_t)a.nclass * a.splitk * P * a.CoutPad * sizeof(float) : 0;
+  // row permutation inside 64-row blocks (IgemmArgs::rowperm) where the tile's waves own whole 64-row blocks
+  {
+    static const bool perm_on = !getenv("VP_NO_ROWPERM");
+    const bool tc4 = p.cfg == 0 || p.cfg == 1 || p.cfg == 6 || p.cfg == 7 || p.cfg == 8;
+    a.rowperm = (perm_on && tc4 && rows % 64 == 0) ? 1 : 0;
+    p.pack.perm = a.rowperm;
+  }
   // packed rows are padded to the largest channel tile so the tile choice may vary with the batch
   a.wp_rows = round_up(rows, 128);
   p.pack.rows_pad = a.wp_rows;

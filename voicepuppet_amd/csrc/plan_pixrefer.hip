@@ -265,12 +265,19 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       L.need_bwd[s] = !ts.is_input || (n.groups == 3) || (n.l[0].g.ks == 3);
       if (L.need_bwd[s]) {
         L.bwd[s] = plan_bwd_data(L.g, L.w_off, row0, rows, rows_real, ts.C, bf16);
-        take(L.bwd[s]);
-        L.pk_bwd[s] = L.bwd[s].pack.dst_off;
         if (alt_batch > 0) {
           ConvGeomX g2 = L.g;
           g2.N = alt_batch;
           L.bwd_alt[s] = plan_bwd_data(g2, L.w_off, row0, rows, rows_real, ts.C, bf16);
+          // both batch sizes read ONE packed block: they must agree on its row order
+          if (L.bwd_alt[s].a.rowperm != L.bwd[s].a.rowperm) {
+            L.bwd[s].a.rowperm = L.bwd_alt[s].a.rowperm = 0;
+            L.bwd[s].pack.perm = L.bwd_alt[s].pack.perm = 0;
+          }
+        }
+        take(L.bwd[s]);
+        L.pk_bwd[s] = L.bwd[s].pack.dst_off;
+        if (alt_batch > 0) {
           L.bwd_alt[s].pack.dst_off = L.pk_bwd[s];
           if (L.bwd_alt[s].partial_bytes > *scratch_max) *scratch_max = L.bwd_alt[s].partial_bytes;
         }

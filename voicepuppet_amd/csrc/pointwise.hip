@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __res
 #pragma unroll
       for (int e = 0; e < E; ++e) if (c0 + e < d.C_real) v[e] = p[(size_t)e * d.s_ch];
     }
-    T* o = dst + (((size_t)cls * (d.Kpad / d.kc) + k0 / d.kc) * d.rows_pad + row) * d.kc + k0 % d.kc;
+    const int prow = d.perm ? perm_row(row) : row;
+    T* o = dst + (((size_t)cls * (d.Kpad / d.kc) + k0 / d.kc) * d.rows_pad + prow) * d.kc + k0 % d.kc;
     *reinterpret_cast<uint4*>(o) = Elem<T>::pack(v);
   }
 }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void pack_weights_one_kernel(const PackDesc d,
           if (cc == cls && tt == tap) { kh = d.kh[cc][tt]; kw = d.kw[cc][tt]; }
       v = src[(size_t)kh * d.s_kh + (size_t)kw * d.s_kw + (size_t)row * d.s_row + (size_t)c * d.s_ch];
     }
-    Elem<T>::st(dst + (((size_t)cls * (d.Kpad / d.kc) + k / d.kc) * d.rows_pad + row) * d.kc + k % d.kc, v);
+    Elem<T>::st(dst + (((size_t)cls * (d.Kpad / d.kc) + k / d.kc) * d.rows_pad + (d.perm ? perm_row(row) : row)) * d.kc + k % d.kc, v);
   }
 }
 

@@ -14,6 +14,7 @@ struct PackDesc {
   size_t dst_off;           // elements into the packed arena
   int nclass, rows_real, rows_pad, ntaps, C, C_real, Kpad;
   int kc;                   // elements per 64-byte K chunk; packed layout is [class][K chunk][row][kc]
+  int perm;                 // rows permuted inside every 64-row block (see IgemmArgs::rowperm): packed row of channel c = perm_row(c)
   int s_kh, s_kw, s_row, s_ch;
   int8_t kh[4][16];
   int8_t kw[4][16];

@@ -94,6 +94,17 @@ template <> __device__ __forceinline__ f32x4 mma16<bf16>(const uint4& a, const u
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, c, 0, 0, 0);
 }
 
+// Row permutation of the packed weights (IgemmArgs::rowperm).  Inside a 64-row block, channel c = 32*hi + 8*q + 4*lo + e sits in
+// MFMA tile t = 2*hi + lo at row 4q + e: after its four tiles a lane (accumulator rows 4q..4q+3) holds channels 8q..8q+7 and
+// 32+8q..32+8q+7 of its pixel - two 16-byte runs instead of four 8-byte ones.
+__host__ __device__ __forceinline__ int perm_row(int c) {
+  return (c & ~63) | ((((c >> 5) & 1) * 2 + ((c >> 2) & 1)) << 4) | (((c >> 3) & 3) << 2) | (c & 3);
+}
+// first of the 4 consecutive channels lane group q holds for 16-row tile T of a block (T counted from the block's first channel)
+__device__ __forceinline__ int tile_chan0(int rowperm, int T, int q) {
+  return rowperm ? ((T >> 2) << 6) + (((T >> 1) & 1) << 5) + (q << 3) + ((T & 1) << 2) : T * 16 + 4 * q;
+}
+
 // wave64 butterfly sum
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
