@@ -364,6 +364,81 @@ constexpr int epi_passes(int BC, int BP, int WP, int ring_bytes) {
   return WP;
 }
 
+// finish 8 consecutive channels c0..c0+7 of one output pixel (offset `off`, BN group in the low byte of `ot`): bias, activation,
+// act'(ref) product, accumulate, one 16-byte store (two for f32)
+template <typename T>
+__device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int c0, size_t off, float (&v)[8]) {
+  if (a.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += a.bias[c0 + e];
+  }
+  if (a.out_act != ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_apply(a.out_act, v[e]);
+  }
+  if (a.ref) {
+    float z[8];
+    const T* rp = reinterpret_cast<const T*>(a.ref) + off;
+    if (sizeof(T) == 2) Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(rp), z);
+    else {
+      Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[0], z);
+      Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[1], z + 4);
+    }
+    if (a.ref_a) {
+      const int goff = (int)(ot & 255) * a.Cout + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = fmaf(a.ref_a[goff + e], z[e], a.ref_b[goff + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= act_grad(a.ref_act, z[e]);
+  }
+  if (a.y_f32 || sizeof(T) == 4) {
+    float* yp = reinterpret_cast<float*>(a.Y) + off;
+    if (a.accumulate) {
+      const float4 e0 = reinterpret_cast<const float4*>(yp)[0], e1 = reinterpret_cast<const float4*>(yp)[1];
+      v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w; v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
+    }
+    reinterpret_cast<float4*>(yp)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(yp)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    bf16* yp = reinterpret_cast<bf16*>(a.Y) + off;
+    if (a.accumulate) {
+      float e[8];
+      Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(yp), e);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += e[k];
+    }
+    *reinterpret_cast<uint4*>(yp) = Elem<bf16>::pack(v);
+  }
+}
+
+// Direct epilogue (opt-in, IgemmArgs::direct_epi; measured slower than the staged one): with the permuted weight rows a lane's accumulators ARE two runs of 8 consecutive channels
+// per pixel and 64-row block, so the tile needs no LDS round trip: per pixel tile the lane finishes and stores its 16-byte runs
+// straight from registers (the four lanes of a pixel write 64 contiguous bytes per store).  Only the per-row output offsets come
+// from LDS (`otab`, BP entries computed cooperatively: they need two integer divisions each).
+template <typename T, int TC, int TP>
+__device__ __forceinline__ void direct_epilogue(const IgemmArgs& a, const long long* otab, int c_base, int blkA0, int blkB0,
+                                                f32x4 (&acc)[TC][TP]) {
+  static_assert(TC % 4 == 0, "whole 64-row blocks per wave");
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    const long long ot = otab[(blkB0 + tp) * 16 + (lane & 15)];
+    if (ot < 0) continue;
+#pragma unroll
+    for (int hb = 0; hb < TC / 4; ++hb)
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        const int c0 = c_base + ((blkA0 >> 2) + hb) * 64 + hi * 32 + 8 * q;
+        if (c0 >= a.Cout) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[hb * 4 + hi * 2][tp][e]; v[4 + e] = acc[hb * 4 + hi * 2 + 1][tp][e]; }
+        epi_store8<T>(a, ot, c0, (size_t)(ot >> 8) + c0, v);
+      }
+  }
+}
+
 // STATS (a batch-normalised layer): the epilogue also produces the layer's batch statistics.  While a pass's f32 tile sits in
 // LDS, thread t sums column (channel) t % BC over its share of the rows - of the values AS STORED, i.e. rounded to T - into two
 // registers; after the last pass the NT / BC threads of a channel fold through LDS and the block writes one [2][channels]
@@ -416,48 +491,7 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
         const float4 v1 = *reinterpret_cast<const float4*>(smem + p * PITCH + cgp * 32 + 16);
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
       }
-      if (a.bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += a.bias[c0 + e];
-      }
-      if (a.out_act != ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = act_apply(a.out_act, v[e]);
-      }
-      if (a.ref) {
-        float z[8];
-        const T* rp = reinterpret_cast<const T*>(a.ref) + off;
-        if (sizeof(T) == 2) Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(rp), z);
-        else {
-          Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[0], z);
-          Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[1], z + 4);
-        }
-        if (a.ref_a) {
-          const int goff = (int)(ot & 255) * a.Cout + c0;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) z[e] = fmaf(a.ref_a[goff + e], z[e], a.ref_b[goff + e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= act_grad(a.ref_act, z[e]);
-      }
-      if (a.y_f32 || sizeof(T) == 4) {
-        float* yp = reinterpret_cast<float*>(a.Y) + off;
-        if (a.accumulate) {
-          const float4 e0 = reinterpret_cast<const float4*>(yp)[0], e1 = reinterpret_cast<const float4*>(yp)[1];
-          v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w; v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
-        }
-        reinterpret_cast<float4*>(yp)[0] = make_float4(v[0], v[1], v[2], v[3]);
-        reinterpret_cast<float4*>(yp)[1] = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-        bf16* yp = reinterpret_cast<bf16*>(a.Y) + off;
-        if (a.accumulate) {
-          float e[8];
-          Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(yp), e);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += e[k];
-        }
-        *reinterpret_cast<uint4*>(yp) = Elem<bf16>::pack(v);
-      }
+      epi_store8<T>(a, ot, c0, off, v);
     }
   }
   if constexpr (STATS) {
@@ -683,6 +717,16 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
     return;
   }
 #endif
+  if constexpr (STAGED && !STATS && TC % 4 == 0) {
+    if (a.direct_epi) {
+      long long* otab = reinterpret_cast<long long*>(smem + NST * BUF * 16 + 64);     // behind the ring and the tap table
+      const LinearPix pix{a, cls, p_base, P};
+      for (int rrow = tid; rrow < BP; rrow += NT) otab[rrow] = pix(rrow);
+      __syncthreads();
+      direct_epilogue<T, TC, TP>(a, otab, c_base, blkA0, blkB0, acc);
+      return;
+    }
+  }
   if (STAGED) {
     constexpr int RINGB = NST * BUF * 16;
     constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
@@ -1034,6 +1078,16 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
   }
   return;
 #endif
+  if constexpr (!STATS && TC % 4 == 0) {
+    if (a.direct_epi) {
+      long long* otab = reinterpret_cast<long long*>(smem + NST * BUF * 16 + 64);
+      const LinearPix pix{a, cls, p_base, P};
+      for (int rrow = tid; rrow < BP; rrow += NT) otab[rrow] = pix(rrow);     // the producers are idle by now: they help
+      __syncthreads();
+      if (!producer) direct_epilogue<T, TC, TP>(a, otab, c_base, blkA0, blkB0, acc);
+      return;
+    }
+  }
   constexpr int RINGB = NST * BUF * 16;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
   staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
@@ -1941,7 +1995,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   constexpr bool RING = ((BC / 16) % NW == 0) && ((BP / 16) % NW == 0);
   constexpr int RINGB = (RING ? VP_RING : 2) * 4 * (BC + BP) * 16;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
-  size_t smem = RINGB + 64;
+  size_t smem = RINGB + 64 + BP * 8;      // ring, tap table, output-offset table of the direct epilogue
   const size_t smem_epi = (size_t)(BP / NPASS) * (BC * 4 + 16) + (BP / NPASS) * 8;
   if (smem_epi > smem) smem = smem_epi;
   const bool plain = a.zeros && !a.x.aff_a[0] && !a.x.aff_a[1] && a.x.act == ACT_NONE;
@@ -1949,6 +2003,9 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   if (plain) {
     IgemmArgs b = a;
     b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
+    // register-direct epilogue: measured SLOWER than the LDS-staged one (64-byte store segments vs 256-byte rows): opt-in
+    static const bool direct_on = getenv("VP_DIRECT_EPI") != nullptr;
+    b.direct_epi = (direct_on && a.rowperm && b.vec_epi) ? 1 : 0;
     // scalar-stepped loader: every 64-byte K chunk inside one tap and one source tensor, sources below the 2 GiB lane-offset range
     constexpr int KCE = 16 * 4 / (int)sizeof(T);
     const size_t xb0 = (size_t)a.N * a.Hin * a.Win * a.x.C[0] * sizeof(T), xb1 = (size_t)a.N * a.Hin * a.Win * a.x.C[1] * sizeof(T);
@@ -1989,7 +2046,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         constexpr int NSTW = (NW == 8) ? 4 : 4;
         constexpr int RB = NSTW * 4 * (BC + BP) * 16;
         constexpr int NPE = epi_passes(BC, BP, WP, RB);
-        size_t sm = RB + 64;
+        size_t sm = RB + 64 + BP * 8;
         const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
         if (se > sm) sm = se;
         if (b.bn_part) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, true>), grid, dim3((NW + 4) * 64), sm, st, b);
