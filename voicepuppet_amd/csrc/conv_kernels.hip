@@ -1094,6 +1094,160 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
 }
 
 // ------------------------------------------------------------------------------------------------
+// igemm_wsw_kernel: igemm_ws_kernel with 128-byte K chunks (IgemmArgs::wide).  A DMA instruction then fetches 8 rows x 128
+// contiguous bytes instead of 16 x 64 (the memory system prefers the wider segments: the loop without MFMAs runs 16 % faster on the
+// Cin >= 256 layers) and a stage carries two MFMA k-steps per barrier.  LDS image of a 16-row tile: row i, 16-byte piece p at slot
+// 8i + (p ^ ((i >> 1) & 7)): the DMA writes slot = lane inside each 8-row block, so lane (r = lane >> 3, x = lane & 7) fetches piece
+// x ^ f(row); every ds_read_b128 service group of the fragment reads (lane (i, g) takes piece 4s + g) lands on 16 distinct slots
+// mod 16.  Packed weights use 128-byte chunks too (PackDesc::kc = 64 elements); sources must be multiples of 64 channels.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WC, int WP, int TC, int TP, int NST, bool STATS = false>
+__global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_wsw_kernel(const IgemmArgs a) {
+  constexpr int E = Elem<T>::E, KCW = 8 * E;
+  constexpr int NPW = 4;
+  constexpr int NW = WC * WP, NT = (NW + NPW) * 64;
+  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
+  constexpr int NBA8 = BC / 8, NBB8 = BP / 8, NB8 = NBA8 + NBB8;
+  static_assert(NB8 % NPW == 0 && NBA8 % 2 == 0, "every producer issues the same number of DMAs per chunk");
+  constexpr int J = NB8 / NPW;
+  constexpr int BUF = 8 * (BC + BP);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  int* ltap = reinterpret_cast<int*>(lds + NST * BUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= NW;
+  const int cls = blockIdx.z;
+  const int P = a.N * a.Hg * a.Wg;
+  int pt, ct;
+  {
+    const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7, slot = id >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    ct = logical % (int)gridDim.y; pt = logical / (int)gridDim.y;
+  }
+  const int p_base = pt * BP, c_base = ct * BC;
+  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
+  const int nchunk = a.Kpad / KCW;
+  const int wc = producer ? 0 : wave / WP, wpi = producer ? 0 : wave - wc * WP;
+  const int blkA0 = wc * TC, blkB0 = producer ? (1 << 20) : wpi * TP;
+  f32x4 acc[TC][TP];
+  __syncthreads();   // tap table visible
+
+  if (producer) {
+    const int pw = wave - NW;
+    const unsigned es = sizeof(T);
+    const T* x0 = reinterpret_cast<const T*>(a.x.ptr[0]);
+    const T* x1 = reinterpret_cast<const T*>(a.x.ptr[1]);
+    const int C0 = a.x.C[0], C1 = a.x.C[1];
+    __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
+    __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
+    __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(x1 ? (const void*)x1 : (const void*)x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * es));
+    const int r = lane >> 3, x = lane & 7;
+    unsigned wvo[J], pce[J];
+    int pn[J], pbh[J], pbw[J];
+    bool pok[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int b = pw + NPW * j;                               // 8-row block: weights (b < NBA8) or pixels
+      const int row16 = (b & 1) * 8 + r;
+      pce[j] = (unsigned)((x ^ ((row16 >> 1) & 7)) * E * es);   // byte offset of the 16-byte piece this lane fetches
+      wvo[j] = (unsigned)((c_base + b * 8 + r) * KCW * es) + pce[j];
+      const int pidx = p_base + (b - NBA8) * 8 + r;
+      pok[j] = b >= NBA8 && pidx < P;
+      const int hw = a.Hg * a.Wg;
+      const int pc = pok[j] ? pidx : 0;
+      const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
+      pn[j] = n * a.Hin; pbh[j] = q * a.sh; pbw[j] = (rem - q * a.Wg) * a.sw;
+    }
+    const unsigned wstep = (unsigned)(a.wp_rows * KCW * es);
+    unsigned wso = 0, xso = 0;
+    int left = 0, tap = 0, src = 0;
+    bool use1 = false;
+    unsigned xvo[J];
+    auto open_segment = [&]() {
+      const bool tok = tap < a.ntaps;
+      const int tv = ltap[tok ? tap : 0];
+      const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
+      use1 = src != 0;
+      const int Cs = use1 ? C1 : C0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int ih = pbh[j] + dh, iw = pbw[j] + dw;
+        const bool ok = pok[j] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+        xvo[j] = ok ? (unsigned)(((pn[j] + ih) * a.Win + iw) * Cs * es) + pce[j] : DMA_OOB;
+      }
+      left = Cs / KCW;
+      xso = 0;
+      if (!use1 && C1 > 0) src = 1; else { src = 0; ++tap; }
+    };
+    auto issue = [&](int buf) {
+      uint4* la = lds + buf * BUF;
+      uint4* lb = la + 8 * BC;
+      if (left == 0) open_segment();
+      const __amdgpu_buffer_rsrc_t rx = use1 ? rsX1 : rsX0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int b = pw + NPW * j;
+        if (b < NBA8) dma16_buf(rsW, wvo[j], wso, la + b * 64);
+        else dma16_buf(rx, xvo[j], xso, lb + (b - NBA8) * 64);
+      }
+      wso += wstep;
+      xso += KCW * es;
+      --left;
+    };
+#pragma unroll
+    for (int d = 0; d < NST - 1; ++d) if (d < nchunk) issue(d);
+    int st = 0;
+    for (int kc = 0; kc < nchunk; ++kc) {
+      if (kc + NST - 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * J) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int stn = st == 0 ? NST - 1 : st - 1;
+      if (kc + NST - 1 < nchunk) issue(stn);
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+      for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int rowslot = i16 * 8, fsw = (i16 >> 1) & 7;
+    int st = 0;
+    for (int kc = 0; kc < nchunk; ++kc) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const uint4* la = lds + st * BUF;
+      const uint4* lb = la + 8 * BC;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int so = rowslot + ((4 * s + g4) ^ fsw);
+        uint4 fb[TP];
+#pragma unroll
+        for (int t = 0; t < TP; ++t) fb[t] = lb[(blkB0 + t) * 128 + so];
+#pragma unroll
+        for (int h = 0; h < TC; h += 4) {
+          uint4 fa[4];
+#pragma unroll
+          for (int t = 0; t < 4 && h + t < TC; ++t) fa[t] = la[(blkA0 + h + t) * 128 + so];
+#pragma unroll
+          for (int tc = 0; tc < 4 && h + tc < TC; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) acc[h + tc][tp] = mma16<T>(fa[tc], fb[tp], acc[h + tc][tp]);
+        }
+      }
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+  }
+  constexpr int RINGB = NST * BUF * 16;
+  constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
+  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
+}
+
+// ------------------------------------------------------------------------------------------------
 // igemm_wsr_kernel: 64-channel outputs with a short K (VGG conv1_2 and its backward, the backward-data of the 64-channel
 // stride-2 layers).  With a 64-row weight tile two thirds of what the tiled kernels move through the LDS-DMA path is pixels and one
 // third is the SAME 64 x K weight matrix, re-fetched by every block.  Here the whole matrix (K <= 576: <= 72 KB) is DMA'd into
@@ -2012,6 +2166,27 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
     static const bool fast_on = !getenv("VP_NO_FASTK");
     b.fastk = (fast_on && a.Cin % KCE == 0 && a.x.C[0] % KCE == 0 && a.x.C[1] % KCE == 0 && a.x.C[0] + a.x.C[1] == a.Cin &&
                xb0 < 0x70000000ull && xb1 < 0x70000000ull) ? 1 : 0;
+    // 128-byte K chunks (plan-time decision: the packed weights are laid out for it)
+    if (a.wide) {
+      if constexpr (((BC + BP) / 8) % 4 == 0 && NW <= 8 && TC % 4 == 0) {
+        if (b.vec_epi && a.splitk == 1) {
+          constexpr int NSTQ = (BC == 64 && BP == 128) ? 3 : 2;
+          constexpr int RB = NSTQ * 8 * (BC + BP) * 16;
+          constexpr int NPE = epi_passes(BC, BP, WP, RB);
+          size_t sm = RB + 64;
+          const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
+          if (se > sm) sm = se;
+          auto kern = b.bn_part ? igemm_wsw_kernel<T, WC, WP, TC, TP, NSTQ, true> : igemm_wsw_kernel<T, WC, WP, TC, TP, NSTQ, false>;
+          if (sm > 64 * 1024) {
+            static bool done[2] = {false, false};
+            if (!done[b.bn_part ? 1 : 0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done[b.bn_part ? 1 : 0] = true; }
+          }
+          hipLaunchKernelGGL(kern, grid, dim3((NW + 4) * 64), sm, st, b);
+          return hipGetLastError();
+        }
+      }
+      return hipErrorInvalidValue;     // a wide plan must run on the wide kernel
+    }
     // resident-weight persistent kernel for 64-channel outputs with K <= 576 (conv1_2 and the 64-channel backward-data passes)
     if constexpr (BC == 64 && BP == 128) {
       static const bool wsr_on = getenv("VP_WSR") != nullptr;   // opt-in: measured SLOWER (conv1_2 0.66 vs 0.53 ms) - one 12-wave block per CU

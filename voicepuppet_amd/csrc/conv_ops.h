@@ -105,6 +105,24 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   p.pack_elems = (size_t)a.nclass * a.wp_rows * a.Kpad;
 }
 
+// 128-byte K chunks (igemm_wsw_kernel): a plan-time decision because the packed weights are laid out for it, so everything the
+// launcher needs must hold here.  srcs_ok: every source tensor's channel count is a multiple of the wide chunk (64 bf16 / 32 f32).
+inline bool plan_wide_eligible(const IgemmPlan& p, int is_bf16, bool srcs_ok, bool prologue_free) {
+  static const int wide_cfgs = getenv("VP_WIDE_CFG") ? atoi(getenv("VP_WIDE_CFG")) : 0;
+  const IgemmArgs& a = p.a;
+  const int kcw = 2 * kc_elems(is_bf16);
+  return ((wide_cfgs >> p.cfg) & 1) && prologue_free && srcs_ok && a.splitk == 1 && a.Cout % 8 == 0 && a.Cin % kcw == 0;
+}
+inline void plan_make_wide(IgemmPlan& p, int is_bf16) {
+  IgemmArgs& a = p.a;
+  const int kcw = 2 * kc_elems(is_bf16);
+  a.wide = 1;
+  a.Kpad = round_up(a.ntaps * a.Cin, kcw);
+  p.pack.Kpad = a.Kpad;
+  p.pack.kc = kcw;
+  p.pack_elems = (size_t)a.nclass * a.wp_rows * a.Kpad;
+}
+
 // x (PixSrc, total channels g.Cin) -> y [N,Hout,Wout,ldY]
 inline IgemmPlan plan_fwd(const ConvGeomX& g, size_t w_off, int is_bf16) {
   IgemmPlan p;

@@ -251,6 +251,9 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       L.fwd.pack.s_row = L.g.Cin; L.fwd.pack.s_ch = 1; L.fwd.pack.s_kh = 0; L.fwd.pack.s_kw = 0;
     } else {
       L.fwd = plan_fwd(L.g, L.w_off, bf16);
+      bool srcs_ok = true;
+      for (int s = 0; s < L.nsrc; ++s) srcs_ok = srcs_ok && n.t[L.src[s]].C % (2 * kc_elems(bf16)) == 0;
+      if (plan_wide_eligible(L.fwd, bf16, srcs_ok, true) && !(L.g.Cout < 8)) plan_make_wide(L.fwd, bf16);
     }
     take(L.fwd);
     L.pk_fwd = L.fwd.pack.dst_off;
@@ -274,6 +277,12 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
             L.bwd[s].a.rowperm = L.bwd_alt[s].a.rowperm = 0;
             L.bwd[s].pack.perm = L.bwd_alt[s].pack.perm = 0;
           }
+        }
+        {
+          const bool dy_ok = L.g.CoutT % (2 * kc_elems(bf16)) == 0;
+          bool wide = plan_wide_eligible(L.bwd[s], bf16, dy_ok, true);
+          if (alt_batch > 0) wide = wide && plan_wide_eligible(L.bwd_alt[s], bf16, dy_ok, true);
+          if (wide) { plan_make_wide(L.bwd[s], bf16); if (alt_batch > 0) plan_make_wide(L.bwd_alt[s], bf16); }
         }
         take(L.bwd[s]);
         L.pk_bwd[s] = L.bwd[s].pack.dst_off;
