@@ -316,3 +316,27 @@ def test_full_width_bf16_against_f32_path():
   # whole-arena gradient agreement (bf16 mask-flip noise is per element; the arena norm of the difference stays small)
   assert rel(b["gd"], a["gd"]) < 0.15, rel(b["gd"], a["gd"])     # measured 8.0e-2
   assert rel(b["gg"], a["gg"]) < 0.05, rel(b["gg"], a["gg"])     # measured 1.0e-2
+
+
+@pytest.mark.gpu
+def test_step_parity_512_f32():
+  """BASELINE configs 4/5 geometry (512x512): D layer_4 is 63x63 and layer_5 62x62 (odd, non-power-of-two grids in the tap-GEMM
+  and the padded-grid weight-gradient walk), the bottleneck reaches 2x2.  f32 engine vs the float64 oracle, N = 1."""
+  ngf = ndf = 8
+  n, h = 1, 512
+  p = make_params(ngf, ndf, 5)
+  batch = synth(n, h, 13)
+  nodes = ref.forward_backward({k: v.astype(np.float64) for k, v in p.items()}, *[b.astype(np.float64) for b in batch], ngf=ngf, ndf=ndf)
+  eng = run_engine(dict(n=n, h=h, ngf=ngf, ndf=ndf, params=p, batch=batch), "f32")
+  got = eng.losses()
+  for k in ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss"):
+    assert abs(got[k] - nodes[k]) <= 1e-4 * abs(nodes[k]), (k, got[k], nodes[k])
+  assert gu.rel_l2(eng.tensor("Outputs_raw").cpu().numpy(), nodes["Outputs_raw"]) < 1e-3
+  for which, key, tol in ((1, "Discrim_grads", 1e-4), (0, "Gen_grads", 5e-3)):
+    grads = eng.get_params(which, src=eng.grads_d if which == 1 else eng.grads_g)
+    for name, g in grads.items():
+      r = nodes[key][name]
+      if np.all(r == 0):
+        assert np.all(g == 0), name
+      else:
+        assert gu.rel_l2(g, r) < tol, (name, gu.rel_l2(g, r))
