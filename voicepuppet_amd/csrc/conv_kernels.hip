@@ -1,16 +1,22 @@
-// Implicit-GEMM convolution family for gfx950 (MI355X), hand-written MFMA kernels.
+// Implicit-GEMM convolution family for gfx950 (MI355X), hand-written MFMA kernels (16x16x32 bf16 / 16x16x4 f32 tiles).
 //
-// One MFMA compute core (16x16 tiles, LDS "plane" layout, double-buffered register staging) is fed
-// by two loader kinds:
-//   * igemm_kernel : both operands are K-contiguous in memory (NHWC pixels gathered per tap, packed
-//                    weights [Cout][K]).  conv fwd, conv bwd-data, deconv fwd/bwd-data.
-//   * wgrad_kernel : the reduction runs over pixels, which is the strided dimension of NHWC, so each
-//                    thread transposes an ExE block in registers on the way into LDS.  bwd-weight.
-// LDS plane layout: a tile of ROWS rows x 64 bytes of K is stored as 4 planes (one per 16-byte
-// k-piece g), plane g = ROWS consecutive 16-byte slots.  MFMA lane (i = lane&15, g = lane>>4) reads
-// slot(row0+i) of plane g with one ds_read_b128: the 16 lanes of every b128 service group hit 16
-// distinct 16-byte slots of a 256-byte bank row, i.e. conflict-free reads; writers use 8-lane
-// contiguous (row loader) or XOR-swizzled (transposing loader) slots so writes are conflict-free too.
+// Kernels on the step path (DESIGN.md section 3 has the measurements and what bounds each):
+//   igemm_dma_kernel   conv fwd / bwd-data, deconv fwd / bwd-data: both operands HBM/L2 -> LDS by LDS-DMA (rb_swz image: coalesced 64-byte
+//                      segments, conflict-free ds_read_b128), 3-deep ring with counted vmcnt, one barrier per 64-byte K chunk,
+//                      scalar-stepped buffer-descriptor loader (fastk), staged LDS epilogue with 16-byte row stores (+ BN statistics)
+//   igemm_ws_kernel    the same GEMM with 4 producer waves issuing every DMA and consumer waves doing only ds_read + MFMA
+//   conv_cin8_kernel   8-channel (padded image) inputs: pieces straight from global memory, weights as LDS fragments, no operand tiles
+//   deconv_cout4_kernel  4-channel transposed conv: 4 parity classes x 4 channels = the 16 rows of one MFMA tile
+//   wgrad_kernel       bwd-weight: K = pixels (the strided NHWC dim): register loader + 8x8 transposes into LDS planes,
+//                      division-free padded-grid K walk, split-K slabs + deterministic reduces
+//   igemm_splitk_reduce_kernel, wgrad_reduce_kernel, wgrad_reduce_wave_kernel
+// Kept behind switches (correct, measured slower; see the table in DESIGN.md): igemm_kernel (register loader with the deferred-BN
+// prologue: single-op API only), igemm_regb_kernel, igemm_wsr_kernel, igemm_wsw_kernel, igemm_patch_kernel, direct_epilogue.
+//
+// LDS plane layout of the register-loader kernels (igemm_kernel, wgrad_kernel): a tile of ROWS rows x 64 bytes of K is stored as 4
+// planes (one per 16-byte k-piece g), plane g = ROWS consecutive 16-byte slots.  MFMA lane (i = lane&15, g = lane>>4) reads
+// slot(row0+i) of plane g with one ds_read_b128: the 16 lanes of every b128 service group hit 16 distinct 16-byte slots of a
+// 256-byte bank row (conflict-free); writers use 8-lane contiguous (row loader) or XOR-swizzled (transposing loader) slots.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

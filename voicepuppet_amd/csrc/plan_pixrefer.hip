@@ -3,13 +3,12 @@
 //
 // Follows voicepuppet/pixrefer/pixrefer.py:59-438 and vgg_simple.py:96-162.
 // Design (MI355X-first, not the TF graph):
-//   * every conv output is stored ONCE, raw (pre-BN); its consumers apply the producer's batch-norm
-//     affine and their own activation while loading (deferred normalisation), so "BN -> act" never
-//     costs a pass over HBM and the skip concats are virtual (two source pointers);
+//   * every conv output is stored ONCE, raw (pre-BN); act(scale*y + shift) is materialised once per activation kind the
+//     consumers need (the LDS-DMA loaders move plain bytes), the skip concats are virtual (two source pointers);
 //   * the three discriminator applications run as ONE batch of 3N with three batch-norm groups;
 //   * the VGG trunk runs on the 2N batch [real | fake]; its backward only on the fake half;
 //   * weights live as f32 masters in flat arenas (also the all-reduce buffers) and are re-packed
-//     into MFMA-friendly [Cout][K] blocks of the compute dtype once per parameter update.
+//     into chunk-major [class][K chunk][row][32 k] blocks of the compute dtype once per parameter update.
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
