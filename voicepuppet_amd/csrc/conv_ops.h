@@ -53,10 +53,13 @@ inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
 }
 
 inline int pick_igemm_splitk(int blocks, int nchunk) {
+  static const int target = getenv("VP_SPLITK_TARGET") ? atoi(getenv("VP_SPLITK_TARGET")) : 512;   // resident blocks aimed at.  (128 / 16 / 16 measured 11.77 vs 11.87 ms/step,
+  static const int cap = getenv("VP_SPLITK_MAX") ? atoi(getenv("VP_SPLITK_MAX")) : 32;         //  scripts/splitk_sweep.sh, but moves the mini-net bf16 d_din check from 1e-2 to 4e-2: not adopted)
+  static const int minchunk = getenv("VP_SPLITK_MINCHUNK") ? atoi(getenv("VP_SPLITK_MINCHUNK")) : 2;   // K chunks per split at least
   if (blocks >= 256) return 1;
-  int s = (512 + blocks - 1) / blocks;
-  if (s > nchunk / 2) s = nchunk / 2;
-  if (s > 32) s = 32;
+  int s = (target + blocks - 1) / blocks;
+  if (s > nchunk / minchunk) s = nchunk / minchunk;
+  if (s > cap) s = cap;
   return s < 1 ? 1 : s;
 }
 
