@@ -184,6 +184,30 @@ int vp_bfmnet_forward(vp_bfmnet_t* h, const float* ears, const float* mfccs, con
 int vp_bfmnet_tensor(vp_bfmnet_t* h, const char* name, void** ptr, int64_t shape[4]);
 
 /* ------------------------------------------------------------------------------------------------
+ * Single pointwise / audio ops of the two executors (the entry-point list of SURVEY.md 8b), for parity tests and reuse.
+ *   vp_maxpool2x2_*      slim max_pool2d 2x2/2 of vgg_simple.py:141,146 (NHWC).  bwd goes through the pool AND the ReLU of the conv
+ *                        that produced x (x is stored post-relu): the gradient lands on the FIRST maximum of a window if it is > 0
+ *   vp_composite_fwd     pixrefer.py:279-290 inference compositing: out4 = tanh(gen_out4), alpha = (out4[3]+1)/2,
+ *                        outputs = rgb*alpha + (2*targets-1)*(1-alpha), outputs_fg = rgb*alpha + alpha - 1   (all float32)
+ *   vp_gan_loss          pixrefer.py:334-347: logits [3][m] = D(real1) | D(real2) | D(fake) -> predict [2][m], losses[0] = Discrim_loss,
+ *                        losses[1] = Gen_loss_GAN, and the loss seeds w.r.t. the logits ([3][m][8] / [m][8] of dtype, channel 0)
+ *   vp_dwconv7x3_bn_act  tinynet.py depthwise [7,3] stride 1 'same' + folded BatchNorm (bias) + relu6; w [21][c], float32 NHWC
+ *   vp_maxpool_hw        tf.layers.max_pooling2d(k, s, 'same') (tinynet.py:178-190, bfmnet.py:35); output ceil(h/sh) x ceil(w/sw)
+ *   vp_gru_seq           tf.contrib.rnn.GRUCell under dynamic_rnn (bfmnet.py:53-61), 256 units: xg [b,t,512] / xc [b,t,256] are the input
+ *                        projections (+ biases), whg [256][512] / whc [256][256] the recurrent halves of gates / candidate kernels
+ * ---------------------------------------------------------------------------------------------- */
+int vp_maxpool2x2_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream);
+int vp_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int dtype, void* stream);
+int vp_composite_fwd(const float* gen_out4, const float* targets, float* out4, float* outputs, float* outputs_fg, int n, int hw,
+                     void* stream);
+int vp_gan_loss(const float* logits, void* seed_d, void* seed_g, float* predict, float* losses, int m, float gan_weight, int dtype,
+                void* stream);
+int vp_dwconv7x3_bn_act(const float* x, const float* w, const float* bias, float* y, int b, int h, int wd, int c, void* stream);
+int vp_maxpool_hw(const float* x, float* y, int b, int h, int w, int c, int kh, int kw, int sh, int sw, void* stream);
+int vp_gru_seq(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, int b, int t,
+               void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Rasteriser ("next" row): replaces mesh_core_cython.render_colors_core ->
  * _render_colors_core(image, face_mask, vertices, triangles, colors, depth_buffer, ntri, h, w, c)
  * (utils/cython/mesh_core.h:63, mesh_core.cpp:169-231; caller infer_bfmvid.py:100-108).  Same argument order and

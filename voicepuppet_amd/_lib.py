@@ -83,6 +83,14 @@ _SIGNATURES = {
     "vp_bfmnet_params_changed": (ctypes.c_int, [_P]),
     "vp_bfmnet_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "vp_bfmnet_tensor": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
+    "vp_maxpool2x2_fwd": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "vp_maxpool2x2_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "vp_composite_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
+    "vp_gan_loss": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_float, ctypes.c_int, _P]),
+    "vp_dwconv7x3_bn_act": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "vp_maxpool_hw": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, _P]),
+    "vp_gru_seq": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     "vp_bfm_reconstruct_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "vp_bfm_reconstruct": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "vp_render_colors_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),

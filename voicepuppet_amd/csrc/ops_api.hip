@@ -3,6 +3,7 @@
 
 #include "conv_ops.h"
 #include "errors.h"
+#include "audio_args.h"
 #include "launch.h"
 #include "vp_common.h"
 
@@ -157,6 +158,65 @@ int vp_bn_bwd(const void* y, const void* dz, void* dy, int pixels, int c, int dt
   b.gamma = gamma; b.mu = const_cast<float*>(mean); b.rstd = const_cast<float*>(rstd);
   b.dgamma = dgamma; b.dbeta = dbeta;
   VP_HIP_CHECK(launch_bn_bwd(b, dtype == VP_BF16, (hipStream_t)stream));
+  return VP_OK;
+}
+
+// ---- single pointwise / audio ops behind the step and BFMNet executors (SURVEY.md 8b list), exported for parity tests and reuse ----
+
+int vp_maxpool2x2_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream) {
+  const int e = dtype == VP_BF16 ? 8 : 4;
+  if (!x || !y || n < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || c < e || c % e) { set_err("vp_maxpool2x2_fwd: bad argument"); return VP_ERR_ARG; }
+  VP_HIP_CHECK(launch_maxpool_fwd(x, y, n, h, w, c, dtype == VP_BF16, (hipStream_t)stream));
+  return VP_OK;
+}
+
+int vp_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int dtype, void* stream) {
+  const int e = dtype == VP_BF16 ? 8 : 4;
+  if (!x || !dy || !dx || n < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || c < e || c % e) { set_err("vp_maxpool2x2_bwd: bad argument"); return VP_ERR_ARG; }
+  VP_HIP_CHECK(launch_maxpool_bwd(x, dy, dx, n, h, w, c, dtype == VP_BF16, (hipStream_t)stream));
+  return VP_OK;
+}
+
+int vp_composite_fwd(const float* gen_out4, const float* targets, float* out4, float* outputs, float* outputs_fg, int n, int hw,
+                     void* stream) {
+  if (!gen_out4 || !targets || !out4 || !outputs || !outputs_fg || n < 1 || hw < 1) { set_err("vp_composite_fwd: bad argument"); return VP_ERR_ARG; }
+  CompositeArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.y4 = gen_out4; ca.targets = targets; ca.o4 = out4; ca.outputs = outputs; ca.outputs_fg = outputs_fg; ca.N = n; ca.HW = hw; ca.train = 0;
+  VP_HIP_CHECK(launch_composite_fwd(ca, 0, (hipStream_t)stream));
+  return VP_OK;
+}
+
+int vp_gan_loss(const float* logits, void* seed_d, void* seed_g, float* predict, float* losses, int m, float gan_weight, int dtype,
+                void* stream) {
+  if (!logits || !seed_d || !seed_g || !predict || !losses || m < 1) { set_err("vp_gan_loss: bad argument"); return VP_ERR_ARG; }
+  GanLossArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.logits = logits; ga.dl_d = seed_d; ga.dl_g = seed_g; ga.predict = predict; ga.losses = losses; ga.M = m; ga.gan_weight = gan_weight;
+  VP_HIP_CHECK(launch_gan_loss(ga, dtype == VP_BF16, (hipStream_t)stream));
+  return VP_OK;
+}
+
+int vp_dwconv7x3_bn_act(const float* x, const float* w, const float* bias, float* y, int b, int h, int wd, int c, void* stream) {
+  if (!x || !w || !bias || !y || b < 1 || h < 1 || wd < 1 || c < 4 || (c & 3)) { set_err("vp_dwconv7x3_bn_act: bad argument"); return VP_ERR_ARG; }
+  VP_HIP_CHECK(launch_dwconv7x3(x, w, bias, y, b, h, wd, c, (hipStream_t)stream));
+  return VP_OK;
+}
+
+int vp_maxpool_hw(const float* x, float* y, int b, int h, int w, int c, int kh, int kw, int sh, int sw, void* stream) {
+  if (!x || !y || b < 1 || h < 1 || w < 1 || c < 4 || (c & 3) || kh < 1 || kw < 1 || sh < 1 || sw < 1) { set_err("vp_maxpool_hw: bad argument"); return VP_ERR_ARG; }
+  // TF 'same': out = ceil(in / stride); total pad = max((out-1)*stride + k - in, 0), the odd unit goes to the end
+  const int ho = (h + sh - 1) / sh, wo = (w + sw - 1) / sw;
+  const int ph = (ho - 1) * sh + kh - h, pw = (wo - 1) * sw + kw - w;
+  const int pt = ph > 0 ? ph / 2 : 0, pl = pw > 0 ? pw / 2 : 0;
+  VP_HIP_CHECK(launch_maxpool_same(x, y, b, h, w, c, kh, kw, sh, sw, pt, pl, ho, wo, (hipStream_t)stream));
+  return VP_OK;
+}
+
+int vp_gru_seq(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, int b, int t,
+               void* stream) {
+  if (!xg || !xc || !whg || !whc || !seq_len || !out || b < 1 || t < 1) { set_err("vp_gru_seq: bad argument"); return VP_ERR_ARG; }
+  VP_HIP_CHECK(launch_gru_seq(xg, xc, whg, whc, seq_len, out, b, t, (hipStream_t)stream));
   return VP_OK;
 }
 
