@@ -340,3 +340,37 @@ def test_step_parity_512_f32():
         assert np.all(g == 0), name
       else:
         assert gu.rel_l2(g, r) < tol, (name, gu.rel_l2(g, r))
+
+
+@pytest.mark.gpu
+def test_bucketed_train_step_through_rccl_single_rank():
+  """engine.train_step's data-parallel branch (staged generator backward, four asynchronous RCCL all-reduces on arena slices,
+  ncclAvg) on a one-rank NCCL group: must equal the plain step bit for bit.  (Multi-rank equality is covered on CPU with gloo.)"""
+  import os
+  import socket
+  import torch.distributed as dist
+  from voicepuppet_amd import parallel
+  if dist.is_initialized():
+    pytest.skip("a process group already exists in this process")
+  s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+  try:
+    ngf = 8
+    rng = np.random.default_rng(9)
+    batch = [torch.tensor(rng.uniform(size=(2, 256, 256, c)).astype(np.float32), device="cuda") for c in (6, 6, 3, 3)]
+    outs = []
+    real = parallel.allreduce_mean
+    for use_group in (False, True):
+      eng = PixReferEngine(2, 256, ngf, ngf, dtype="bf16", training=True)
+      eng.load_params(eng.random_params(2))
+      parallel.allreduce_mean = (lambda t, group=None, async_op=False: real(t, group, async_op, skip_single=False)) if use_group else real
+      for _ in range(2):
+        eng.train_step(*batch, lr=3e-4, group=dist.group.WORLD if use_group else None)
+      torch.cuda.synchronize()
+      outs.append((eng.params_g.clone(), eng.params_d.clone(), eng.grads_g.clone()))
+    parallel.allreduce_mean = real
+    for a, b in zip(*outs):
+      assert torch.equal(a, b)
+  finally:
+    dist.destroy_process_group()

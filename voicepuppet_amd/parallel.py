@@ -24,12 +24,13 @@ class _SumThenScale(object):
     return True
 
 
-def allreduce_mean(t, group=None, async_op=False):
-  """In-place mean of tensor `t` over the group; returns an object with .wait()."""
+def allreduce_mean(t, group=None, async_op=False, skip_single=True):
+  """In-place mean of tensor `t` over the group; returns an object with .wait().  A one-rank group is a no-op unless
+  skip_single=False (tests drive the real collective path on one GPU that way)."""
   if group is None and not dist.is_initialized():
     return _Done()
   world = dist.get_world_size(group)
-  if world == 1:
+  if world == 1 and skip_single:
     return _Done()
   if dist.get_backend(group) == "nccl":
     w = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=True)
