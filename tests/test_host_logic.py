@@ -146,3 +146,42 @@ def test_angle_sequence_follows_render_face_state_machine():
   d = np.diff(np.concatenate([[0.0], a[:, 1]]))
   assert np.allclose(np.abs(d), 0.005, atol=1e-6)
   assert a[:, 1].max() < 0.0401 and a[:, 1].min() > -0.0401 and (d < 0).any() and (d[20:] > 0).any()
+
+
+def test_product_path_never_imports_the_oracle():
+  """oracle/ is test infrastructure: the package and the launchers must not import it, bench.py only inside cpu_baseline()."""
+  import ast
+  import glob
+  import os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+  def oracle_imports(path):
+    tree = ast.parse(open(path).read())
+    hits = []
+    for node in ast.walk(tree):
+      if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+        hits.append(node.lineno)
+      if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+        hits.append(node.lineno)
+    return tree, hits
+
+  files = glob.glob(os.path.join(root, "voicepuppet_amd", "**", "*.py"), recursive=True) + \
+      glob.glob(os.path.join(root, "voicepuppet", "**", "*.py"), recursive=True)
+  assert files
+  for f in files:
+    assert not oracle_imports(f)[1], f
+  tree, hits = oracle_imports(os.path.join(root, "bench.py"))
+  fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline"][0]
+  assert hits and all(fn.lineno <= h <= fn.end_lineno for h in hits), hits
+
+
+def test_pmc_kernel_classifier():
+  import os
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+  import pmc_summary as p
+  assert p.classify("_ZN2vp16igemm_dma_kernelIDF16bLi2ELi4ELi4ELi4ELb1ELb0EEEvNS_9IgemmArgsE") == "igemm_bf16_128x256"
+  assert p.classify("_ZN2vp15igemm_ws_kernelIDF16bLi2ELi4ELi8ELi4ELi4ELb0EEEvNS_9IgemmArgsE") == "igemm_bf16_256x256"
+  assert p.classify("_ZN2vp12wgrad_kernelIDF16bLi2ELi2ELi4ELi4ELi2ELb1EEEvNS_9WgradArgsE") == "wgrad_bf16_128x128"
+  assert p.classify("void vp::conv_cin8_kernel<3>(vp::IgemmArgs, int, int)") == "cin8_bf16_64x16"
+  assert p.classify("vp::adam_tf_kernel(vp::AdamArgs)") is None
