@@ -291,11 +291,11 @@ def test_forward_is_hipgraph_capturable():
 
 
 @pytest.mark.gpu
-def test_full_width_bf16_against_f32_path():
+@pytest.mark.parametrize("n,h", [(4, 256), (1, 512)])
+def test_full_width_bf16_against_f32_path(n, h):
   """ngf = ndf = 64 (the benchmark width: 128x256 / 256x256 tiles, wave-specialised kernels, tap-GEMM, epilogue statistics all
   engage), batch 4: the bf16 step against the f32 step of the same engine - two different instantiations of every kernel.
   The oracle is far too slow at this width; the f32 path is pinned to it at the mini sizes above."""
-  n, h = 4, 256
   res = {}
   for dt in ("f32", "bf16"):
     eng = PixReferEngine(n, h, 64, 64, dtype=dt, training=True)
