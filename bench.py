@@ -1,46 +1,92 @@
 #!/usr/bin/env python
-"""Headline benchmark: PixReferNet G+D training step, frames/s at 256x256, bf16, per-GPU batch 32
-(BASELINE.json metric).  One process per GPU; `python bench.py --gpus N --steps K --warmup W`
-(N > 1: launched by torch.distributed.run, RCCL all-reduce of the G/D gradient arenas).
+"""Headline benchmark: PixReferNet G+D training step, frames/s at 256x256, bf16, GLOBAL batch 32 (BASELINE.json metric).
 
-A step = forward (G, composite, 3xD, VGG trunk on 2N, all losses) + both backward passes + all-reduce
-+ Adam(D) + Adam(G) on synthetic inputs already resident in HBM.  Weak scaling: the per-GPU batch is fixed.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(timed live with HIP events on the launch stream) and `cpu_baseline` (the numpy oracle, float32, timed on
-the host cores on a bounded sample of the same workload).
+  python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
+
+One process per GPU.  With N > 1 and no WORLD_SIZE in the environment this script itself starts the N ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, before anything here has touched
+the GPU) and relays rank 0's JSON line; under torch.distributed.run it is a rank (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* from the environment), over RCCL.
+
+A step = forward (G, composite, 3xD, VGG trunk on 2N, all losses) + both backward passes + all-reduce of the G/D gradient
+arenas + Adam(D) + Adam(G) on synthetic inputs already resident in HBM.
+  --scaling strong (default): the global batch stays 32, each rank runs 32/N samples;
+  --scaling weak: every rank runs 32 samples.  With N > 1 the other mode is measured too and reported under "other_scaling".
+Rank 0 prints ONE JSON line (contract in the task statement) with
+  roofline      the dominant kernel class, timed live with HIP events on the launch stream,
+  f32           (N = 1) the same step on the float32 path - the path that meets the 1e-3 pixel tolerance,
+  cpu_baseline  (N = 1) CPU restatements of the same step on the host cores: the numpy port (oracle/pixrefer_ref.py) and
+                a torch-CPU float32 (oneDNN) restatement as the TF-CPU proxy (oracle/pixrefer_torch.py), bounded samples.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 BF16_MFMA_PEAK = 2500.0   # TFLOP/s dense (MI355X_MICROARCH.md)
 F32_MFMA_PEAK = 157.3
 HBM_PEAK = 8000.0         # GB/s
+GFLOP_PER_FRAME_256 = 163.02
 
-# bench kernel name -> substring of the rocprofv3 kernel name (for the offline PMC traffic numbers)
+
+def parse_args(argv=None):
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+  ap.add_argument("--global-batch", type=int, default=32, help="strong scaling: samples per step over all ranks")
+  ap.add_argument("--batch", type=int, default=32, help="weak scaling: samples per step per rank")
+  ap.add_argument("--height", type=int, default=256)
+  ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-profile", action="store_true")
+  ap.add_argument("--no-f32", action="store_true")
+  ap.add_argument("--no-other-scaling", action="store_true")
+  return ap.parse_args(argv)
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def launch_ranks(args):
+  """Parent of an N-rank run: has not initialised the GPU (importing torch does not), starts the ranks as a child process
+  and exits with its code."""
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  env.setdefault("OMP_NUM_THREADS", "8")
+  return subprocess.call(cmd, env=env)
+
+
 def pmc_traffic(name):
-  """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+  """HBM bytes per launch of a kernel class from the newest committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE in
   separate runs of this same command, folded by scripts/pmc_summary.py; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM');
   launch-weighted over the template variants of the class; None when not collected."""
-  path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-  if not os.path.exists(path):
+  paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+  if not paths:
     return None
-  rows = [r for r in json.load(open(path)) if r.get("class") == name]
+  rows = [r for r in json.load(open(paths[-1])) if r.get("class") == name]
   n = sum(r["launches"] for r in rows)
   return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
 
 
 def synth_batch(n, h, seed, device):
   """U[0,1) box-blurred 5x5; soft-disc matte; fg = targets * masks packing."""
+  import torch
   g = torch.Generator(device="cpu").manual_seed(seed)
 
   def img(c):
@@ -56,49 +102,70 @@ def synth_batch(n, h, seed, device):
   return [t.to(device) for t in (inputs, fg, targets, masks)]
 
 
-def cpu_baseline(h, n, ngf, ndf, steps=2):
-  """The CPU restatement (oracle, float32, BLAS threads = all host cores) of the same G+D step: a bounded sample of `steps`
-  steps at batch `n` (the reference trains at batch 2, train_pixrefer.py:36)."""
-  from oracle import pixrefer_ref as ref
-  p = ref.init_params(ngf, ndf, seed=0, dtype=np.float32)
-  rng = np.random.default_rng(0)
-  batch = [rng.uniform(size=(n, h, h, c)).astype(np.float32) for c in (6, 6, 3, 3)]
-  st = ref.TrainState(p, ngf, ndf)
-  t0 = time.time()
-  for _ in range(steps):
-    st.step(*batch)
+# ---- CPU restatements (rank 0, N = 1 only; the oracle is the thing timed here, never the GPU path) ---------------------
+def _cpu_model():
+  try:
+    for line in open("/proc/cpuinfo"):
+      if line.startswith("model name"):
+        return line.split(":", 1)[1].strip()
+  except OSError:
+    pass
+  return "unknown"
+
+
+def _timed_steps(step, n, warm, steps, cap_s):
+  """`warm` untimed calls, then up to `steps` timed ones (stops early once `cap_s` seconds of timed work are spent, but never
+  before one step)."""
+  for _ in range(warm):
+    step()
+  done, t0 = 0, time.time()
+  while done < steps:
+    step()
+    done += 1
+    if time.time() - t0 > cap_s:
+      break
   dt = time.time() - t0
-  return {"value": n * steps / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-          "sample": "%d G+D steps (fwd+bwd+Adam) of the numpy float32 oracle at batch %d, %dx%d, ngf=ndf=%d: %.1f s" % (steps, n, h, h, ngf, dt)}
+  return {"frames_per_s": n * done / dt, "steps": done, "warmup": warm, "batch": n, "seconds": round(dt, 2)}
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=20)
-  ap.add_argument("--warmup", type=int, default=5)
-  ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
-  ap.add_argument("--height", type=int, default=256)
-  ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-  ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--no-profile", action="store_true")
-  args = ap.parse_args()
+def cpu_baseline(h, ngf=64, ndf=64, cap_s=25.0):
+  import numpy as np
+  import torch
+  from oracle import pixrefer_ref as ref
+  from oracle.pixrefer_torch import TorchGraph
+  cores = os.cpu_count()
+  torch.set_num_threads(cores)
+  rng = np.random.default_rng(0)
 
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  rank = int(os.environ.get("RANK", "0"))
-  local = int(os.environ.get("LOCAL_RANK", "0"))
-  torch.cuda.set_device(local)
-  device = torch.device("cuda", local)
-  group = None
-  if world > 1:
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=device)
-    group = dist.group.WORLD
+  def batch(n):
+    return [rng.uniform(size=(n, h, h, c)).astype(np.float32) for c in (6, 6, 3, 3)]
+  out = {}
+  p = ref.init_params(ngf, ndf, seed=0, dtype=np.float32)
+  b2 = batch(2)
+  st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf)
+  out["numpy_port_bs2"] = _timed_steps(lambda: st.step(*b2), 2, 1, 3, cap_s)
+  tg = TorchGraph(p, ngf, ndf, torch.float32)
+  out["torch_cpu_bs2"] = _timed_steps(lambda: tg.step(*b2), 2, 2, 3, cap_s)
+  b32 = batch(32)
+  tg = TorchGraph(p, ngf, ndf, torch.float32)
+  out["torch_cpu_bs32"] = _timed_steps(lambda: tg.step(*b32), 32, 1, 3, 2 * cap_s)
+  best = max(out, key=lambda k: out[k]["frames_per_s"])
+  return {"value": out[best]["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+          "label": "CPU restatement (TF-CPU proxy): TensorFlow exists on neither box",
+          "sample": "full G+D steps (fwd + both bwd + TF-Adam x2) at %dx%d, ngf=ndf=%d, float32, %d threads: numpy port "
+                    "(oracle/pixrefer_ref.py) at the reference's batch 2, torch-CPU/oneDNN restatement (oracle/pixrefer_torch.py) "
+                    "at batch 2 and 32, each after warm-up; value = the fastest of them (%s)" % (h, h, ngf, cores, best),
+          "runs": out}
 
+
+# ---- one measured configuration on this rank -----------------------------------------------------------------------------
+def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group, profile):
+  import torch
+  import torch.distributed as dist
   from voicepuppet_amd.engine import PixReferEngine
-  eng = PixReferEngine(args.batch, args.height, 64, 64, dtype=args.dtype, training=True)
+  eng = PixReferEngine(per_gpu, height, 64, 64, dtype=dtype, training=True)
   eng.load_params(eng.random_params(seed=0))   # the reference's initialisers, identical on every rank
-  batch = synth_batch(args.batch, args.height, 1000 + rank, device)
+  batch = synth_batch(per_gpu, height, 1000 + rank, device)
   lr = 3e-4
 
   def sync():
@@ -106,24 +173,23 @@ def main():
       dist.barrier(group=group)
     torch.cuda.synchronize()
 
-  for _ in range(args.warmup):
+  for _ in range(warmup):
     eng.train_step(*batch, lr=lr, group=group)
   sync()
   t0 = time.perf_counter()
-  for _ in range(args.steps):
+  for _ in range(steps):
     eng.train_step(*batch, lr=lr, group=group)
   sync()
   dt = time.perf_counter() - t0
-  tmax = torch.tensor([dt], device=device)
   if world > 1:
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-  dt = float(tmax.item())
-  ms = dt / args.steps * 1e3
-  fps = args.batch * world * args.steps / dt
-
-  roofline = None
-  kernels = None
-  if rank == 0 and not args.no_profile:
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+    dt = float(tmax.item())
+  ms = dt / steps * 1e3
+  res = {"ms_per_step": ms, "frames_per_s": per_gpu * world * steps / dt, "per_gpu_batch": per_gpu,
+         "global_batch": per_gpu * world,
+         "step_tflops": GFLOP_PER_FRAME_256 * 1e9 * (height / 256) ** 2 * per_gpu * world / (ms * 1e-3) / 1e12}
+  if profile and rank == 0:
     # per-kernel launch durations, HIP events on the launch stream, over a few extra steps (outside the timed region)
     eng.profile(True)
     psteps = 3
@@ -133,32 +199,89 @@ def main():
     recs = eng.profile_collect()
     eng.profile(False)
     recs.sort(key=lambda r: -r["ms"])
-    kernels = [{"name": r["name"], "calls_per_step": r["calls"] / psteps, "ms_per_step": r["ms"] / psteps,
-                "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0} for r in recs]
+    res["kernels"] = [{"name": r["name"], "calls_per_step": r["calls"] / psteps, "ms_per_step": r["ms"] / psteps,
+                       "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0} for r in recs]
+    res["launches_per_step"] = sum(r["calls"] for r in recs) / psteps
     top = recs[0]
-    peak = BF16_MFMA_PEAK if args.dtype == "bf16" else F32_MFMA_PEAK
+    peak = BF16_MFMA_PEAK if dtype == "bf16" else F32_MFMA_PEAK
     ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
-    roofline = {"kernel": top["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": pmc_traffic(top["name"]), "avg_launch_ms": top["ms"] / top["calls"],
-                "launches_per_step": top["calls"] / psteps, "algorithmic_bytes_per_launch": top["bytes"] / top["calls"],
-                "algorithmic_flops_per_launch": top["flops"] / top["calls"]}
+    res["roofline"] = {"kernel": top["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                       "frac": ach / peak, "traffic": pmc_traffic(top["name"]) if dtype == "bf16" else None,
+                       "avg_launch_ms": top["ms"] / top["calls"], "launches_per_step": top["calls"] / psteps,
+                       "algorithmic_bytes_per_launch": top["bytes"] / top["calls"],
+                       "algorithmic_flops_per_launch": top["flops"] / top["calls"]}
   if world > 1:
     dist.barrier(group=group)
+  del eng
+  torch.cuda.empty_cache()
+  return res
+
+
+def per_gpu_batch(args, scaling, world):
+  if scaling == "weak":
+    return args.batch
+  if args.global_batch % world:
+    raise SystemExit("strong scaling: global batch %d is not divisible by %d ranks" % (args.global_batch, world))
+  return args.global_batch // world
+
+
+def main():
+  args = parse_args()
+  if "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1:
+      sys.exit(launch_ranks(args))
+    world, rank, local = 1, 0, 0
+  else:
+    world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+      sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+      sys.exit(2)
+
+  import torch
+  import torch.distributed as dist
+  torch.cuda.set_device(local)
+  device = torch.device("cuda", local)
+  group = None
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=device)
+    group = dist.group.WORLD
+    assert dist.get_world_size() == args.gpus
+
+  main_res = run_config(per_gpu_batch(args, args.scaling, world), args.height, args.dtype, args.steps, args.warmup,
+                        rank, world, device, group, not args.no_profile)
+  other = None
+  if world > 1 and not args.no_other_scaling:
+    mode = "weak" if args.scaling == "strong" else "strong"
+    other = run_config(per_gpu_batch(args, mode, world), args.height, args.dtype, args.steps, args.warmup,
+                       rank, world, device, group, False)
+    other["scaling"] = mode
+  f32 = None
+  if world == 1 and args.dtype == "bf16" and not args.no_f32:
+    r = run_config(per_gpu_batch(args, args.scaling, world), args.height, "f32", max(3, args.steps // 4), 2,
+                   rank, world, device, group, not args.no_profile)
+    f32 = {"ms_per_step": r["ms_per_step"], "value": r["frames_per_s"], "unit": "frames/s", "step_tflops": r["step_tflops"],
+           "roofline": r.get("roofline"), "tolerance": "generator pixels <= 1e-3 rel-L2 vs the float64 oracle (tests/test_gpu_step.py)"}
 
   if rank == 0:
-    out = {"metric": "PixReferNet G+D step frames/sec @256x256 bs=32", "value": fps, "unit": "frames/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-           "data": "synthetic",
+    n, h = main_res["per_gpu_batch"], args.height
+    out = {"metric": "PixReferNet G+D step frames/sec @256x256 bs=32", "value": main_res["frames_per_s"], "unit": "frames/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "PixReferNet G+D training step (G + 3xD + VGG16-conv3_3 perceptual + TF-Adam x2), "
-                                  "%dx%d, ngf=ndf=64, per-GPU batch %d" % (args.height, args.height, args.batch),
-                      "global_batch": args.batch * world, "parallelism": "dp%d" % world},
-           "roofline": roofline, "kernels": kernels,
-           "step_tflops": 163.02e9 * (args.height / 256) ** 2 * args.batch * world / (ms * 1e-3) / 1e12}
+                                  "%dx%d, ngf=ndf=64, global batch %d = %d per GPU" % (h, h, n * world, n),
+                      "global_batch": n * world, "per_gpu_batch": n, "parallelism": "dp%d" % world},
+           "roofline": main_res.get("roofline"), "kernels": main_res.get("kernels"),
+           "launches_per_step": main_res.get("launches_per_step"), "step_tflops": main_res["step_tflops"]}
+    if other is not None:
+      out["other_scaling"] = other
+    if f32 is not None:
+      out["f32"] = f32
     if not args.no_cpu_baseline and world == 1:
-      out["cpu_baseline"] = cpu_baseline(args.height, 2, 64, 64)
-    print(json.dumps(out))
+      out["cpu_baseline"] = cpu_baseline(args.height)
+    print(json.dumps(out), flush=True)
   if world > 1:
+    dist.barrier(group=group)
     dist.destroy_process_group()
 
 

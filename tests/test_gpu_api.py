@@ -90,3 +90,50 @@ def test_infer_bfmvid_cli_end_to_end(tmp_path, monkeypatch):
   frames = sorted(os.listdir("output"))
   assert len(frames) == int(1 + 8000 / 640)            # pad_len video frames (infer_bfmvid.py:162)
   assert Image.open(os.path.join("output", "0.jpg")).size == (512, 512)
+
+
+def _train_net(batch=1, dtype="f32"):
+  from voicepuppet_amd.pixrefer.pixrefer import PixReferNet
+  from voicepuppet_amd.runtime import Placeholder, Session
+  net = PixReferNet(CFG)
+  p = net.params
+  p.batch_size = batch
+  p.ngf = p.ndf = 8
+  p.add_hparam("is_training", True)
+  p.sess = Session()
+  p.vgg_model_path = "allmodels/vgg_16.ckpt"
+  p.amd = dict(p.amd, dtype=dtype)
+  net.set_params(p)
+  ph = [Placeholder([batch, 256, 256, c], n) for c, n in ((6, "inputs"), (6, "fg"), (3, "targets"), (3, "masks"))]
+  nodes = net.build_train_op(*ph)
+  return net, p.sess, nodes, ph
+
+
+def test_save_restore_resumes_bit_for_bit(tmp_path):
+  """restore() brings back everything save() wrote (parameters, Adam m / v, update counters, global_step):
+  2 steps + save + restore into a fresh net + 2 steps == 4 uninterrupted steps, bit for bit."""
+  rng = np.random.default_rng(3)
+  batches = [[rng.uniform(size=(1, 256, 256, c)).astype(np.float32) for c in (6, 6, 3, 3)] for _ in range(4)]
+  net_a, sess_a, nodes_a, ph_a = _train_net()
+  init = {}
+  for w in (0, 1, 2):
+    init.update(net_a.engine.get_params(w))
+  for b in batches:
+    sess_a.run(nodes_a["Train_op"], feed_dict=dict(zip(ph_a, b)))
+  net_b, sess_b, nodes_b, ph_b = _train_net()
+  net_b.engine.load_params(init)
+  for b in batches[:2]:
+    sess_b.run(nodes_b["Train_op"], feed_dict=dict(zip(ph_b, b)))
+  path = net_b.save(str(tmp_path / "ck.npz"))
+  net_c, sess_c, nodes_c, ph_c = _train_net()
+  net_c.engine.load_params({k: v for k, v in init.items() if k.startswith("vgg_16")})
+  net_c.restore(path)
+  assert net_c.global_step == 4 and net_c.engine.t_g == 2 and net_c.engine.t_d == 2
+  for b in batches[2:]:
+    sess_c.run(nodes_c["Train_op"], feed_dict=dict(zip(ph_c, b)))
+  assert net_c.global_step == net_a.global_step == 8
+  for w in (0, 1):
+    assert torch.equal(net_a.engine.arena(w), net_c.engine.arena(w))
+    for k in (0, 1):
+      key = "g" if w == 0 else "d"
+      assert torch.equal(net_a.engine.adam[key][k], net_c.engine.adam[key][k])

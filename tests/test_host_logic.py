@@ -3,6 +3,7 @@ infer_bfmvid.py, and that libvp_hip.so loads and exports every symbol include/vp
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -185,3 +186,35 @@ def test_pmc_kernel_classifier():
   assert p.classify("_ZN2vp12wgrad_kernelIDF16bLi2ELi2ELi4ELi4ELi2ELb1EEEvNS_9WgradArgsE") == "wgrad_bf16_128x128"
   assert p.classify("void vp::conv_cin8_kernel<3>(vp::IgemmArgs, int, int)") == "cin8_bf16_64x16"
   assert p.classify("vp::adam_tf_kernel(vp::AdamArgs)") is None
+
+
+def test_bench_launches_n_ranks_as_a_child_before_touching_the_gpu(monkeypatch):
+  """`python bench.py --gpus 4` with no WORLD_SIZE: the parent builds a torch.distributed.run command for 4 ranks on
+  127.0.0.1 and relays the child's exit code; a rank whose WORLD_SIZE disagrees with --gpus refuses to run."""
+  import importlib
+  import subprocess
+  import bench
+  importlib.reload(bench)
+  seen = {}
+
+  def fake_call(cmd, env=None):
+    seen["cmd"], seen["env"] = cmd, env
+    return 7
+  monkeypatch.setattr(subprocess, "call", fake_call)
+  monkeypatch.delenv("WORLD_SIZE", raising=False)
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+  with pytest.raises(SystemExit) as e:
+    bench.main()
+  assert e.value.code == 7
+  cmd = seen["cmd"]
+  assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+  assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+  assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+  monkeypatch.setenv("WORLD_SIZE", "2")
+  with pytest.raises(SystemExit) as e:
+    bench.main()
+  assert e.value.code == 2
+  a = bench.parse_args(["--gpus", "8"])
+  assert a.scaling == "strong" and bench.per_gpu_batch(a, "strong", 8) == 4 and bench.per_gpu_batch(a, "weak", 8) == 32
+  with pytest.raises(SystemExit):
+    bench.per_gpu_batch(bench.parse_args(["--global-batch", "30"]), "strong", 8)

@@ -84,72 +84,9 @@ def test_manifest_parameter_counts():
 
 
 # ---------------------------------------------------------------------------
-# torch restatement of the whole training graph (float64 autograd)
+# torch restatement of the whole training graph (float64 autograd): oracle/pixrefer_torch.py
 # ---------------------------------------------------------------------------
-def _t(a):
-  return torch.tensor(a, dtype=torch.float64)
-
-
-def _nchw(a):
-  return _t(a).permute(0, 3, 1, 2)
-
-
-def _lrelu(x):
-  return 0.6 * x + 0.4 * x.abs()
-
-
-def torch_graph(p, inputs, fg_inputs, targets, masks, ngf, ndf):
-  tp = {k: _t(v).requires_grad_() for k, v in p.items()}
-  inp, fg, tgt = _nchw(inputs) * 2 - 1, _nchw(fg_inputs) * 2 - 1, _nchw(targets) * 2 - 1
-  msk = _nchw(masks)
-  acts = {'inputs': inp, 'fg_inputs': fg[:, :3]}
-  for scope, kind, srcs, cout, bn, pre in ref.generator_spec(ngf):
-    x = torch.cat([acts[s] for s in srcs], 1)
-    x = {None: lambda v: v, 'lrelu': _lrelu, 'relu': torch.relu}[pre](x)
-    if kind == 'conv':
-      y = F.conv2d(x, tp['generator/%s/conv2d/kernel' % scope].permute(3, 2, 0, 1).contiguous(), tp['generator/%s/conv2d/bias' % scope], 2, 1)
-    else:
-      y = F.conv_transpose2d(x, tp['generator/%s/conv2d_transpose/kernel' % scope].permute(3, 2, 0, 1).contiguous(),
-                             tp['generator/%s/conv2d_transpose/bias' % scope], 2, 1)
-    if bn:
-      y = F.batch_norm(y, None, None, tp['generator/%s/batch_normalization/gamma' % scope],
-                       tp['generator/%s/batch_normalization/beta' % scope], True, 0.1, 1e-5)
-    acts[scope] = y
-  out = torch.tanh(acts['decoder_1'])
-  rgb, alpha = out[:, :3], ((out[:, 3:] + 1) / 2).repeat(1, 3, 1, 1)
-  outputs = rgb * alpha + tgt * (1 - alpha)
-  outputs_fg = rgb * alpha + alpha - 1
-
-  def disc(a, b):
-    x = torch.cat([a, b], 1)
-    for scope, cout, stride, bn in ref.discriminator_spec(ndf):
-      x = F.conv2d(x, tp['discriminator/%s/conv2d/kernel' % scope].permute(3, 2, 0, 1).contiguous(), tp['discriminator/%s/conv2d/bias' % scope], stride, 1)
-      if bn:
-        x = F.batch_norm(x, None, None, tp['discriminator/%s/batch_normalization/gamma' % scope],
-                         tp['discriminator/%s/batch_normalization/beta' % scope], True, 0.1, 1e-5)
-      x = torch.sigmoid(x) if scope == 'layer_5' else _lrelu(x)
-    return x
-
-  p_real = (disc(inp[:, 3:], fg[:, 3:]) + disc(inp[:, :3], fg[:, :3])) / 2
-  p_fake = disc(inp[:, 3:], outputs_fg)
-  x = torch.cat([fg[:, 3:], outputs_fg], 0)
-  for item in ref.VGG_SPEC:
-    if item == 'pool':
-      x = F.max_pool2d(x, 2)
-    else:
-      x = torch.relu(F.conv2d(x, tp['vgg_16/%s/weights' % item[0]].permute(3, 2, 0, 1).contiguous(), tp['vgg_16/%s/biases' % item[0]], 1, 1))
-  n = inp.shape[0]
-  content = ((x[:n] - x[n:]) ** 2).sum() / 2 / x[:n].numel()
-  d_loss = (-(torch.log(p_real + 1e-12) * 2 + torch.log(1 - p_fake + 1e-12))).mean()
-  g_gan = (-torch.log(p_fake + 1e-12)).mean()
-  g_l1 = (tgt - outputs).abs().mean() + (msk - alpha).abs().mean() + content
-  g_loss = g_gan * 1.0 + g_l1 * 500.0
-  gn, dn = ref.param_manifest(ngf, ndf)
-  dgr = torch.autograd.grad(d_loss, [tp[k] for k, _ in dn], retain_graph=True)
-  ggr = torch.autograd.grad(g_loss, [tp[k] for k, _ in gn])
-  return dict(d_loss=d_loss.item(), g_gan=g_gan.item(), g_l1=g_l1.item(), content=content.item(),
-              outputs=outputs.detach().permute(0, 2, 3, 1).numpy(),
-              dgr={k: g.numpy() for (k, _), g in zip(dn, dgr)}, ggr={k: g.numpy() for (k, _), g in zip(gn, ggr)})
+from oracle.pixrefer_torch import TorchGraph, torch_graph  # noqa: E402
 
 
 def synth_batch(n, h, seed=0):
@@ -218,3 +155,21 @@ def test_finite_difference_generator_weight(mini):
     vals.append(ref.forward_backward(q, *batch, ngf=ngf, ndf=ndf, want_grads=False)['Gen_loss'])
   fd = (vals[0] - vals[1]) / (2 * h)
   assert nodes['Gen_grads'][k][idx] == pytest.approx(fd, rel=2e-4, abs=1e-9)
+
+
+def test_three_adam_steps_numpy_oracle_vs_torch_autograd(mini):
+  """TrainState.step (hand-written backward + TF-Adam) against autograd + the same update rule, 3 consecutive steps."""
+  p, batch, nodes, ngf, ndf = mini
+  st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf)
+  tg = TorchGraph(p, ngf, ndf)
+  for _ in range(3):
+    out = st.step(*batch)
+    got = tg.step(*batch)
+    assert out['Discrim_loss'] == pytest.approx(got['d_loss'], rel=1e-9)
+    assert out['Gen_loss'] == pytest.approx(got['g_loss'], rel=1e-9)
+  assert st.global_step == tg.global_step == 6
+  for k in tg.g_names + tg.d_names:
+    a, b = st.p[k], tg.tp[k].detach().numpy()
+    if k.endswith('bias') and np.all(a == p[k]):
+      continue   # analytically-zero bias gradients: the oracle pins them to 0, autograd leaves round-off that Adam's sign-like first steps amplify
+    assert np.abs(a - b).max() <= 1e-6 * max(np.abs(a).max(), 1e-3), k

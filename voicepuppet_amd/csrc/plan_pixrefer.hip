@@ -396,10 +396,15 @@ static void init_handle(vp_pixrefer* h, const vp_pixrefer_desc* d) {
   h->params_dirty = true;
 }
 
+// The batch-norm partial-sum workspace (bn_partial: 1024 chunk rows x 2 x 512 channels of f64) bounds the widths and the
+// number of batch-norm groups a plan may have: channels <= 8 * ngf <= 512, groups * chunks <= 1024.
 static bool valid_desc(const vp_pixrefer_desc* d) {
-  if (!d || d->batch < 1 || d->height < 256 || d->height % 256 != 0) return false;
-  if (d->ngf < 8 || (d->ngf & (d->ngf - 1)) || d->ndf < 8 || (d->ndf & (d->ndf - 1))) return false;
-  if (d->dtype != VP_F32 && d->dtype != VP_BF16) return false;
+  if (!d) { set_err("pixrefer descriptor: null"); return false; }
+  if (d->batch < 1 || d->height < 256 || d->height % 256 != 0) { set_err("pixrefer descriptor: batch %d / height %d (height must be a multiple of 256)", d->batch, d->height); return false; }
+  if (d->ngf < 8 || (d->ngf & (d->ngf - 1)) || d->ndf < 8 || (d->ndf & (d->ndf - 1))) { set_err("pixrefer descriptor: ngf %d / ndf %d must be powers of two >= 8", d->ngf, d->ndf); return false; }
+  if (d->ngf > 64 || d->ndf > 64) { set_err("pixrefer descriptor: ngf %d / ndf %d > 64 exceed the batch-norm workspace (512 channels)", d->ngf, d->ndf); return false; }
+  if (!d->training && d->per_sample_bn && d->batch > 1024) { set_err("pixrefer descriptor: per-sample batch-norm supports at most 1024 frames per call (got %d)", d->batch); return false; }
+  if (d->dtype != VP_F32 && d->dtype != VP_BF16) { set_err("pixrefer descriptor: dtype %d", d->dtype); return false; }
   return true;
 }
 

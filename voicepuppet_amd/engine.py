@@ -83,20 +83,39 @@ class PixReferEngine:
   def arena(self, which):
     return [self.params_g, self.params_d, self.params_vgg][which]
 
+  def fill_arena(self, dst, which, params, suffix=""):
+    """Write {tf_variable_name + suffix: array} into the flat f32 tensor `dst` laid out like arena `which`; names that are
+    absent keep their current value.  Returns the number of variables written."""
+    host = dst.cpu().numpy()
+    hit = 0
+    for name, off, shape in self.manifests[which]:
+      key = name + suffix
+      if key in params:
+        v = np.asarray(params[key], dtype=np.float32)
+        assert v.shape == shape, (key, v.shape, shape)
+        host[off:off + v.size] = v.reshape(-1)
+        hit += 1
+    dst.copy_(torch.from_numpy(host))
+    return hit
+
   def load_params(self, params):
     """params: {tf_variable_name: numpy array}; missing names keep their current value."""
     for which in range(3):
       a = self.arena(which)
-      if a is None:
-        continue
-      host = a.cpu().numpy()
-      for name, off, shape in self.manifests[which]:
-        if name in params:
-          v = np.asarray(params[name], dtype=np.float32)
-          assert v.shape == shape, (name, v.shape, shape)
-          host[off:off + v.size] = v.reshape(-1)
-      a.copy_(torch.from_numpy(host))
+      if a is not None:
+        self.fill_arena(a, which, params)
     self.params_changed()
+
+  def load_adam(self, params, t_g=None, t_d=None):
+    """Optimiser slots in tf.train.Saver naming: '<variable>/Adam' (m) and '<variable>/Adam_1' (v) (pixrefer.py:398,405);
+    t_* = the number of updates already applied (TF keeps beta1_power / beta2_power = beta ** (t + 1) instead)."""
+    for key, which in (("g", 0), ("d", 1)):
+      for idx, tag in ((0, "/Adam"), (1, "/Adam_1")):
+        self.fill_arena(self.adam[key][idx], which, params, tag)
+    if t_g is not None:
+      self.t_g = int(t_g)
+    if t_d is not None:
+      self.t_d = int(t_d)
 
   def random_params(self, seed=0):
     """The reference's variable initialisers (pixrefer.py:64,68,100-101: kernels N(0,0.02), gamma N(1,0.02), bias/beta 0)

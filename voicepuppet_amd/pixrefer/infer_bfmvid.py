@@ -199,8 +199,9 @@ def main(argv=None):
           Image.fromarray((np.clip(frames[k], 0, 1) * 255).astype(np.uint8)).save('output/{}.jpg'.format(i0 + k))
 
     if shutil.which('ffmpeg'):
-      cmd = 'ffmpeg -i output/%d.jpg -i ' + audio_file + ' -c:v libx264 -c:a aac -strict experimental -y output.mp4'
-      subprocess.call(cmd, shell=True)
+      # same command line as infer_bfmvid.py:245, as an argument vector (no shell: the audio path is user input)
+      subprocess.call(['ffmpeg', '-i', 'output/%d.jpg', '-i', audio_file, '-c:v', 'libx264', '-c:a', 'aac',
+                       '-strict', 'experimental', '-y', 'output.mp4'])
     else:
       logger.warning('ffmpeg not found: frames are in output/, no mp4 written')
 

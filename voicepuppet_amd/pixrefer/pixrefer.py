@@ -211,7 +211,13 @@ class PixReferNet(ModelBuilder):
     return path
 
   def restore(self, path):
+    """Everything save() wrote: parameters, both Adam slot sets, the two update counters and global_step - a resumed run
+    continues bit for bit (the reference's Saver(var_list=tf.global_variables()) keeps the slots and beta powers too)."""
     z = np.load(path)
-    self.engine.load_params({k: z[k] for k in z.files})
-    if 'global_step' in z.files:
-      self.global_step = int(z['global_step'])
+    d = {k: z[k] for k in z.files}
+    self.engine.load_params(d)
+    if self.engine.training:
+      t = d.get('adam_t')
+      self.engine.load_adam(d, t_g=None if t is None else t[0], t_d=None if t is None else t[1])
+    if 'global_step' in d:
+      self.global_step = int(d['global_step'])
