@@ -109,7 +109,8 @@ def _train_net(batch=1, dtype="f32"):
   return net, p.sess, nodes, ph
 
 
-def test_save_restore_resumes_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("fmt", ["npz", "tf"])
+def test_save_restore_resumes_bit_for_bit(tmp_path, fmt):
   """restore() brings back everything save() wrote (parameters, Adam m / v, update counters, global_step):
   2 steps + save + restore into a fresh net + 2 steps == 4 uninterrupted steps, bit for bit."""
   rng = np.random.default_rng(3)
@@ -124,7 +125,14 @@ def test_save_restore_resumes_bit_for_bit(tmp_path):
   net_b.engine.load_params(init)
   for b in batches[:2]:
     sess_b.run(nodes_b["Train_op"], feed_dict=dict(zip(ph_b, b)))
-  path = net_b.save(str(tmp_path / "ck.npz"))
+  path = net_b.save(str(tmp_path / ("ck.npz" if fmt == "npz" else "ckpt_pixrefer/pixrefernet-4")))
+  if fmt == "tf":   # a TensorFlow V2 checkpoint under the reference's names: Saver slots, beta powers, moving statistics
+    from voicepuppet_amd.utils import tf_checkpoint
+    names = tf_checkpoint.CheckpointReader(path).get_variable_to_shape_map()
+    for k in ("generator/encoder_1/conv2d/kernel", "generator/encoder_1/conv2d/kernel/Adam_1", "generator_train/beta2_power",
+              "discriminator/layer_2/batch_normalization/moving_variance", "vgg_16/conv3/conv3_3/weights", "global_step"):
+      assert k in names, k
+    path = str(tmp_path / "ckpt_pixrefer")      # restore through the directory's `checkpoint` state file
   net_c, sess_c, nodes_c, ph_c = _train_net()
   net_c.engine.load_params({k: v for k, v in init.items() if k.startswith("vgg_16")})
   net_c.restore(path)
@@ -137,3 +145,45 @@ def test_save_restore_resumes_bit_for_bit(tmp_path):
     for k in (0, 1):
       key = "g" if w == 0 else "d"
       assert torch.equal(net_a.engine.adam[key][k], net_c.engine.adam[key][k])
+
+
+def test_vgg_and_bfmnet_weights_come_from_tensorflow_checkpoints(tmp_path):
+  """init_variables() reads allmodels/vgg_16.ckpt itself (pixrefer.py:325-327); BFMNet.restore reads 'ckpt_bfmnet/bfmnet-65000'
+  (infer_bfmvid.py:217): TensorFlow bundles written here with known values, read back into the device arenas."""
+  from voicepuppet_amd.bfmnet.bfmnet import BFMNet
+  from voicepuppet_amd.pixrefer.pixrefer import PixReferNet
+  from voicepuppet_amd.runtime import Placeholder, Session
+  from voicepuppet_amd.utils import tf_checkpoint
+  from oracle import pixrefer_ref as ref
+  rng = np.random.default_rng(11)
+  vgg = {n: rng.normal(0, 0.05, s).astype(np.float32) for n, s in ref.vgg_manifest()}
+  vgg["vgg_16/fc8/biases"] = np.zeros(1000, np.float32)           # present in the real file, not used by the trunk
+  vpath = tf_checkpoint.write_checkpoint(str(tmp_path / "allmodels" / "vgg_16.ckpt"), vgg)
+  net = PixReferNet(CFG)
+  p = net.params
+  p.batch_size = 1
+  p.ngf = p.ndf = 8
+  p.add_hparam("is_training", True)
+  p.sess = Session()
+  p.vgg_model_path = vpath
+  p.amd = dict(p.amd, dtype="f32")
+  net.set_params(p)
+  net.build_train_op(*[Placeholder([1, 256, 256, c], "x") for c in (6, 6, 3, 3)])
+  got = net.engine.get_params(2)
+  for n, _ in ref.vgg_manifest():
+    np.testing.assert_array_equal(got[n], vgg[n])
+
+  bfm = BFMNet(CFG)
+  bp = bfm.params
+  bp.batch_size = 1
+  bfm.set_params(bp)
+  bfm.build_inference_op(Placeholder([1, 5, 1], "ears"), Placeholder([1, 25, 80], "mfccs"), Placeholder([1], "seq"))
+  w = {n: rng.normal(0, 0.05, s).astype(np.float32) for n, _, s in bfm.engine.manifest}
+  w["global_step"] = np.int64(65000)
+  bpath = tf_checkpoint.write_checkpoint(str(tmp_path / "ckpt_bfmnet" / "bfmnet-65000"), w)
+  bfm.restore(bpath)
+  back = bfm.engine.get_params()
+  for n, _, _ in bfm.engine.manifest:
+    np.testing.assert_array_equal(back[n], w[n])
+  with pytest.raises(KeyError):
+    bfm.restore(vpath)

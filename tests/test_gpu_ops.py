@@ -37,6 +37,8 @@ FWD_CASES = [
     (0, 1, 256, 256, 32, 256, 3, 1, 1, 0, 2, False),  # 65536 pixels x 256 channels: the 256x256 wave-specialised tile
     (0, 2, 128, 128, 64, 128, 4, 2, 1, 0, 0, False),  # encoder_2 geometry: weight gradient on the 256x128 8-wave tile
     (0, 8, 64, 64, 64, 256, 4, 2, 1, 0, 0, False),    # weight gradient on the 256x256 8-wave tile
+    (0, 2, 256, 256, 32, 128, 3, 1, 1, 0, 2, False),  # 131072 pixels x 128 channels: the 128x512 register-double-buffered tile
+    (0, 4, 256, 256, 64, 256, 4, 2, 1, 0, 0, False),  # 65536 pixels x 256 channels, 4x4 stride 2, K = 1024: 256x256 double-buffered tile
 ]
 
 

@@ -94,6 +94,10 @@ class BFMNetEngine:
     self.params.copy_(torch.from_numpy(host))
     _lib.check(self.L.vp_bfmnet_params_changed(self.h))
 
+  def get_params(self):
+    host = self.params.cpu().numpy()
+    return {name: host[off:off + int(np.prod(shape))].reshape(shape).copy() for name, off, shape in self.manifest}
+
   def forward(self, ears, mfccs, seq_len):
     B, T = self.desc.batch, self.desc.frames
     ears, mfccs = ears.contiguous(), mfccs.contiguous()

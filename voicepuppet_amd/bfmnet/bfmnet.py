@@ -82,8 +82,18 @@ class BFMNet(ModelBuilder):
     self.engine.load_params(p)
 
   def restore(self, path):
-    z = np.load(path)
-    self.engine.load_params({k: z[k] for k in z.files})
+    """tf.train.Saver().restore(sess, 'ckpt_bfmnet/bfmnet-65000') (infer_bfmnet.py:192, infer_bfmvid.py:217): a TensorFlow
+    checkpoint prefix / directory, or an .npz keyed by the same variable names."""
+    if path.endswith('.npz'):
+      z = np.load(path)
+      d = {k: z[k] for k in z.files}
+    else:
+      from ..utils import tf_checkpoint
+      d = tf_checkpoint.read_checkpoint(path, names=[n for n, _, _ in self.engine.manifest])
+    missing = [n for n, _, _ in self.engine.manifest if n not in d]
+    if missing:
+      raise KeyError('%s holds no %s (%d BFMNet variables missing)' % (path, missing[0], len(missing)))
+    self.engine.load_params(d)
 
   def execute(self, names, feed_dict):
     import torch

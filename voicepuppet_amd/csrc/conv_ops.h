@@ -39,6 +39,11 @@ inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
     if (rows % bc == 0) return force;
   }
   if (P >= 96) {
+    // 128-accumulator tiles on the register-double-buffered kernel (one 8-wave block per CU): VP_DBTILE bit 0: 256x256, bit 1: 128x512
+    static const int dbt = getenv("VP_DBTILE") ? atoi(getenv("VP_DBTILE")) : 0;
+    static const int dbk = getenv("VP_DB_MINK") ? atoi(getenv("VP_DB_MINK")) : 512;
+    if ((dbt & 1) && rows % 256 == 0 && P >= 256 * 256 && Kpad >= dbk) return 7;
+    if ((dbt & 2) && rows % 128 == 0 && rows % 256 != 0 && P >= 256 * 512 && Kpad >= dbk) return 9;
     // 256x256 runs one block per CU: its prologue / epilogue are exposed, only long K loops amortise them
     if ((big & 2) && rows % 256 == 0 && P >= 256 * 256 && Kpad >= 4096) return 7;
     if ((big & 1) && rows % 128 == 0 && P >= 256 * 512) return 6;
@@ -96,7 +101,7 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   // row permutation inside 64-row blocks (IgemmArgs::rowperm) where the tile's waves own whole 64-row blocks
   {
     static const bool perm_on = !getenv("VP_NO_ROWPERM");
-    const bool tc4 = p.cfg == 0 || p.cfg == 1 || p.cfg == 6 || p.cfg == 7 || p.cfg == 8;
+    const bool tc4 = p.cfg == 0 || p.cfg == 1 || p.cfg == 6 || p.cfg == 7 || p.cfg == 8 || p.cfg == 9;
     a.rowperm = (perm_on && tc4 && rows % 64 == 0) ? 1 : 0;
     p.pack.perm = a.rowperm;
   }

@@ -1,0 +1,222 @@
+// Device-side building blocks shared by the LDS-DMA implicit-GEMM kernels (conv_kernels.hip, conv_db.hip): the swizzled 16-row block
+// image, the LDS-DMA wrappers (flat and buffer-descriptor forms) and the staged LDS epilogue with 16-byte row stores.
+#pragma once
+#include "conv_args.h"
+#include "vp_common.h"
+
+namespace vp {
+
+// piece permutation of row i inside a 16-row block: LDS slot = i*4 + (g ^ rb_swz(i)).  The DMA writes
+// slot = lane, so lane (i = lane>>2, p = lane&3) fetches global piece p ^ rb_swz(i): four adjacent lanes
+// read one contiguous 64-byte segment (coalesced), and with h = (0,2,3,1) every ds_read_b128 service
+// group {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... lands on 16 distinct slots mod 16 (conflict-free).
+__device__ __forceinline__ int rb_swz(int i) { return (0x78 >> ((i >> 1) & 6)) & 3; }
+
+template <typename T, int TC, int TP, int BC, int BP>
+__device__ __forceinline__ void mma_chunk_rb(const uint4* __restrict__ ldsA, const uint4* __restrict__ ldsB,
+                                             int blkA0, int blkB0, int lane, f32x4 (&acc)[TC][TP]) {
+  const int i = lane & 15, g = lane >> 4;
+  const int so = i * 4 + (g ^ rb_swz(i));
+  uint4 fa[TC], fb[TP];
+#pragma unroll
+  for (int t = 0; t < TC; ++t) fa[t] = ldsA[(blkA0 + t) * 64 + so];
+#pragma unroll
+  for (int t = 0; t < TP; ++t) fb[t] = ldsB[(blkB0 + t) * 64 + so];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], fb[tp], acc[tc][tp]);
+}
+
+__device__ __forceinline__ void dma16(const void* src, uint4* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+// Buffer-descriptor form of the same DMA (buffer_load_dwordx4 ... offen lds): address = descriptor base + per-lane
+// 32-bit byte offset + SCALAR offset.  Two things the flat form cannot do: an out-of-range offset returns zeros
+// (padding pixels need no zero page and no per-lane select), and the per-chunk advance along K is a scalar add,
+// so a K chunk costs no vector ALU at all once the per-tap lane offsets exist.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x27000);
+}
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, uint4* lds_dst_wave_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, (int)voff, (int)soff, 0, 0);
+}
+constexpr unsigned DMA_OOB = 0xF0000000u;     // lane offset beyond every descriptor's range -> the DMA writes zeros
+
+// ------------------------------------------------------------------------------------------------
+// Staged epilogue: the accumulators go through LDS as an f32 [pixel][channel] tile, then every thread
+// finishes 8 consecutive channels of one pixel (bias, activation, act'(ref) product, accumulate) and
+// issues ONE 16-byte store; 16 adjacent lanes cover 256 contiguous bytes of an NHWC row.  (The direct
+// MFMA-layout store writes 8 bytes per lane at a 32-byte granularity and ran at ~0.4 TB/s.)
+// ------------------------------------------------------------------------------------------------
+// default tile-row -> output-pixel map: rows are consecutive pixels of the flattened (n, q, r) grid
+struct LinearPix {
+  const IgemmArgs& a; int cls, p_base, P;
+  __device__ __forceinline__ long long operator()(int row) const {
+    const int pidx = p_base + row;
+    if (pidx >= P) return -1;
+    const int hw = a.Hg * a.Wg;
+    const int n = pidx / hw, rem = pidx - n * hw, q = rem / a.Wg, r = rem - q * a.Wg;
+    long long off = (((long long)n * a.Hof + (q * a.os + a.o0h[cls])) * a.Wof + (r * a.os + a.o0w[cls])) * a.ldY;
+    return (off << 8) | (long long)(n / a.ref_group_n);   // BN group of the pixel in the low byte
+  }
+};
+
+// number of epilogue passes so that the f32 tile of one pass (+ its offset table) fits the ring's LDS; a wave's rows stay in one pass
+constexpr int epi_passes(int BC, int BP, int WP, int ring_bytes) {
+  for (int np = 1; np <= WP; np *= 2)
+    if ((BP / np) * (BC * 4 + 16) + (BP / np) * 8 <= ring_bytes) return np;
+  return WP;
+}
+
+// finish 8 consecutive channels c0..c0+7 of one output pixel (offset `off`, BN group in the low byte of `ot`): bias, activation,
+// act'(ref) product, accumulate, one 16-byte store (two for f32)
+template <typename T>
+__device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int c0, size_t off, float (&v)[8]) {
+  if (a.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += a.bias[c0 + e];
+  }
+  if (a.out_act != ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_apply(a.out_act, v[e]);
+  }
+  if (a.ref) {
+    float z[8];
+    const T* rp = reinterpret_cast<const T*>(a.ref) + off;
+    if (sizeof(T) == 2) Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(rp), z);
+    else {
+      Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[0], z);
+      Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[1], z + 4);
+    }
+    if (a.ref_a) {
+      const int goff = (int)(ot & 255) * a.Cout + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = fmaf(a.ref_a[goff + e], z[e], a.ref_b[goff + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= act_grad(a.ref_act, z[e]);
+  }
+  if (a.y_f32 || sizeof(T) == 4) {
+    float* yp = reinterpret_cast<float*>(a.Y) + off;
+    if (a.accumulate) {
+      const float4 e0 = reinterpret_cast<const float4*>(yp)[0], e1 = reinterpret_cast<const float4*>(yp)[1];
+      v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w; v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
+    }
+    reinterpret_cast<float4*>(yp)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(yp)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    bf16* yp = reinterpret_cast<bf16*>(a.Y) + off;
+    if (a.accumulate) {
+      float e[8];
+      Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(yp), e);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += e[k];
+    }
+    *reinterpret_cast<uint4*>(yp) = Elem<bf16>::pack(v);
+  }
+}
+
+// Direct epilogue (opt-in, IgemmArgs::direct_epi; measured slower than the staged one): with the permuted weight rows a lane's accumulators ARE two runs of 8 consecutive channels
+// per pixel and 64-row block, so the tile needs no LDS round trip: per pixel tile the lane finishes and stores its 16-byte runs
+// straight from registers (the four lanes of a pixel write 64 contiguous bytes per store).  Only the per-row output offsets come
+// from LDS (`otab`, BP entries computed cooperatively: they need two integer divisions each).
+template <typename T, int TC, int TP>
+__device__ __forceinline__ void direct_epilogue(const IgemmArgs& a, const long long* otab, int c_base, int blkA0, int blkB0,
+                                                f32x4 (&acc)[TC][TP]) {
+  static_assert(TC % 4 == 0, "whole 64-row blocks per wave");
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    const long long ot = otab[(blkB0 + tp) * 16 + (lane & 15)];
+    if (ot < 0) continue;
+#pragma unroll
+    for (int hb = 0; hb < TC / 4; ++hb)
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        const int c0 = c_base + ((blkA0 >> 2) + hb) * 64 + hi * 32 + 8 * q;
+        if (c0 >= a.Cout) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[hb * 4 + hi * 2][tp][e]; v[4 + e] = acc[hb * 4 + hi * 2 + 1][tp][e]; }
+        epi_store8<T>(a, ot, c0, (size_t)(ot >> 8) + c0, v);
+      }
+  }
+}
+
+// STATS (a batch-normalised layer): the epilogue also produces the layer's batch statistics.  While a pass's f32 tile sits in
+// LDS, thread t sums column (channel) t % BC over its share of the rows - of the values AS STORED, i.e. rounded to T - into two
+// registers; after the last pass the NT / BC threads of a channel fold through LDS and the block writes one [2][channels]
+// partial per pixel tile for bn_finalize_kernel.  The tensor is never re-read.
+template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, bool STATS = false, typename PixFn>
+__device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn& pixfn, int c_base, int blkA0, int blkB0,
+                                                f32x4 (&acc)[TC][TP], char* smem, int pt = 0, int cls = 0) {
+  constexpr int PITCH = BC * 4 + 16;                 // bytes per pixel row (+16: conflict-free b128 writes)
+  constexpr int CG = BC / 8;                         // 8-channel groups per row
+  constexpr int RP = BP / NPASS;                     // pixel rows staged per pass (keeps the tile inside the ring's LDS)
+  static_assert(RP % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
+  const int tid = threadIdx.x, lane = tid & 63;
+  long long* otab = reinterpret_cast<long long*>(smem + RP * PITCH);
+  static_assert(!STATS || NT % BC == 0, "column sums: whole thread groups per channel");
+  float bsum = 0.f, bsq = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();                                 // ring (pass 0) / previous pass's tile no longer needed
+    if (tid < RP) otab[tid] = pixfn(ps * RP + tid);
+    if (blkB0 * 16 >= ps * RP && blkB0 * 16 < (ps + 1) * RP) {
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+          const int row = (blkB0 + tp) * 16 + (lane & 15) - ps * RP;
+          const int ch = tile_chan0(a.rowperm, blkA0 + tc, lane >> 4);
+          *reinterpret_cast<f32x4*>(smem + row * PITCH + ch * 4) = acc[tc][tp];
+          __builtin_amdgcn_sched_barrier(0);   // keep the AGPR->VGPR copies 4 at a time (register budget of the K loop)
+        }
+    }
+    __syncthreads();
+    if constexpr (STATS) {
+      const int col = tid % BC;
+      for (int rr = tid / BC; rr < RP; rr += NT / BC) {
+        if (otab[rr] < 0) continue;
+        float x = *reinterpret_cast<const float*>(smem + rr * PITCH + col * 4);
+        if (sizeof(T) == 2) x = bf16_bits_to_f32(f32_to_bf16_bits(x));
+        bsum += x; bsq = fmaf(x, x, bsq);
+      }
+    }
+    for (int idx = tid; idx < RP * CG; idx += NT) {
+      const int p = idx / CG, cgp = idx - p * CG;
+      const long long ot = otab[p];
+      const int c0 = c_base + cgp * 8;
+      if (ot < 0 || c0 >= a.Cout) continue;
+      const size_t off = (size_t)(ot >> 8) + c0;
+      float v[8];
+      {
+        const float4 v0 = *reinterpret_cast<const float4*>(smem + p * PITCH + cgp * 32);
+        const float4 v1 = *reinterpret_cast<const float4*>(smem + p * PITCH + cgp * 32 + 16);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      }
+      epi_store8<T>(a, ot, c0, off, v);
+    }
+  }
+  if constexpr (STATS) {
+    __syncthreads();                                   // the staged tile is dead: reuse its LDS
+    float* red = reinterpret_cast<float*>(smem);       // [NT / BC][2][BC]
+    red[(tid / BC) * 2 * BC + tid % BC] = bsum;
+    red[(tid / BC) * 2 * BC + BC + tid % BC] = bsq;
+    __syncthreads();
+    if (tid < 2 * BC || (NT < 2 * BC && tid < BC)) {
+      const int grp = pt / a.bn_tpg, chunk = cls * a.bn_tpg + (pt - grp * a.bn_tpg);
+      for (int j = tid; j < 2 * BC; j += NT) {
+        float t = 0.f;
+        for (int m = 0; m < NT / BC; ++m) t += red[m * 2 * BC + j];
+        const int c = c_base + (j % BC);
+        if (c < a.Cout) a.bn_part[((size_t)(grp * a.bn_nchunk + chunk) * 2 + j / BC) * a.Cout + c] = (double)t;
+      }
+    }
+  }
+}
+
+}  // namespace vp

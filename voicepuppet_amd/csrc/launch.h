@@ -9,6 +9,7 @@ namespace vp {
 
 hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st);
 void igemm_tile(int cfg, int* bc, int* bp);
+hipError_t launch_igemm_db(const IgemmArgs& b, int is_bf16, int bc, dim3 grid, hipStream_t st);   // conv_db.hip
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
 void wgrad_tile(int cfg, int* bm, int* bn);
 

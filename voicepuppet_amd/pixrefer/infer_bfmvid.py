@@ -150,13 +150,16 @@ def main(argv=None):
     targets_holder = placeholder([None, img_size, img_size, 3])
     vid2vid_nodes = vid2vidnet.build_inference_op(inputs_holder, fg_inputs_holder, targets_holder)
 
-    for net, ckpt in ((bfmnet, 'ckpt_bfmnet/bfmnet-65000.npz'), (vid2vidnet, 'ckpt_pixrefer/pixrefernet-20000.npz')):
-      if os.path.exists(ckpt):
+    # infer_bfmvid.py:217-218: the TensorFlow checkpoints themselves (or .npz archives with the same variable names)
+    for net, ckpt in ((bfmnet, 'ckpt_bfmnet/bfmnet-65000'), (vid2vidnet, 'ckpt_pixrefer/pixrefernet-20000')):
+      if os.path.exists(ckpt + '.index'):
         net.restore(ckpt)
+      elif os.path.exists(ckpt + '.npz'):
+        net.restore(ckpt + '.npz')
       else:
         logger.warning('%s not found: running with randomly initialised weights', ckpt)
-    if not os.path.exists('ckpt_bfmnet/bfmnet-65000.npz'):
-      bfmnet.init_variables()
+        if net is bfmnet:
+          bfmnet.init_variables()
 
     ### Run inference
     bfm_coeff_seq = sess.run(bfmnet_nodes['BFMCoeffDecoder'])

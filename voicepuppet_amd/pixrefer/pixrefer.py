@@ -13,6 +13,7 @@ import numpy as np
 from ..builder import ModelBuilder
 from ..config.configure import YParams
 from ..runtime import Constant, IteratorNext, Node, Placeholder
+from ..utils import tf_checkpoint
 
 logger = logging.getLogger(__name__)
 
@@ -78,7 +79,7 @@ class PixReferNet(ModelBuilder):
   def init_variables(self, seed=None):
     """tf.variables_initializer of the non-VGG variables (train_pixrefer.py:89-92): kernels N(0,0.02),
     gamma N(1,0.02), bias/beta 0 (pixrefer.py:64,68,100-101); VGG restored from vgg_model_path when it is
-    an .npz of TF-named arrays (a TF checkpoint importer is a queued follow-up), else He-normal."""
+    the TensorFlow checkpoint itself (utils/tf_checkpoint.py) or an .npz of TF-named arrays, else He-normal."""
     rng = np.random.default_rng(seed)
     p = {}
     for which in (0, 1):
@@ -94,8 +95,10 @@ class PixReferNet(ModelBuilder):
     if self.engine.arena(2) is not None:
       path = getattr(self, 'vgg_model_path', None)
       npz = None
+      if tf_checkpoint.is_tf_checkpoint(path):   # the slim vgg_16.ckpt download itself (pixrefer.py:325-327), V1 file or V2 bundle
+        npz = tf_checkpoint.read_checkpoint(path, names=[name for name, _, _ in self.engine.manifests[2]])
       for cand in (path, (path or '') + '.npz'):
-        if cand and os.path.exists(cand) and cand.endswith('.npz'):
+        if npz is None and cand and os.path.exists(cand) and cand.endswith('.npz'):
           npz = np.load(cand)
       for name, _, shape in self.engine.manifests[2]:
         if npz is not None and name in npz:
@@ -196,8 +199,13 @@ class PixReferNet(ModelBuilder):
         raise KeyError(n)
     return out
 
-  # ---- checkpoints (own format: .npz keyed by the TF variable names) ------------------------------
-  def save(self, path):
+  # ---- checkpoints: TensorFlow Saver V2 bundles under the reference's variable names, or .npz with the same keys ----------
+  BETA2 = 0.999
+
+  def _state_dict(self):
+    """Everything tf.train.Saver(var_list=tf.global_variables()) holds for this graph (train_pixrefer.py:150): variables,
+    Adam slots '<var>/Adam', '<var>/Adam_1', the optimisers' beta powers, the never-updated batch-norm moving statistics,
+    the frozen vgg_16 trunk and global_step."""
     eng = self.engine
     d = {}
     for which in (0, 1):
@@ -205,19 +213,53 @@ class PixReferNet(ModelBuilder):
       for tag, idx in (('Adam', 0), ('Adam_1', 1)):
         st = eng.get_params(which, src=eng.adam['g' if which == 0 else 'd'][idx])
         d.update({'%s/%s' % (k, tag): v for k, v in st.items()})
-    d['global_step'] = np.int64(self.global_step)
-    d['adam_t'] = np.int64([eng.t_g, eng.t_d])
-    np.savez(path, **d)
-    return path
+      for name, _, shape in eng.manifests[which]:
+        if name.endswith('batch_normalization/gamma'):    # tf.layers.batch_normalization(training=True): moving stats stay at init
+          d[name[:-5] + 'moving_mean'] = np.zeros(shape, np.float32)
+          d[name[:-5] + 'moving_variance'] = np.ones(shape, np.float32)
+    d.update(eng.get_params(2))
+    for scope, t in (('discriminator_train', eng.t_d), ('generator_train', eng.t_g)):
+      d[scope + '/beta1_power'] = np.float32(self.beta1 ** (t + 1))
+      d[scope + '/beta2_power'] = np.float32(self.BETA2 ** (t + 1))
+    d['global_step'] = np.int32(self.global_step)
+    return d
+
+  def save(self, path):
+    """`path` ending in .npz: one numpy archive (+ the exact update counters); anything else: a TensorFlow V2 checkpoint prefix
+    ('ckpt_pixrefer/pixrefernet-20000' -> .index / .data-00000-of-00001 / checkpoint), as the reference's Saver writes."""
+    d = self._state_dict()
+    if path.endswith('.npz'):
+      d['adam_t'] = np.int64([self.engine.t_g, self.engine.t_d])
+      np.savez(path, **d)
+      return path
+    return tf_checkpoint.write_checkpoint(path, d)
 
   def restore(self, path):
-    """Everything save() wrote: parameters, both Adam slot sets, the two update counters and global_step - a resumed run
-    continues bit for bit (the reference's Saver(var_list=tf.global_variables()) keeps the slots and beta powers too)."""
-    z = np.load(path)
-    d = {k: z[k] for k in z.files}
+    """Everything save() wrote - parameters, both Adam slot sets, update counters, global_step - from an .npz, a TensorFlow
+    checkpoint prefix or a checkpoint directory (infer_bfmvid.py:218, train_pixrefer.py:96-99): a resumed run continues bit
+    for bit."""
+    if path.endswith('.npz'):
+      z = np.load(path)
+      d = {k: z[k] for k in z.files}
+    else:
+      d = tf_checkpoint.read_checkpoint(path)
+    missing = [n for n, _, _ in self.engine.manifests[0] if n not in d]
+    if missing:
+      raise KeyError('%s holds no %s (%d generator variables missing)' % (path, missing[0], len(missing)))
     self.engine.load_params(d)
     if self.engine.training:
-      t = d.get('adam_t')
-      self.engine.load_adam(d, t_g=None if t is None else t[0], t_d=None if t is None else t[1])
+      t_g = t_d = None
+      if 'adam_t' in d:
+        t_g, t_d = int(d['adam_t'][0]), int(d['adam_t'][1])
+      else:
+        def steps(cands):
+          for b1, b2 in cands:
+            if b2 in d:
+              return tf_checkpoint.adam_steps_from_beta_powers(d.get(b1, 0.0), d[b2], self.beta1, self.BETA2)
+          return None
+        # discriminator optimiser is created first (pixrefer.py:398,405): its non-slot variables carry no numeric suffix
+        t_d = steps([('discriminator_train/beta1_power', 'discriminator_train/beta2_power'), ('beta1_power', 'beta2_power')])
+        t_g = steps([('generator_train/beta1_power', 'generator_train/beta2_power'), ('beta1_power_1', 'beta2_power_1')])
+      self.engine.load_adam(d, t_g=t_g, t_d=t_d)
     if 'global_step' in d:
       self.global_step = int(d['global_step'])

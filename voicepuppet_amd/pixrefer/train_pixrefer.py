@@ -121,10 +121,14 @@ def main(argv=None):
 
     ### Save checkpoint
     if (global_step % params.save_step == 0 and rank == 0):
-      path = vid2vidnet.save(os.path.join(params.save_dir, '%s-%d.npz' % (params.save_name, global_step)))
+      # train_pixrefer.py:150: Saver(max_to_keep).save(sess, 'ckpt_pixrefer/pixrefernet', global_step) - a TensorFlow V2 checkpoint
+      path = vid2vidnet.save(os.path.join(params.save_dir, '%s-%d' % (params.save_name, global_step)))
       saved.append(path)
       while len(saved) > params.max_to_keep:
-        os.remove(saved.pop(0))
+        old = saved.pop(0)
+        for suffix in ('.index', '.data-00000-of-00001'):
+          if os.path.exists(old + suffix):
+            os.remove(old + suffix)
   if world > 1:
     dist.destroy_process_group()
 
