@@ -7,6 +7,9 @@
   ops.npz            toy-size conv / deconv / batch-norm / pool forward+backward results of the float64 oracle
   mini_step.npz      one G+D step of a mini PixReferNet (ngf=ndf=8, N=1, 256x256) on sample22: losses, output
                      crop, per-tensor gradient norms, post-Adam parameter checksums
+  full_width.npz     config 1 proper: the generator forward on sample22 at ngf = 64; and three consecutive full G+D steps at
+                     ngf = ndf = 64, N = 1 (losses per step, step-1 output, per-tensor gradient norms, post-step parameter sums)
+                     (`python tests/golden/make_golden.py full`: ~10 minutes)
   logmel.npz         log-mel of a seeded 4096-sample chirp+noise, and the 257x80 mel matrix
   bfmnet.npz         BFMNet coefficients for a seeded 5-frame clip (parameters regenerated from the seed)
   bfm_recon.npz      outputs of the REFERENCE's own utils/reconstruct_mesh.py (pure numpy, imported from /root/reference here)
@@ -95,6 +98,40 @@ def mini_step(panels, bg):
   np.savez_compressed(os.path.join(HERE, "mini_step.npz"), **d)
 
 
+def full_width(panels, bg):
+  """BASELINE config 1 proper (generator forward on sample/22.jpg at ngf = 64) and THREE consecutive full G+D steps at the
+  benchmark width (ngf = ndf = 64, N = 1, 256x256) from the float64 oracle.  The parameters are float32 draws (what the device
+  holds) promoted to float64, regenerated from the seed by the tests; ~10 minutes of numpy on 8 cores."""
+  ngf = ndf = 64
+  seed = 9
+  frame, face3d, matte = [p.astype(np.float64) / 255.0 for p in panels]
+  inputs = np.concatenate([face3d, face3d], axis=-1)[None]
+  fg = np.concatenate([frame * matte, frame * matte], axis=-1)[None]
+  targets, masks = frame[None], matte[None]
+  p = {k: v.astype(np.float64) for k, v in ref.init_params(ngf, ndf, seed=seed, dtype=np.float32).items()}
+  inf = ref.inference(p, inputs, fg[..., :3], bg[None].astype(np.float64) / 255.0, ngf)
+  d = {"seed": seed, "ngf": ngf, "Infer_Outputs": inf["Outputs"][0].astype(np.float32), "Infer_Alphas_mean": np.float64(inf["Alphas"].mean())}
+  st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf)
+  keys = ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss")
+  losses, sums, norms2 = [], [], []
+  names = None
+  for step in range(3):
+    nodes = st.step(inputs, fg, targets, masks)
+    if names is None:
+      names = sorted(nodes["Gen_grads"]) + sorted(nodes["Discrim_grads"])
+      d["grad_names"] = np.array(names)
+      d["Outputs"] = nodes["Outputs"][0].astype(np.float32)
+      d["grad_norms"] = np.array([np.linalg.norm(nodes["Gen_grads" if n.startswith("generator") else "Discrim_grads"][n]) for n in names])
+    losses.append([nodes[k] for k in keys])
+    sums.append([st.p[n].sum() for n in names])
+    norms2.append([np.linalg.norm(st.p[n] - p[n]) for n in names])     # size of the update since the start
+    print("full-width step", step, dict(zip(keys, losses[-1])), flush=True)
+  d["losses"] = np.array(losses)
+  d["param_sums_after"] = np.array(sums)
+  d["update_norms_after"] = np.array(norms2)
+  np.savez_compressed(os.path.join(HERE, "full_width.npz"), **d)
+
+
 def audio():
   rng = np.random.default_rng(11)
   t = np.arange(4096) / 16000.0
@@ -152,6 +189,9 @@ def bfm_recon():
 
 
 if __name__ == "__main__":
+  if sys.argv[1:] == ["full"]:
+    full_width(*sample22())
+    sys.exit(0)
   if sys.argv[1:] == ["raster"]:
     raster()
     bfm_recon()

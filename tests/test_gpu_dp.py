@@ -1,0 +1,101 @@
+"""-m gpu: data parallel on ENGINE gradients.  Two processes (one rank each, both on the one GPU of the test box, exchanging over
+gloo - RCCL refuses two ranks on one device) run engine.train_step with the bucketed, overlapped all-reduce of the real gradient
+arenas; the result must equal, bit for bit, one process that runs the two micro-batches one after the other, averages the two
+gradient sets and applies the same Adam updates (batch-norm statistics stay per replica: SURVEY.md 8e)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+NGF, STEPS, LR = 8, 2, 3e-4
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _setup(n):
+  from oracle import pixrefer_ref as ref
+  params = ref.init_params(NGF, NGF, seed=3, dtype=np.float32)
+  rng = np.random.default_rng(11)
+  batch = [rng.uniform(size=(n, 256, 256, c)).astype(np.float32) for c in (6, 6, 3, 3)]
+  return params, batch
+
+
+def _worker(rank, world, port, out_dir):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  torch.cuda.set_device(0)
+  from voicepuppet_amd.engine import PixReferEngine
+  from voicepuppet_amd.parallel import shard_batch
+  params, batch = _setup(world)
+  lo, hi = shard_batch(world, rank, world)
+  mine = [torch.tensor(b[lo:hi], device="cuda") for b in batch]
+  eng = PixReferEngine(hi - lo, 256, NGF, NGF, dtype="f32", training=True)
+  eng.load_params(params)
+  for _ in range(STEPS):
+    eng.train_step(*mine, lr=LR, group=dist.group.WORLD)
+  torch.cuda.synchronize()
+  torch.save({"g": eng.params_g.cpu(), "d": eng.params_d.cpu(), "gg": eng.grads_g.cpu()}, os.path.join(out_dir, "rank%d.pt" % rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_ranks_equal_sequential_microbatches_on_engine_gradients(tmp_path):
+  world = 2
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  from voicepuppet_amd.engine import PixReferEngine
+  params, batch = _setup(world)
+  eng = PixReferEngine(1, 256, NGF, NGF, dtype="f32", training=True)
+  eng.load_params(params)
+  micro = [[torch.tensor(b[k:k + 1], device="cuda") for b in batch] for k in range(world)]
+  for _ in range(STEPS):
+    gs, ds = [], []
+    for mb in micro:
+      eng.forward(*mb)
+      eng.backward()
+      gs.append(eng.grads_g.clone())
+      ds.append(eng.grads_d.clone())
+    eng.grads_g.copy_((gs[0] + gs[1]) / world)
+    eng.grads_d.copy_((ds[0] + ds[1]) / world)
+    eng.adam_step(LR)
+  torch.cuda.synchronize()
+  for r in range(world):
+    got = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+    assert torch.equal(got["g"], eng.params_g.cpu()), "generator parameters of rank %d differ from the sequential run" % r
+    assert torch.equal(got["d"], eng.params_d.cpu()), "discriminator parameters of rank %d differ" % r
+    assert torch.equal(got["gg"], eng.grads_g.cpu())
+
+
+def test_config5_clips_sharded_over_two_ranks(tmp_path, monkeypatch):
+  """infer_clips: three clips over two ranks (both on this box's GPU): every clip directory is filled by exactly one rank."""
+  from PIL import Image
+  from scipy.io import wavfile
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  monkeypatch.chdir(tmp_path)
+  rng = np.random.default_rng(0)
+  lines = []
+  for i, nsamp in enumerate((8000, 4000, 12000)):
+    Image.fromarray((rng.uniform(size=(512, 1536, 3)) * 255).astype(np.uint8)).save("face%d.jpg" % i)
+    t = np.arange(nsamp) / 16000.0
+    wavfile.write("a%d.wav" % i, 16000, (0.3 * np.sin(2 * np.pi * (300 + 100 * i) * t) * 32767).astype(np.int16))
+    lines.append("face%d.jpg a%d.wav" % (i, i))
+  open("clips.txt", "w").write("\n".join(lines) + "\n")
+  env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+  rc = subprocess.call([sys.executable, "-m", "voicepuppet_amd.pixrefer.infer_clips", "--config_path", os.path.join(root, "config", "params.yml"),
+                        "--gpus", "2", "--frame_batch", "4", "clips.txt"], env=env)
+  assert rc == 0
+  for i, nsamp in enumerate((8000, 4000, 12000)):
+    frames = os.listdir(os.path.join("output_clips", "clip_%d" % i))
+    assert len(frames) == int(1 + nsamp / 640), (i, len(frames))

@@ -1,0 +1,129 @@
+"""-m gpu: the BENCHMARK-WIDTH network (ngf = ndf = 64) against the float64 oracle's committed fixture
+tests/golden/full_width.npz (tests/golden/make_golden.py full): BASELINE config 1 proper - the generator forward on
+sample/22.jpg - and three consecutive full G+D steps at N = 1, 256x256 (losses per step, step-1 pixels, per-tensor gradient
+norms, post-step parameter sums and update norms: SURVEY.md 8c last row).
+Tolerances: f32 path pixels <= 1e-3 rel-L2, losses <= 1e-4 (the north-star tolerance); bf16 path pixels <= 3e-2, losses <= 5e-2
+(bf16 storage, f32 accumulate - stated, not hidden).  Also: BASELINE config 4's per-GPU workload (N = 8, 512x512, bf16)
+through size-independent properties, since the oracle cannot run that size in seconds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pixrefer_ref as ref
+from voicepuppet_amd.engine import PixReferEngine
+
+import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss")
+
+
+@pytest.fixture(scope="module")
+def fixture():
+  d = np.load(os.path.join(G, "full_width.npz"))
+  s = np.load(os.path.join(G, "sample22_256.npz"))
+  frame, face3d, matte, bg = [s[k].astype(np.float32) / 255.0 for k in ("frame", "face3d", "matte", "background")]
+  inputs = np.concatenate([face3d, face3d], axis=-1)[None]
+  fg = np.concatenate([frame * matte, frame * matte], axis=-1)[None]
+  params = ref.init_params(int(d["ngf"]), int(d["ngf"]), seed=int(d["seed"]), dtype=np.float32)
+  return d, params, [inputs, fg, frame[None], matte[None]], bg[None]
+
+
+@pytest.mark.parametrize("dtype,tol_pix", [("f32", 1e-3), ("bf16", 3e-2)])
+def test_config1_generator_forward_on_sample22_at_full_width(fixture, dtype, tol_pix):
+  d, params, batch, bg = fixture
+  eng = PixReferEngine(1, 256, 64, 64, dtype=dtype, training=False)
+  eng.load_params(params)
+  dev = lambda a: torch.tensor(a, device="cuda")
+  eng.forward(dev(batch[0]), dev(batch[1][..., :3].copy()), dev(bg))
+  out = ((eng.tensor("Outputs_raw") + 1) / 2).cpu().numpy()[0]
+  err = gu.rel_l2(out, d["Infer_Outputs"])
+  alpha = float(((eng.tensor("gen_out4")[..., 3] + 1) / 2).mean())
+  print("\n[%s] config 1 (ngf=64) pixels relL2 %.3e, mean alpha %.6f vs %.6f" % (dtype, err, alpha, float(d["Infer_Alphas_mean"])))
+  assert err < tol_pix
+  assert abs(alpha - float(d["Infer_Alphas_mean"])) < (1e-4 if dtype == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("dtype,tol_pix,tol_loss,tol_norm,tol_upd", [("f32", 1e-3, 1e-4, 5e-3, 2e-2), ("bf16", 3e-2, 5e-2, 2e-1, 5e-1)])
+def test_three_consecutive_full_width_steps(fixture, dtype, tol_pix, tol_loss, tol_norm, tol_upd):
+  d, params, batch, _ = fixture
+  eng = PixReferEngine(1, 256, 64, 64, dtype=dtype, training=True)
+  eng.load_params(params)
+  dev = [torch.tensor(b, device="cuda") for b in batch]
+  names = [str(n) for n in d["grad_names"]]
+  p0 = {}
+  for w in (0, 1):
+    p0.update(eng.get_params(w))
+  worst_loss, worst_sum, worst_upd = 0.0, 0.0, 0.0
+  for step in range(3):
+    eng.forward(*dev)
+    eng.backward()
+    torch.cuda.synchronize()
+    got = eng.losses()
+    for i, k in enumerate(KEYS):
+      worst_loss = max(worst_loss, abs(got[k] - d["losses"][step, i]) / abs(d["losses"][step, i]))
+    if step == 0:
+      pix = gu.rel_l2(((eng.tensor("Outputs_raw") + 1) / 2).cpu().numpy()[0], d["Outputs"])
+      grads = dict(eng.get_params(0, src=eng.grads_g), **eng.get_params(1, src=eng.grads_d))
+      norms = np.array([np.linalg.norm(grads[n].astype(np.float64)) for n in names])
+      ref_norms = d["grad_norms"]
+      live = ref_norms > 0
+      worst_norm = float(np.max(np.abs(norms[live] - ref_norms[live]) / ref_norms[live]))
+      assert np.all(norms[~live] == 0)
+    eng.adam_step(ref.learning_rate(3e-4, 2 * step, 1000, 0.999))
+    torch.cuda.synchronize()
+    now = dict(eng.get_params(0), **eng.get_params(1))
+    for j, n in enumerate(names):
+      upd = np.linalg.norm(now[n].astype(np.float64) - p0[n].astype(np.float64))
+      ref_upd = d["update_norms_after"][step, j]
+      if ref_upd == 0:
+        assert upd == 0, n
+        continue
+      worst_upd = max(worst_upd, abs(upd - ref_upd) / ref_upd)
+      scale = max(abs(d["param_sums_after"][step, j]), np.sqrt(now[n].size) * 0.02)      # sums of N(0, 0.02) weights are small
+      worst_sum = max(worst_sum, abs(now[n].astype(np.float64).sum() - d["param_sums_after"][step, j]) / scale)
+  print("\n[%s] full width, 3 steps: step-1 pixels %.3e, worst loss %.3e, worst grad-norm %.3e, worst update-norm %.3e, worst param-sum %.3e"
+        % (dtype, pix, worst_loss, worst_norm, worst_upd, worst_sum))
+  assert pix < tol_pix and worst_loss < tol_loss
+  assert worst_norm < tol_norm and worst_upd < tol_upd and worst_sum < tol_upd
+
+
+def test_config4_per_gpu_workload_properties():
+  """BASELINE config 4 per GPU: N = 8, 512x512, ngf = ndf = 64, bf16.  Size-independent checks: two identical steps are bit
+  identical; permuting the samples of the batch leaves the losses and the gradient arenas unchanged up to summation order (all
+  reductions are over the batch); the step is finite and close to the f32 path's losses."""
+  from bench import synth_batch
+  n, h = 8, 512
+  batch = synth_batch(n, h, 5, torch.device("cuda"))
+  perm = torch.tensor([3, 7, 0, 5, 1, 6, 2, 4], device="cuda")
+  eng = PixReferEngine(n, h, 64, 64, dtype="bf16", training=True)
+  params = eng.random_params(seed=2)
+  eng.load_params(params)
+
+  def run(b):
+    eng.forward(*b)
+    eng.backward()
+    torch.cuda.synchronize()
+    return eng.losses(), eng.grads_g.clone(), eng.grads_d.clone()
+  l1, g1, d1 = run(batch)
+  l2, g2, d2 = run(batch)
+  assert l1 == l2 and torch.equal(g1, g2) and torch.equal(d1, d2)
+  assert all(np.isfinite(v) for v in l1.values()) and torch.isfinite(g1).all() and torch.isfinite(d1).all()
+  l3, g3, d3 = run([t[perm].contiguous() for t in batch])
+  for k in l1:
+    assert abs(l1[k] - l3[k]) <= 2e-3 * abs(l1[k]), (k, l1[k], l3[k])
+  rel = lambda a, b: float((a - b).double().norm() / b.double().norm())
+  print("\nconfig-4 workload: permutation changes G grads by %.2e, D grads by %.2e; losses %s" % (rel(g3, g1), rel(d3, d1), l1))
+  assert rel(g3, g1) < 5e-2 and rel(d3, d1) < 5e-2
+  del eng
+  torch.cuda.empty_cache()
+  e32 = PixReferEngine(n, h, 64, 64, dtype="f32", training=True)
+  e32.load_params(params)
+  e32.forward(*batch)
+  torch.cuda.synchronize()
+  l32 = e32.losses()
+  for k in l1:
+    assert abs(l1[k] - l32[k]) <= 5e-2 * abs(l32[k]), (k, l1[k], l32[k])

@@ -218,3 +218,30 @@ def test_bench_launches_n_ranks_as_a_child_before_touching_the_gpu(monkeypatch):
   assert a.scaling == "strong" and bench.per_gpu_batch(a, "strong", 8) == 4 and bench.per_gpu_batch(a, "weak", 8) == 32
   with pytest.raises(SystemExit):
     bench.per_gpu_batch(bench.parse_args(["--global-batch", "30"]), "strong", 8)
+
+
+def test_clip_sharding_and_the_config5_launcher(tmp_path, monkeypatch):
+  """BASELINE config 5 (8 clips over 8 GPUs): clips are dealt round-robin, every clip has exactly one owner, and the launcher
+  starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE set (no collective anywhere on this path)."""
+  from voicepuppet_amd.parallel import shard_round_robin
+  from voicepuppet_amd.pixrefer import infer_clips
+  for n, w in ((8, 8), (11, 4), (3, 8), (0, 2)):
+    owners = [shard_round_robin(n, r, w) for r in range(w)]
+    assert sorted(i for o in owners for i in o) == list(range(n))
+    assert max(len(o) for o in owners) - min(len(o) for o in owners) <= 1
+  with pytest.raises(ValueError):
+    shard_round_robin(4, 4, 4)
+  lst = tmp_path / "clips.txt"
+  lst.write_text("a.jpg a.wav\n# comment\nb.jpg b.wav b.npz\n\n")
+  assert infer_clips.read_clip_list(str(lst)) == [("a.jpg", "a.wav"), ("b.jpg", "b.wav", "b.npz")]
+  lst.write_text("only_one_field\n")
+  with pytest.raises(ValueError):
+    infer_clips.read_clip_list(str(lst))
+
+  class Opts:
+    config_path, frame_batch, out_root = CFG, 4, "o"
+  cmds = infer_clips.rank_commands(Opts, "clips.txt", 8)
+  assert len(cmds) == 8
+  for r, (argv, env) in enumerate(cmds):
+    assert env["RANK"] == env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "8"
+    assert argv[1:3] == ["-m", "voicepuppet_amd.pixrefer.infer_clips"] and argv[-1] == "clips.txt" and "--gpus" in argv

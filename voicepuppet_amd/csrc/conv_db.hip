@@ -18,6 +18,17 @@ namespace vp {
 // Chunk k lives in registers while the ring holds chunks k+1 .. k+NST: NST-1 chunks stay in flight across each barrier.
 // fastk operands only (scalar K stepping, hardware zero fill), no K split; epilogue = the staged 16-byte row stores.
 // ------------------------------------------------------------------------------------------------
+// The fragment reads go through __restrict__ parameters on purpose: hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of any
+// LDS read that may alias a pending LDS-DMA (which would drain the whole ring every chunk); reads that carry alias-scope metadata
+// are checked against the recorded DMA stores instead, and the counted vmcnt + barrier in the loop is what really orders them.
+template <int TC, int TP>
+__device__ __forceinline__ void frag_read_rb(const uint4* __restrict__ pa, const uint4* __restrict__ pb, uint4 (&fa)[TC], uint4 (&fb)[TP]) {
+#pragma unroll
+  for (int t = 0; t < TP; ++t) fb[t] = pb[t * 64];
+#pragma unroll
+  for (int t = 0; t < TC; ++t) fa[t] = pa[t * 64];
+}
+
 template <typename T, int WC, int WP, int TC, int TP, int NST, bool STATS = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_db_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
@@ -115,11 +126,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_db_kernel(const IgemmArgs 
 
   auto frag_read = [&](int stage, uint4 (&fa)[TC], uint4 (&fb)[TP]) {
     const uint4* la = lds + stage * BUF;
-    const uint4* lb = la + 4 * BC;
-#pragma unroll
-    for (int t = 0; t < TP; ++t) fb[t] = lb[(blkB0 + t) * 64 + so];
-#pragma unroll
-    for (int t = 0; t < TC; ++t) fa[t] = la[(blkA0 + t) * 64 + so];
+    frag_read_rb<TC, TP>(la + blkA0 * 64 + so, la + 4 * BC + blkB0 * 64 + so, fa, fb);
   };
   auto mma_all = [&](const uint4 (&fa)[TC], const uint4 (&fb)[TP]) {
 #pragma unroll
@@ -136,8 +143,9 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_db_kernel(const IgemmArgs 
     asm volatile("" ::: "memory");
     if (kc + NST < nchunk) issue(stage_cur);
     const int stage_nxt = stage_cur == NST - 1 ? 0 : stage_cur + 1;
-    if (kc + 1 < nchunk) frag_read(stage_nxt, fa_nxt, fb_nxt);
-    mma_all(fa_cur, fb_cur);
+    frag_read(stage_nxt, fa_nxt, fb_nxt);     // unconditional (past the last chunk it reads a stale stage that nobody uses): a
+    __builtin_amdgcn_sched_barrier(0);        // branch here makes the compiler wait lgkmcnt(0) before the MFMAs of `cur`; the scheduling
+    mma_all(fa_cur, fb_cur);                  // barrier keeps the reads AHEAD of the MFMAs (else they sink below and share one register set)
   };
 
   __syncthreads();   // tap table visible

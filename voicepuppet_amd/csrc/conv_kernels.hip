@@ -2009,7 +2009,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
     }
     // register-double-buffered kernel for the 128-accumulator tiles (256x256, 128x512): conv_db.hip
     if constexpr (NW == 8 && TC == 8 && TP == 4) {
-      static const bool db_on = !getenv("VP_NO_DB");
+      static const bool db_on = getenv("VP_DB") != nullptr;   // opt-in: measured no faster than the wave-specialised 256x256 kernel (round 2)
       if (db_on && b.vec_epi && b.fastk && a.splitk == 1) return launch_igemm_db(b, sizeof(T) == 2, BC, grid, st);
     }
     // wave-specialised kernel, per tile shape (bit = launch_igemm cfg index): measured gains for 128x128 (cfg 0), 64x128 (cfg 1), 256x256 (cfg 7); 128x256 is faster without

@@ -52,3 +52,11 @@ def shard_batch(global_batch, rank, world):
     raise ValueError("global batch %d is not divisible by %d ranks" % (global_batch, world))
   per = global_batch // world
   return rank * per, (rank + 1) * per
+
+
+def shard_round_robin(n_items, rank, world):
+  """Indices of `n_items` independent work items (clips) owned by `rank`: rank, rank + world, ...  No collective is involved:
+  the items are independent (log-mel / BFMNet / infer_bfmvid shard by clip, replicas only)."""
+  if not 0 <= rank < world:
+    raise ValueError("rank %d outside a world of %d" % (rank, world))
+  return list(range(rank, n_items, world))

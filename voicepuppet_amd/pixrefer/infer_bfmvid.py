@@ -93,6 +93,8 @@ def main(argv=None):
   cmd_parser.add_option('--frame_batch', type="int", dest="frame_batch", default=8, help='frames per device batch')
   cmd_parser.add_option('--bfmcoeff', type="string", dest="bfmcoeff", default=None,
                         help='npz with the photo\'s bfmcoeff [1,257], transform_params [5], center_x, center_y, ratio')
+  cmd_parser.add_option('--output_dir', type="string", dest="output_dir", default='output',
+                        help='frame directory (the reference always writes output/; infer_clips.py gives every clip its own)')
   opts, argv = cmd_parser.parse_args(argv)
 
   if (opts.config_path is None):
@@ -105,10 +107,11 @@ def main(argv=None):
 
   image_file, audio_file = argv
 
-  if not os.path.exists('output'):
-    os.makedirs('output')
-  for file in os.listdir('output'):
-    p = os.path.join('output', file)
+  out_dir = opts.output_dir
+  if not os.path.exists(out_dir):
+    os.makedirs(out_dir)
+  for file in os.listdir(out_dir):
+    p = os.path.join(out_dir, file)
     shutil.rmtree(p) if os.path.isdir(p) else os.remove(p)
 
   batch_size = 1
@@ -199,12 +202,12 @@ def main(argv=None):
                               feed_dict={inputs_holder: inputs, fg_inputs_holder: fg_inputs, targets_holder: targets})
       for k in range(nb):
         if i0 + k < T:
-          Image.fromarray((np.clip(frames[k], 0, 1) * 255).astype(np.uint8)).save('output/{}.jpg'.format(i0 + k))
+          Image.fromarray((np.clip(frames[k], 0, 1) * 255).astype(np.uint8)).save(os.path.join(out_dir, '{}.jpg'.format(i0 + k)))
 
     if shutil.which('ffmpeg'):
       # same command line as infer_bfmvid.py:245, as an argument vector (no shell: the audio path is user input)
-      subprocess.call(['ffmpeg', '-i', 'output/%d.jpg', '-i', audio_file, '-c:v', 'libx264', '-c:a', 'aac',
-                       '-strict', 'experimental', '-y', 'output.mp4'])
+      subprocess.call(['ffmpeg', '-i', os.path.join(out_dir, '%d.jpg'), '-i', audio_file, '-c:v', 'libx264', '-c:a', 'aac',
+                       '-strict', 'experimental', '-y', out_dir.rstrip('/') + '.mp4'])
     else:
       logger.warning('ffmpeg not found: frames are in output/, no mp4 written')
 
