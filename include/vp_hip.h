@@ -88,6 +88,13 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream);
  * discriminator gradients while the generator backward runs. */
 int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream);
 int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream);
+/* vp_pixrefer_backward runs the two (independent) halves CONCURRENTLY: the discriminator-loss pass on a HIP stream the handle
+ * owns, forked from and joined into `stream` with events (no host blocking; bit-identical results).  The same for a host with
+ * work of its own in between: _fork starts the discriminator-loss pass behind everything already enqueued on `stream`, _join
+ * makes `stream` wait for it; grads_d is final after the join.  (VP_NO_OVERLAP=1 in the environment at create time: both run
+ * on `stream`, one after the other.) */
+int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream);
+int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream);
 /* The same pass in vp_pixrefer_backward_g_stages() = 3 consecutive stages (stage < 0: all).  After stage s a contiguous
  * range of the generator gradient arena is final (0: from generator/merged_decoder_5 to the end; 1: from
  * generator/merged_encoder_2 up to merged_decoder_5; 2: the rest), so a data-parallel host can start that bucket's
@@ -107,6 +114,22 @@ int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t s
  * synchronising the stream; returns the bytes needed (including the terminator). */
 int vp_profile_enable(int on);
 size_t vp_profile_collect(char* json, size_t cap);
+
+/* Input pipeline on the device.  Replaces the per-sample host work of PixReferDataGenerator.iterator (generator/generator.py:
+ * 956-1019: BGR->RGB, split of the S x 3S triptych into target | 3-D face | matte, random square crop, cv2.resize back to S x S,
+ * the 6-channel packing of (example, current) and fg = target * matte).  example_frames / current_frames: [n][S][3S][3] uint8
+ * exactly as cv2.imread decodes the training jpgs; crops: [n][2][3] int32 = (rx rows, ry columns, rsize) for the example and the
+ * current frame, 0 <= rx, ry and rx + rsize, ry + rsize <= S (drawn by the caller as generator.py:975-977, 994-996); outputs:
+ * the four float32 tensors vp_pixrefer_forward takes.  All pointers are device memory; crop values are NOT range-checked. */
+int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned char* current_frames, const int* crops,
+                            int n, int img_size, float* inputs, float* fg_inputs, float* targets, float* masks, void* stream);
+
+/* Kernel-selection knobs for tests and experiments (they choose between kernels that compute the same result); plans made AFTER
+ * the call see the new value.  Keys: "patch_tiles" (bit 0 / 1 / 2: allow the 256- / 128- / 64-row tiles of the stride-1 patch
+ * kernel, default 7), "patch_min_blocks" (smallest grid that runs on it, default 384), "patch_small_tiles" (bit 0: 16x16-pixel
+ * tiles for the 128- / 64-row variants, bit 1: 8x16 for the 256-row variant - two blocks per CU; default 3), "patch_long_k_on_256"
+ * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile).  No counterpart in the reference. */
+int vp_tune(const char* key, int value);
 
 /* theta -= lr_t * m / (sqrt(v) + eps) with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) (TF formulation) */
 int vp_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, int step_t,

@@ -219,7 +219,8 @@ def composite_bwd(out4, targets, d_outputs, d_alphas, d_outputs_fg):
 # ----------------------------------------------------------------------------
 # discriminator  (pixrefer.py:103-134); one application = its own batch stats
 # ----------------------------------------------------------------------------
-def discriminator_fwd(p, cond3, img3, ndf=64):
+def discriminator_fwd(p, cond3, img3, ndf=64, f32_probs=False):
+  """f32_probs: the sigmoid output is rounded to float32, as the reference's float32 graph holds it (see forward_backward)."""
   x = np.concatenate([cond3, img3], axis=3)
   tape = []
   for scope, cout, stride, bn in discriminator_spec(ndf):
@@ -234,6 +235,9 @@ def discriminator_fwd(p, cond3, img3, ndf=64):
       z = y
     rec['z'] = z
     x = ops.sigmoid(z) if scope == 'layer_5' else ops.lrelu(z, 0.2)
+    if scope == 'layer_5' and f32_probs:
+      x = x.astype(np.float32)
+      rec['f32'] = True
     rec['out'] = x
     tape.append(rec)
   return x, tape
@@ -247,7 +251,10 @@ def discriminator_bwd(p, tape, dp, ndf=64, need_dw=True):
   for li in range(len(spec) - 1, -1, -1):
     scope, cout, stride, bn = spec[li]
     rec = tape[li]
-    if scope == 'layer_5':
+    if scope == 'layer_5' and rec.get('f32'):
+      o = rec['out']                                    # float32: 1 - o is exactly 0 once the sigmoid has saturated
+      dz = (dout.astype(np.float32) * o * (np.float32(1) - o)).astype(np.float64)
+    elif scope == 'layer_5':
       dz = dout * rec['out'] * (1 - rec['out'])
     else:
       dz = dout * ops.lrelu_grad(rec['z'], 0.2)
@@ -317,10 +324,16 @@ def learning_rate(base_lr, global_step, decay_steps, decay_rate):
 # the whole training graph: forward, losses, both gradients  (build_train_op)
 # ----------------------------------------------------------------------------
 def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64,
-                     l1_weight=500.0, gan_weight=1.0, want_grads=True):
+                     l1_weight=500.0, gan_weight=1.0, want_grads=True, f32_probs=False):
   """inputs/fg_inputs [N,H,H,6], targets/masks [N,H,H,3], all in [0,1] as the
   data generator yields them (generator.py:1011-1019).  Returns a dict with the
-  `nodes` of pixrefer.py:356-412 plus gradient dicts."""
+  `nodes` of pixrefer.py:356-412 plus gradient dicts.
+
+  f32_probs: evaluate the GAN terms the way the reference's float32 graph does (pixrefer.py:336-345: tf.log(1 - predict_fake
+  + EPS) on a float32 sigmoid output).  Once the discriminator saturates (predict_fake within 6e-8 of 1, which happens after
+  ONE Adam step at the reference's learning rate) float32 holds predict_fake == 1 exactly: the loss term is -log(1e-12) and
+  its gradient through the sigmoid is exactly 0, where exact arithmetic gives -log(1 - p) and a gradient of 1.  This is a
+  property of the reference's dtype, not of an implementation, so multi-step trajectories are compared with it switched on."""
   inp = inputs * 2 - 1          # preprocess, pixrefer.py:373-375 (masks are NOT preprocessed)
   fg = fg_inputs * 2 - 1
   tgt = targets * 2 - 1
@@ -330,10 +343,10 @@ def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64,
   outputs, alphas, outputs_fg = composite(out4, tgt)
 
   # three discriminator applications, shared weights, separate batch statistics (pixrefer.py:295-306)
-  p_real1, t_real1 = discriminator_fwd(p, inp[..., 3:], fg[..., 3:], ndf)
-  p_real2, t_real2 = discriminator_fwd(p, inp[..., :3], fg[..., :3], ndf)
-  predict_real = (p_real1 + p_real2) / 2
-  predict_fake, t_fake = discriminator_fwd(p, inp[..., 3:], outputs_fg, ndf)
+  p_real1, t_real1 = discriminator_fwd(p, inp[..., 3:], fg[..., 3:], ndf, f32_probs)
+  p_real2, t_real2 = discriminator_fwd(p, inp[..., :3], fg[..., :3], ndf, f32_probs)
+  predict_real = (p_real1 + p_real2) * (np.float32(0.5) if f32_probs else 0.5)
+  predict_fake, t_fake = discriminator_fwd(p, inp[..., 3:], outputs_fg, ndf, f32_probs)
 
   # perceptual loss (pixrefer.py:318-323)
   n = inp.shape[0]
@@ -341,9 +354,10 @@ def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64,
   fa, fb = f3[:n], f3[n:]
   content_loss = ((fa - fb) ** 2).sum() / 2 / fa.size
 
-  eps = 1e-12
-  discrim_loss = np.mean(-(np.log(predict_real + eps) * 2 + np.log(1 - predict_fake + eps)))
-  gen_loss_gan = np.mean(-np.log(predict_fake + eps))
+  eps = np.float32(1e-12) if f32_probs else 1e-12
+  one = np.float32(1) if f32_probs else 1.0
+  discrim_loss = np.mean(-(np.log(predict_real + eps) * 2 + np.log(one - predict_fake + eps)), dtype=np.float64)
+  gen_loss_gan = np.mean(-np.log(predict_fake + eps), dtype=np.float64)
   gen_loss_l1 = np.mean(np.abs(tgt - outputs)) + np.mean(np.abs(masks - alphas)) + content_loss
   gen_loss = gen_loss_gan * gan_weight + gen_loss_l1 * l1_weight
 
@@ -356,8 +370,8 @@ def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64,
 
   # ---- discriminator gradients (var_list = discriminator*) ----
   m = predict_real.size
-  d_preal = -2.0 / (predict_real + eps) / m
-  d_pfake = 1.0 / (1 - predict_fake + eps) / m
+  d_preal = (-2 * one) / (predict_real + eps) / m
+  d_pfake = one / (one - predict_fake + eps) / m
   dgr = {}
   for tape, dp in ((t_real1, d_preal / 2), (t_real2, d_preal / 2), (t_fake, d_pfake)):
     g, _ = discriminator_bwd(p, tape, dp, ndf)
@@ -365,7 +379,7 @@ def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64,
       dgr[k] = dgr.get(k, 0) + v
 
   # ---- generator gradients (var_list = generator*) ----
-  d_pfake_g = gan_weight * (-1.0 / (predict_fake + eps) / m)
+  d_pfake_g = gan_weight * (-one / (predict_fake + eps) / m)
   _, d_dinput = discriminator_bwd(p, t_fake, d_pfake_g, ndf, need_dw=False)
   d_outputs_fg = d_dinput[..., 3:].copy()
   df3 = np.zeros_like(f3)
@@ -392,8 +406,9 @@ def _slice_rec(rec, n):
 class TrainState:
   """Parameters + the two Adam states + global_step (pixrefer.py:390-407)."""
 
-  def __init__(self, params, ngf=64, ndf=64, base_lr=3e-4, beta1=0.5, decay_steps=1000, decay_rate=0.999):
+  def __init__(self, params, ngf=64, ndf=64, base_lr=3e-4, beta1=0.5, decay_steps=1000, decay_rate=0.999, f32_probs=False):
     self.p = params
+    self.f32_probs = f32_probs
     self.ngf, self.ndf = ngf, ndf
     self.base_lr, self.beta1 = base_lr, beta1
     self.decay_steps, self.decay_rate = decay_steps, decay_rate
@@ -407,7 +422,8 @@ class TrainState:
     self.v = {n: np.zeros_like(params[n]) for n in self.g_names + self.d_names}
 
   def step(self, inputs, fg_inputs, targets, masks, l1_weight=500.0, gan_weight=1.0):
-    nodes = forward_backward(self.p, inputs, fg_inputs, targets, masks, self.ngf, self.ndf, l1_weight, gan_weight)
+    nodes = forward_backward(self.p, inputs, fg_inputs, targets, masks, self.ngf, self.ndf, l1_weight, gan_weight,
+                             f32_probs=self.f32_probs)
     lr = learning_rate(self.base_lr, self.global_step, self.decay_steps, self.decay_rate)
     self.t_d += 1
     for nme in self.d_names:

@@ -10,6 +10,7 @@
   full_width.npz     config 1 proper: the generator forward on sample22 at ngf = 64; and three consecutive full G+D steps at
                      ngf = ndf = 64, N = 1 (losses per step, step-1 output, per-tensor gradient norms, post-step parameter sums)
                      (`python tests/golden/make_golden.py full`: ~10 minutes)
+  frame_pack.npz     input pipeline: uint8 triptych frames + crops -> packed float tensors by the host path (PIL bilinear)
   logmel.npz         log-mel of a seeded 4096-sample chirp+noise, and the 257x80 mel matrix
   bfmnet.npz         BFMNet coefficients for a seeded 5-frame clip (parameters regenerated from the seed)
   bfm_recon.npz      outputs of the REFERENCE's own utils/reconstruct_mesh.py (pure numpy, imported from /root/reference here)
@@ -111,8 +112,11 @@ def full_width(panels, bg):
   p = {k: v.astype(np.float64) for k, v in ref.init_params(ngf, ndf, seed=seed, dtype=np.float32).items()}
   inf = ref.inference(p, inputs, fg[..., :3], bg[None].astype(np.float64) / 255.0, ngf)
   d = {"seed": seed, "ngf": ngf, "Infer_Outputs": inf["Outputs"][0].astype(np.float32), "Infer_Alphas_mean": np.float64(inf["Alphas"].mean())}
-  st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf)
+  # f32_probs: the GAN terms as the reference's float32 graph evaluates them (the discriminator saturates after one step here:
+  # see oracle.pixrefer_ref.forward_backward); everything else in float64
+  st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf, f32_probs=True)
   keys = ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss")
+  sat = []
   losses, sums, norms2 = [], [], []
   names = None
   for step in range(3):
@@ -123,13 +127,35 @@ def full_width(panels, bg):
       d["Outputs"] = nodes["Outputs"][0].astype(np.float32)
       d["grad_norms"] = np.array([np.linalg.norm(nodes["Gen_grads" if n.startswith("generator") else "Discrim_grads"][n]) for n in names])
     losses.append([nodes[k] for k in keys])
+    sat.append(int((nodes["Predict_fake"] == 1).sum()))
     sums.append([st.p[n].sum() for n in names])
     norms2.append([np.linalg.norm(st.p[n] - p[n]) for n in names])     # size of the update since the start
     print("full-width step", step, dict(zip(keys, losses[-1])), flush=True)
   d["losses"] = np.array(losses)
+  d["saturated_fake_predictions"] = np.array(sat)
   d["param_sums_after"] = np.array(sums)
   d["update_norms_after"] = np.array(norms2)
   np.savez_compressed(os.path.join(HERE, "full_width.npz"), **d)
+
+
+def frame_pack():
+  """Input-pipeline fixture: uint8 triptych frames + crops -> the four packed float tensors, computed by the
+  host path (PIL bilinear on float planes standing in for cv2.resize, generator.py:956-1019)."""
+  from voicepuppet_amd.generator.device_pipeline import host_pack_reference
+  S, N = 32, 4
+  rng = np.random.default_rng(31)
+  yy, xx = np.mgrid[0:S, 0:3 * S]
+  ex = np.stack([np.clip(rng.integers(0, 256, (S, 3 * S, 3)) * 0.5 + 64 * np.sin(yy / 3.0 + k)[..., None] + 64, 0, 255) for k in range(N)]).astype(np.uint8)
+  cur = rng.integers(0, 256, (N, S, 3 * S, 3)).astype(np.uint8)
+  crops = np.array([[[0, 0, S], [0, 0, S]],                       # no crop: the resize is the identity
+                    [[0, 3, 29], [3, 0, 29]],                     # int(0.9 * 32) = 28 .. 32
+                    [[4, 4, 28], [0, 0, 28]],
+                    [[1, 2, 30], [1, 0, 31]]], np.int32)
+  assert (crops[..., 0] + crops[..., 2] <= S).all() and (crops[..., 1] + crops[..., 2] <= S).all()
+  outs = [host_pack_reference(ex[i], cur[i], crops[i], S) for i in range(N)]
+  np.savez_compressed(os.path.join(HERE, "frame_pack.npz"), ex=ex, cur=cur, crops=crops,
+                      inputs=np.stack([o[0] for o in outs]).astype(np.float32), fg_inputs=np.stack([o[1] for o in outs]).astype(np.float32),
+                      targets=np.stack([o[2] for o in outs]).astype(np.float32), masks=np.stack([o[3] for o in outs]).astype(np.float32))
 
 
 def audio():
@@ -189,6 +215,9 @@ def bfm_recon():
 
 
 if __name__ == "__main__":
+  if sys.argv[1:] == ["frame_pack"]:
+    frame_pack()
+    sys.exit(0)
   if sys.argv[1:] == ["full"]:
     full_width(*sample22())
     sys.exit(0)
@@ -198,6 +227,7 @@ if __name__ == "__main__":
     sys.exit(0)
   panels, bg = sample22()
   toy_ops()
+  frame_pack()
   mini_step(panels, bg)
   audio()
   raster()

@@ -39,7 +39,20 @@ FWD_CASES = [
     (0, 8, 64, 64, 64, 256, 4, 2, 1, 0, 0, False),    # weight gradient on the 256x256 8-wave tile
     (0, 2, 256, 256, 32, 128, 3, 1, 1, 0, 2, False),  # 131072 pixels x 128 channels: the 128x512 register-double-buffered tile
     (0, 4, 256, 256, 64, 256, 4, 2, 1, 0, 0, False),  # 65536 pixels x 256 channels, 4x4 stride 2, K = 1024: 256x256 double-buffered tile
+    # stride-1 patch kernel (conv_patch.hip; the fixture below lets it run on small grids): ragged 2-D tiles, every tile shape
+    (0, 2, 40, 48, 64, 256, 3, 1, 1, 0, 2, False),    # 256 ch x 16x16 px tiles, 3x3, ragged in both directions, two channel chunks
+    (0, 2, 33, 70, 32, 128, 4, 1, 1, 0, 0, False),    # 128 ch x 16x32 px tiles, 4x4 stride 1 (32 x 69 outputs), one chunk
+    (0, 1, 48, 64, 128, 64, 3, 1, 1, 0, 2, False),    # 64 ch x 16x32 px tiles (half-instruction weight DMAs), four chunks
+    (0, 3, 31, 31, 64, 64, 4, 1, 1, 0, 0, False),     # D layer_4 geometry at a small width: 30 x 30 outputs
 ]
+
+
+@pytest.fixture(autouse=True)
+def small_grids_on_the_patch_kernel():
+  L = _lib.lib()
+  L.vp_tune(b"patch_min_blocks", 1)
+  yield
+  L.vp_tune(b"patch_min_blocks", 384)
 
 
 def make_case(case, seed=0):
@@ -74,6 +87,21 @@ def test_conv_fwd(case, dtype):
   yr = ACTS[out_act](yr)
   assert np.isfinite(y).all()
   assert gu.rel_l2(y, yr) < TOL[dtype], gu.rel_l2(y, yr)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("small", [0, 1])
+@pytest.mark.parametrize("case", [c for c in FWD_CASES if c[6] in (3, 4) and c[7] == 1 and c[4] >= 32 and c[5] >= 64 and not c[11] and c[9] == 0])
+def test_patch_kernel_tile_variants(case, small, dtype):
+  """The other tile shapes of the stride-1 patch kernel (test_conv_fwd runs the default): small = 0: one 8-wave block per CU
+  (16x16 / 16x32 pixel tiles), small = 1: two blocks per CU for the 128- / 64-row tiles only (the default, 3, adds 8x16 pixels for
+  the 256-row tile)."""
+  L = _lib.lib()
+  L.vp_tune(b"patch_small_tiles", small)
+  try:
+    test_conv_fwd(case, dtype)
+  finally:
+    L.vp_tune(b"patch_small_tiles", 3)
 
 
 BWD_CASES = [c for c in FWD_CASES if c[5] >= 8 and (c[5] & (c[5] - 1)) == 0]

@@ -374,3 +374,29 @@ def test_bucketed_train_step_through_rccl_single_rank():
       assert torch.equal(a, b)
   finally:
     dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_overlapped_backward_equals_sequential_passes():
+  """vp_pixrefer_backward runs the discriminator-loss pass on the executor's side stream, concurrently with the generator-loss
+  pass (own gradient / scratch buffers for each): bit-identical to the two passes run one after the other on one stream, over
+  repeated steps (the buffers of one pass must never leak into the other)."""
+  ngf = ndf = 8
+  p = make_params(ngf, ndf, 5)
+  batch = [torch.tensor(b, device="cuda") for b in synth(2, 256, 13)]
+  for dtype in ("f32", "bf16"):
+    a = PixReferEngine(2, 256, ngf, ndf, dtype=dtype, training=True)
+    b = PixReferEngine(2, 256, ngf, ndf, dtype=dtype, training=True)
+    a.load_params(p)
+    b.load_params(p)
+    for _ in range(3):
+      a.forward(*batch)
+      a.backward()
+      b.forward(*batch)
+      b.backward_d()
+      b.backward_g()
+      torch.cuda.synchronize()
+      assert torch.equal(a.grads_d, b.grads_d) and torch.equal(a.grads_g, b.grads_g), dtype
+      a.adam_step(3e-4)
+      b.adam_step(3e-4)
+    assert torch.equal(a.params_g, b.params_g) and torch.equal(a.params_d, b.params_d)

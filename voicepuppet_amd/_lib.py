@@ -55,9 +55,13 @@ _SIGNATURES = {
     "vp_pixrefer_backward": (ctypes.c_int, [_P, _P]),
     "vp_pixrefer_backward_d": (ctypes.c_int, [_P, _P]),
     "vp_pixrefer_backward_g": (ctypes.c_int, [_P, _P]),
+    "vp_pixrefer_backward_d_fork": (ctypes.c_int, [_P, _P]),
+    "vp_pixrefer_backward_d_join": (ctypes.c_int, [_P, _P]),
     "vp_pixrefer_backward_g_stages": (ctypes.c_int, []),
     "vp_pixrefer_backward_g_stage": (ctypes.c_int, [_P, ctypes.c_int, _P]),
     "vp_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "vp_tune": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "vp_pixrefer_pack_frames": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P]),
     "vp_profile_collect": (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
     "vp_pixrefer_tensor": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_int)]),

@@ -60,6 +60,9 @@ struct IgemmArgs {
   double* bn_part;          // staged epilogue also writes batch-norm partials [group][bn_nchunk][2][Cout] (null: no)
   int bn_tpg, bn_nchunk;    // pixel tiles per BN group (per class), partial chunks per group = nclass * bn_tpg
   const void* zeros;        // >= 16 bytes of zeros (padding source of the LDS-DMA loader); null: register loader
+  // patch kernel (conv_patch.hip; plan-time decision, the packed weights carry PackDesc::kswap): stride-1 taps on a regular grid,
+  // tap t = r * p_kw + c  ->  (dh, dw) = (p_dhf + r * p_dhs, p_dwf + c * p_dws)
+  int patch, p_kw, p_dhf, p_dhs, p_dwf, p_dws;
 };
 
 // dW[tap][g][d] = sum_{pixels} G~[pixel (+) tap, g] * D~[pixel, d]

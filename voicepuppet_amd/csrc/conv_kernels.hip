@@ -10,8 +10,8 @@
 //   wgrad_kernel       bwd-weight: K = pixels (the strided NHWC dim): register loader + 8x8 transposes into LDS planes,
 //                      division-free padded-grid K walk, split-K slabs + deterministic reduces
 //   igemm_splitk_reduce_kernel, wgrad_reduce_kernel, wgrad_reduce_wave_kernel
-// Kept behind switches (correct, measured slower; see the table in DESIGN.md): igemm_kernel (register loader with the deferred-BN
-// prologue: single-op API only), igemm_regb_kernel, igemm_wsr_kernel, igemm_wsw_kernel, igemm_patch_kernel, direct_epilogue.
+// Not in this library: the kernels that were measured slower live in experiments/igemm_experiments.inc and conv_db.hip and are only
+// compiled by `make experiments` (-DVP_EXPERIMENTS).  igemm_kernel (register loader with the deferred-BN prologue) serves the single-op API.
 //
 // LDS plane layout of the register-loader kernels (igemm_kernel, wgrad_kernel): a tile of ROWS rows x 64 bytes of K is stored as 4
 // planes (one per 16-byte k-piece g), plane g = ROWS consecutive 16-byte slots.  MFMA lane (i = lane&15, g = lane>>4) reads
@@ -512,6 +512,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
     return;
   }
 #endif
+#ifdef VP_EXPERIMENTS
   if constexpr (STAGED && !STATS && TC % 4 == 0) {
     if (a.direct_epi) {
       long long* otab = reinterpret_cast<long long*>(smem + NST * BUF * 16 + 64);     // behind the ring and the tap table
@@ -522,6 +523,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
       return;
     }
   }
+#endif
   if (STAGED) {
     constexpr int RINGB = NST * BUF * 16;
     constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
@@ -544,168 +546,6 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
       }
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// igemm_regb_kernel: the same GEMM with the two operands on two different paths into the CU.  Every tile shape of the
-// LDS-DMA kernel above tops out at the same ~13 TB/s of aggregate LDS fill (whatever the tile, DMA bytes/s are constant),
-// so here only the WEIGHT tile (shared by the block's waves) rides the LDS-DMA ring; each wave fetches the MFMA B fragments
-// of ITS OWN pixels straight into registers with buffer_load_dwordx4 (lane (i, g) needs the 16 bytes k = 8g..8g+7 of pixel
-// row i: exactly one piece, four lanes cover a contiguous 64-byte segment) - no LDS round trip for the pixel operand at all.
-// Out-of-range offsets return zeros (padding), K steps by scalar offsets (the fastk scheme).  Order per K chunk:
-//   wait(vmcnt: this chunk's fragments + weight stage) -> barrier -> load fragments kc+1 -> DMA weights kc+2 -> MFMA kc.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int WC, int WP, int TC, int TP>
-__global__ __launch_bounds__(WC * WP * 64) void igemm_regb_kernel(const IgemmArgs a) {
-  constexpr int E = Elem<T>::E, KC = 4 * E;
-  constexpr int NW = WC * WP, NT = NW * 64;
-  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
-  constexpr int NBA = BC / 16;
-  static_assert(NBA % NW == 0, "every wave issues the same number of weight DMAs");
-  constexpr int JA = NBA / NW;
-  constexpr int BUF = 4 * BC;                          // 16-byte slots of one weight stage
-  constexpr int NST = 3;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* lds = reinterpret_cast<uint4*>(smem);
-  int* ltap = reinterpret_cast<int*>(lds + NST * BUF);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cls = blockIdx.z;
-  const int P = a.N * a.Hg * a.Wg;
-  int pt, ct;
-  {
-    const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
-    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7, slot = id >> 3;
-    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    ct = logical % (int)gridDim.y; pt = logical / (int)gridDim.y;
-  }
-  const int p_base = pt * BP, c_base = ct * BC;
-  const int wc = wave / WP, wpi = wave - wc * WP;
-  const int blkA0 = wc * TC, blkB0 = wpi * TP;
-  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
-
-  const unsigned es = sizeof(T);
-  const T* x0 = reinterpret_cast<const T*>(a.x.ptr[0]);
-  const T* x1 = reinterpret_cast<const T*>(a.x.ptr[1]);
-  const int C0 = a.x.C[0], C1 = a.x.C[1];
-  __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
-  __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
-  __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(x1 ? (const void*)x1 : (const void*)x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * es));
-
-  // weight DMA lanes: 16-row block (wave + NW*j), row r, piece g (rb_swz image, as in igemm_dma_kernel)
-  unsigned wvo[JA];
-  {
-    const int r = lane >> 2, g = (lane & 3) ^ rb_swz(lane >> 2);
-#pragma unroll
-    for (int j = 0; j < JA; ++j) wvo[j] = (unsigned)(((c_base + (wave + NW * j) * 16 + r) * KC + g * E) * es);
-  }
-  const unsigned wstep = (unsigned)(a.wp_rows * KC * es);
-  unsigned wso = 0;
-  // this lane's pixel rows: tile t -> row (blkB0 + t)*16 + (lane & 15), piece lane >> 4
-  const int fi = lane & 15, fg = lane >> 4;
-  int pn[TP], pbh[TP], pbw[TP];
-  bool pok[TP];
-#pragma unroll
-  for (int t = 0; t < TP; ++t) {
-    const int pidx = p_base + (blkB0 + t) * 16 + fi;
-    pok[t] = pidx < P;
-    const int hw = a.Hg * a.Wg;
-    const int pc = pok[t] ? pidx : 0;
-    const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
-    pn[t] = n * a.Hin; pbh[t] = q * a.sh; pbw[t] = (rem - q * a.Wg) * a.sw;
-  }
-  const int nchunk = a.Kpad / KC;
-
-  // segment walker of the pixel operand (tap, source), see igemm_dma_kernel
-  unsigned xso = 0;
-  int left = 0, tap = 0, src = 0;
-  bool use1 = false;
-  unsigned xvo[TP];
-  auto open_segment = [&]() {
-    const bool tok = tap < a.ntaps;
-    const int tv = ltap[tok ? tap : 0];
-    const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
-    use1 = src != 0;
-    const int Cs = use1 ? C1 : C0;
-#pragma unroll
-    for (int t = 0; t < TP; ++t) {
-      const int ih = pbh[t] + dh, iw = pbw[t] + dw;
-      const bool ok = pok[t] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-      xvo[t] = ok ? (unsigned)((((pn[t] + ih) * a.Win + iw) * Cs + fg * E) * es) : DMA_OOB;
-    }
-    left = Cs / KC;
-    xso = 0;
-    if (!use1 && C1 > 0) src = 1; else { src = 0; ++tap; }
-  };
-  auto load_x = [&](uint4 (&f)[TP]) {
-    if (left == 0) open_segment();
-    const __amdgpu_buffer_rsrc_t rx = use1 ? rsX1 : rsX0;
-#pragma unroll
-    for (int t = 0; t < TP; ++t) {
-      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xvo[t], (int)xso, 0);
-      f[t] = make_uint4(v.x, v.y, v.z, v.w);
-    }
-    xso += KC * es;
-    --left;
-  };
-  auto issue_w = [&](int buf) {
-    uint4* la = lds + buf * BUF;
-#pragma unroll
-    for (int j = 0; j < JA; ++j) dma16_buf(rsW, wvo[j], wso, la + (wave + NW * j) * 64);
-    wso += wstep;
-  };
-
-  f32x4 acc[TC][TP];
-#pragma unroll
-  for (int i = 0; i < TC; ++i)
-#pragma unroll
-    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int so = fi * 4 + (fg ^ rb_swz(fi));            // LDS slot of this lane's A fragment inside a 16-row block
-  uint4 fb0[TP], fb1[TP];
-  __syncthreads();   // tap table visible
-
-  // one K chunk: kc is consumed from ring stage st with fragments `cur`; fragments of kc+1 go to `nxt`.
-  // hipcc puts a full vmcnt(0) in front of the first MFMA that reads `cur` (its scoreboard does not count through the
-  // LDS-DMAs of the loop), so the next loads are issued AFTER the first row of MFMAs: the wait then finds nothing new
-  // in flight and the loads overlap the remaining MFMAs, the barrier and the other resident blocks.
-  auto step = [&](int kc, int st, uint4 (&cur)[TP], uint4 (&nxt)[TP]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const uint4* la = lds + st * BUF;
-    uint4 fa[TC];
-#pragma unroll
-    for (int t = 0; t < TC; ++t) fa[t] = la[(blkA0 + t) * 64 + so];
-#pragma unroll
-    for (int tp = 0; tp < TP; ++tp) acc[0][tp] = mma16<T>(fa[0], cur[tp], acc[0][tp]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kc + 1 < nchunk) load_x(nxt);
-    if (kc + 2 < nchunk) issue_w(st == 0 ? 2 : st - 1);                                // the stage chunk kc-1 used
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int tc = 1; tc < TC; ++tc)
-#pragma unroll
-      for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], cur[tp], acc[tc][tp]);
-  };
-
-  issue_w(0);
-  load_x(fb0);
-  if (nchunk > 1) issue_w(1);
-  int st = 0;
-  for (int kc = 0; kc < nchunk; kc += 2) {
-    step(kc, st, fb0, fb1);
-    st = st == 2 ? 0 : st + 1;
-    if (kc + 1 < nchunk) {
-      step(kc + 1, st, fb1, fb0);
-      st = st == 2 ? 0 : st + 1;
-    }
-  }
-
-  constexpr int NPASS = epi_passes(BC, BP, WP, VP_REGB_EPI_BYTES);
-  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -873,6 +713,7 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
   }
   return;
 #endif
+#ifdef VP_EXPERIMENTS
   if constexpr (!STATS && TC % 4 == 0) {
     if (a.direct_epi) {
       long long* otab = reinterpret_cast<long long*>(smem + NST * BUF * 16 + 64);
@@ -883,302 +724,15 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
       return;
     }
   }
+#endif
   constexpr int RINGB = NST * BUF * 16;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
   staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
 }
 
-// ------------------------------------------------------------------------------------------------
-// igemm_wsw_kernel: igemm_ws_kernel with 128-byte K chunks (IgemmArgs::wide).  A DMA instruction then fetches 8 rows x 128
-// contiguous bytes instead of 16 x 64 (the memory system prefers the wider segments: the loop without MFMAs runs 16 % faster on the
-// Cin >= 256 layers) and a stage carries two MFMA k-steps per barrier.  LDS image of a 16-row tile: row i, 16-byte piece p at slot
-// 8i + (p ^ ((i >> 1) & 7)): the DMA writes slot = lane inside each 8-row block, so lane (r = lane >> 3, x = lane & 7) fetches piece
-// x ^ f(row); every ds_read_b128 service group of the fragment reads (lane (i, g) takes piece 4s + g) lands on 16 distinct slots
-// mod 16.  Packed weights use 128-byte chunks too (PackDesc::kc = 64 elements); sources must be multiples of 64 channels.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int WC, int WP, int TC, int TP, int NST, bool STATS = false>
-__global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_wsw_kernel(const IgemmArgs a) {
-  constexpr int E = Elem<T>::E, KCW = 8 * E;
-  constexpr int NPW = 4;
-  constexpr int NW = WC * WP, NT = (NW + NPW) * 64;
-  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
-  constexpr int NBA8 = BC / 8, NBB8 = BP / 8, NB8 = NBA8 + NBB8;
-  static_assert(NB8 % NPW == 0 && NBA8 % 2 == 0, "every producer issues the same number of DMAs per chunk");
-  constexpr int J = NB8 / NPW;
-  constexpr int BUF = 8 * (BC + BP);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* lds = reinterpret_cast<uint4*>(smem);
-  int* ltap = reinterpret_cast<int*>(lds + NST * BUF);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= NW;
-  const int cls = blockIdx.z;
-  const int P = a.N * a.Hg * a.Wg;
-  int pt, ct;
-  {
-    const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
-    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7, slot = id >> 3;
-    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    ct = logical % (int)gridDim.y; pt = logical / (int)gridDim.y;
-  }
-  const int p_base = pt * BP, c_base = ct * BC;
-  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
-  const int nchunk = a.Kpad / KCW;
-  const int wc = producer ? 0 : wave / WP, wpi = producer ? 0 : wave - wc * WP;
-  const int blkA0 = wc * TC, blkB0 = producer ? (1 << 20) : wpi * TP;
-  f32x4 acc[TC][TP];
-  __syncthreads();   // tap table visible
-
-  if (producer) {
-    const int pw = wave - NW;
-    const unsigned es = sizeof(T);
-    const T* x0 = reinterpret_cast<const T*>(a.x.ptr[0]);
-    const T* x1 = reinterpret_cast<const T*>(a.x.ptr[1]);
-    const int C0 = a.x.C[0], C1 = a.x.C[1];
-    __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
-    __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
-    __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(x1 ? (const void*)x1 : (const void*)x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * es));
-    const int r = lane >> 3, x = lane & 7;
-    unsigned wvo[J], pce[J];
-    int pn[J], pbh[J], pbw[J];
-    bool pok[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int b = pw + NPW * j;                               // 8-row block: weights (b < NBA8) or pixels
-      const int row16 = (b & 1) * 8 + r;
-      pce[j] = (unsigned)((x ^ ((row16 >> 1) & 7)) * E * es);   // byte offset of the 16-byte piece this lane fetches
-      wvo[j] = (unsigned)((c_base + b * 8 + r) * KCW * es) + pce[j];
-      const int pidx = p_base + (b - NBA8) * 8 + r;
-      pok[j] = b >= NBA8 && pidx < P;
-      const int hw = a.Hg * a.Wg;
-      const int pc = pok[j] ? pidx : 0;
-      const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
-      pn[j] = n * a.Hin; pbh[j] = q * a.sh; pbw[j] = (rem - q * a.Wg) * a.sw;
-    }
-    const unsigned wstep = (unsigned)(a.wp_rows * KCW * es);
-    unsigned wso = 0, xso = 0;
-    int left = 0, tap = 0, src = 0;
-    bool use1 = false;
-    unsigned xvo[J];
-    auto open_segment = [&]() {
-      const bool tok = tap < a.ntaps;
-      const int tv = ltap[tok ? tap : 0];
-      const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
-      use1 = src != 0;
-      const int Cs = use1 ? C1 : C0;
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int ih = pbh[j] + dh, iw = pbw[j] + dw;
-        const bool ok = pok[j] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-        xvo[j] = ok ? (unsigned)(((pn[j] + ih) * a.Win + iw) * Cs * es) + pce[j] : DMA_OOB;
-      }
-      left = Cs / KCW;
-      xso = 0;
-      if (!use1 && C1 > 0) src = 1; else { src = 0; ++tap; }
-    };
-    auto issue = [&](int buf) {
-      uint4* la = lds + buf * BUF;
-      uint4* lb = la + 8 * BC;
-      if (left == 0) open_segment();
-      const __amdgpu_buffer_rsrc_t rx = use1 ? rsX1 : rsX0;
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int b = pw + NPW * j;
-        if (b < NBA8) dma16_buf(rsW, wvo[j], wso, la + b * 64);
-        else dma16_buf(rx, xvo[j], xso, lb + (b - NBA8) * 64);
-      }
-      wso += wstep;
-      xso += KCW * es;
-      --left;
-    };
-#pragma unroll
-    for (int d = 0; d < NST - 1; ++d) if (d < nchunk) issue(d);
-    int st = 0;
-    for (int kc = 0; kc < nchunk; ++kc) {
-      if (kc + NST - 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * J) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int stn = st == 0 ? NST - 1 : st - 1;
-      if (kc + NST - 1 < nchunk) issue(stn);
-      st = st == NST - 1 ? 0 : st + 1;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < TC; ++i)
-#pragma unroll
-      for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int i16 = lane & 15, g4 = lane >> 4;
-    const int rowslot = i16 * 8, fsw = (i16 >> 1) & 7;
-    int st = 0;
-    for (int kc = 0; kc < nchunk; ++kc) {
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const uint4* la = lds + st * BUF;
-      const uint4* lb = la + 8 * BC;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int so = rowslot + ((4 * s + g4) ^ fsw);
-        uint4 fb[TP];
-#pragma unroll
-        for (int t = 0; t < TP; ++t) fb[t] = lb[(blkB0 + t) * 128 + so];
-#pragma unroll
-        for (int h = 0; h < TC; h += 4) {
-          uint4 fa[4];
-#pragma unroll
-          for (int t = 0; t < 4 && h + t < TC; ++t) fa[t] = la[(blkA0 + h + t) * 128 + so];
-#pragma unroll
-          for (int tc = 0; tc < 4 && h + tc < TC; ++tc)
-#pragma unroll
-            for (int tp = 0; tp < TP; ++tp) acc[h + tc][tp] = mma16<T>(fa[tc], fb[tp], acc[h + tc][tp]);
-        }
-      }
-      st = st == NST - 1 ? 0 : st + 1;
-    }
-  }
-  constexpr int RINGB = NST * BUF * 16;
-  constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
-  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
-}
-
-// ------------------------------------------------------------------------------------------------
-// igemm_wsr_kernel: 64-channel outputs with a short K (VGG conv1_2 and its backward, the backward-data of the 64-channel
-// stride-2 layers).  With a 64-row weight tile two thirds of what the tiled kernels move through the LDS-DMA path is pixels and one
-// third is the SAME 64 x K weight matrix, re-fetched by every block.  Here the whole matrix (K <= 576: <= 72 KB) is DMA'd into
-// LDS once per block and stays; the block is persistent and walks pixel tiles, so only the pixel operand streams through the
-// ring (4 producer waves, WP consumer waves as in igemm_ws_kernel, one barrier per K chunk, the pipeline runs across tiles).
-// The staged epilogue has its own LDS buffer because the producers already prefetch the next tile while a tile is stored.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int WP, int TP, int NST, bool STATS = false>
-__global__ __launch_bounds__((WP + 4) * 64) void igemm_wsr_kernel(const IgemmArgs a) {
-  constexpr int E = Elem<T>::E, KC = 4 * E;
-  constexpr int NPW = 4, TC = 4;
-  constexpr int NW = WP, NT = (NW + NPW) * 64;
-  constexpr int BC = 64, BP = WP * TP * 16;
-  constexpr int NBA = BC / 16, NBB = BP / 16;
-  static_assert(NBB % NPW == 0, "every producer issues the same number of pixel DMAs per chunk");
-  constexpr int J = NBB / NPW;
-  constexpr int BUFW = 4 * BC, BUFX = 4 * BP;
-  constexpr int NPASS = epi_passes(BC, BP, WP, VP_REGB_EPI_BYTES);
-  constexpr int EPIB = (BP / NPASS) * (BC * 4 + 16) + (BP / NPASS) * 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nchunk = a.Kpad / KC;
-  uint4* wres = reinterpret_cast<uint4*>(smem);                 // [nchunk][BUFW]
-  uint4* ring = wres + nchunk * BUFW;                           // [NST][BUFX]
-  char* epi = reinterpret_cast<char*>(ring + NST * BUFX);       // staged epilogue buffer
-  int* ltap = reinterpret_cast<int*>(epi + ((EPIB + 15) & ~15));
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= NW;
-  const int cls = blockIdx.z;
-  const int P = a.N * a.Hg * a.Wg;
-  const int ntile = (P + BP - 1) / BP;
-  const int c_base = blockIdx.y * BC;
-  if (tid < 16) ltap[tid] = (tid < a.ntaps) ? (((int)a.taps[cls].dh[tid] << 16) | ((int)a.taps[cls].dw[tid] & 0xffff)) : 0;
-  const int blkB0 = producer ? (1 << 20) : wave * TP;           // producers stage nothing in the epilogue
-  const int my_tiles = ((int)blockIdx.x < ntile) ? (ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  f32x4 acc[TC][TP];                                            // consumers only
-  __syncthreads();   // tap table visible
-
-  if (producer) {
-    const int pw = wave - NW;
-    const unsigned es = sizeof(T);
-    const T* x0 = reinterpret_cast<const T*>(a.x.ptr[0]);
-    const T* x1 = reinterpret_cast<const T*>(a.x.ptr[1]);
-    const int C0 = a.x.C[0], C1 = a.x.C[1];
-    __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
-    __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
-    __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(x1 ? (const void*)x1 : (const void*)x0, (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * es));
-    const int r = lane >> 2, g = (lane & 3) ^ rb_swz(lane >> 2);
-    // the weight matrix, once: 16-row block b of chunk kc -> wres[kc][b]
-    {
-      const unsigned wstep = (unsigned)(a.wp_rows * KC * es);
-      for (int idx = pw; idx < nchunk * NBA; idx += NPW) {
-        const int kc = idx / NBA, b = idx - kc * NBA;
-        dma16_buf(rsW, (unsigned)(((c_base + b * 16 + r) * KC + g * E) * es), (unsigned)kc * wstep, wres + kc * BUFW + b * 64);
-      }
-    }
-    // pixel stream: units u = tile_i * nchunk + kc, issued NST-1 ahead of the consumers, across tile boundaries
-    int it_tile = -1, it_kc = nchunk;                           // issue cursor (next unit to issue)
-    int pn[J], pbh[J], pbw[J];
-    bool pok[J];
-    unsigned xso = 0, xvo[J];
-    int left = 0, tap = 0, src = 0;
-    bool use1 = false;
-    const int total = my_tiles * nchunk;
-    int issued = 0;
-    auto next_tile = [&]() {
-      ++it_tile; it_kc = 0;
-      const int p_base = ((int)blockIdx.x + it_tile * (int)gridDim.x) * BP;
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int pidx = p_base + (pw + NPW * j) * 16 + r;
-        pok[j] = pidx < P;
-        const int hw = a.Hg * a.Wg;
-        const int pc = pok[j] ? pidx : 0;
-        const int n = pc / hw, rem = pc - n * hw, q = rem / a.Wg;
-        pn[j] = n * a.Hin; pbh[j] = q * a.sh; pbw[j] = (rem - q * a.Wg) * a.sw;
-      }
-      left = 0; tap = 0; src = 0;
-    };
-    auto open_segment = [&]() {
-      const bool tok = tap < a.ntaps;
-      const int tv = ltap[tok ? tap : 0];
-      const int dh = tv >> 16, dw = (int)(short)(tv & 0xffff);
-      use1 = src != 0;
-      const int Cs = use1 ? C1 : C0;
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int ih = pbh[j] + dh, iw = pbw[j] + dw;
-        const bool ok = pok[j] && tok && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-        xvo[j] = ok ? (unsigned)((((pn[j] + ih) * a.Win + iw) * Cs + g * E) * es) : DMA_OOB;
-      }
-      left = Cs / KC;
-      xso = 0;
-      if (!use1 && C1 > 0) src = 1; else { src = 0; ++tap; }
-    };
-    auto issue = [&]() {
-      if (it_kc == nchunk) next_tile();
-      if (left == 0) open_segment();
-      uint4* lb = ring + (issued % NST) * BUFX;
-      const __amdgpu_buffer_rsrc_t rx = use1 ? rsX1 : rsX0;
-#pragma unroll
-      for (int j = 0; j < J; ++j) dma16_buf(rx, xvo[j], xso, lb + (pw + NPW * j) * 64);
-      xso += KC * es;
-      --left; ++it_kc; ++issued;
-    };
-    for (int d = 0; d < NST - 1; ++d) if (issued < total) issue();
-    int u = 0;
-    for (int ti = 0; ti < my_tiles; ++ti) {
-      for (int kc = 0; kc < nchunk; ++kc, ++u) {
-        if (u + NST - 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * J) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (issued < total) issue();
-      }
-      const int p_base = ((int)blockIdx.x + ti * (int)gridDim.x) * BP;
-      staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, 0, blkB0, acc, epi, p_base / BP, cls);
-    }
-  } else {
-    int u = 0;
-    for (int ti = 0; ti < my_tiles; ++ti) {
-#pragma unroll
-      for (int i = 0; i < TC; ++i)
-#pragma unroll
-        for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int kc = 0; kc < nchunk; ++kc, ++u) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        mma_chunk_rb<T, TC, TP, BC, BP>(wres + kc * BUFW, ring + (u % NST) * BUFX, 0, blkB0, lane, acc);
-      }
-      const int p_base = ((int)blockIdx.x + ti * (int)gridDim.x) * BP;
-      staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, 0, blkB0, acc, epi, p_base / BP, cls);
-    }
-  }
-}
+#ifdef VP_EXPERIMENTS
+#include "experiments/igemm_experiments.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // conv_cin8_kernel: the first layers of the three nets (3- and 6-channel images padded to 8: VGG conv1_1, discriminator layer_1,
@@ -1391,140 +945,6 @@ __global__ __launch_bounds__(256) void deconv_cout4_kernel(const IgemmArgs a, in
     }
     tile = nxt;
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// igemm_patch_kernel: stride-1 convolutions (VGG 3x3, discriminator 4x4 s1, their backward-data) with the
-// input tile staged ONCE per channel chunk.  The 128 output pixels of a block are an 8 x 16 patch of one
-// image; the (8+k-1) x (16+k-1) input patch of a 64-byte channel chunk is DMA'd into LDS once and every tap
-// reads its B fragments from shifted positions of it, so the pixel operand moves ~k*k/1.4 times fewer bytes
-// through the vector-memory path than the gather-per-tap kernel (the step-1 bottleneck: TA ~ MFMA time).
-// Weights still stream per (chunk, tap) through the 3-deep ring.  K order = [chunk][tap].
-// ------------------------------------------------------------------------------------------------
-struct PatchPix {
-  const IgemmArgs& a; int n, y0, x0;
-  __device__ __forceinline__ long long operator()(int row) const {
-    const int y = y0 + (row >> 4), x = x0 + (row & 15);
-    if (y >= a.Hg || x >= a.Wg) return -1;
-    long long off = (((long long)n * a.Hof + y) * a.Wof + x) * a.ldY;
-    return (off << 8) | (long long)(n / a.ref_group_n);
-  }
-};
-
-template <typename T, int WC, int WP, int TC, int TP>
-__global__ __launch_bounds__(256) void igemm_patch_kernel(const IgemmArgs a) {
-  constexpr int E = Elem<T>::E, KC = 4 * E;
-  constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
-  static_assert(BP == 128, "8 x 16 pixel patch");
-  constexpr int NBA = BC / 16, JA = NBA / 4;
-  static_assert(NBA % 4 == 0, "every wave issues JA weight DMAs per iteration");
-  constexpr int ABUF = 4 * BC;                 // slots per weight stage
-  constexpr int PMAX = 224;                    // patch pixels (padded to 16): 11 x 19 = 209 for 4x4, 10 x 18 = 180 for 3x3
-  constexpr int PBUF = 4 * PMAX;
-  constexpr int JP = (PMAX / 16 + 3) / 4;      // patch DMA instructions per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* lds = reinterpret_cast<uint4*>(smem);
-  uint4* lpatch = lds + 3 * ABUF;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c_base = blockIdx.y * BC;
-  // block -> (image, tile row, tile col)
-  const int tx_n = (a.Wg + 15) >> 4, ty_n = (a.Hg + 7) >> 3;
-  const int bt = blockIdx.x;
-  const int n = bt / (tx_n * ty_n);
-  const int trem = bt - n * (tx_n * ty_n);
-  const int y0 = (trem / tx_n) * 8, x0 = (trem % tx_n) * 16;
-  // tap offset range (host guarantees stride 1)
-  int dh0 = 127, dw0 = 127, dh1 = -127, dw1 = -127;
-  for (int t = 0; t < a.ntaps; ++t) {
-    dh0 = min(dh0, (int)a.taps[0].dh[t]); dh1 = max(dh1, (int)a.taps[0].dh[t]);
-    dw0 = min(dw0, (int)a.taps[0].dw[t]); dw1 = max(dw1, (int)a.taps[0].dw[t]);
-  }
-  const int PW = 16 + dw1 - dw0, PH = 8 + dh1 - dh0;
-
-  // weight DMA rows and patch DMA pixels of this thread
-  const int r = lane >> 2, gp = (lane & 3) ^ rb_swz(lane >> 2);
-  const T* wrow[JA];
-#pragma unroll
-  for (int j = 0; j < JA; ++j)
-    wrow[j] = reinterpret_cast<const T*>(a.Wp) + ((size_t)c_base + (wave + 4 * j) * 16 + r) * KC + gp * E;
-  const T* prow[JP];
-  bool pok[JP];
-  const T* x0p = reinterpret_cast<const T*>(a.x.ptr[0]);
-#pragma unroll
-  for (int j = 0; j < JP; ++j) {
-    const int pp = (wave + 4 * j) * 16 + (lane >> 2);          // patch pixel of this lane
-    const int py = pp / PW, px = pp - py * PW;
-    const int iy = y0 + dh0 + py, ix = x0 + dw0 + px;
-    pok[j] = pp < PH * PW && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-    // LDS slot of (pixel pp, piece g) is pp*4 + (g ^ rb_swz(pp)); the DMA writes slot = lane, i.e. piece (lane&3)^swz
-    const int g = (lane & 3) ^ rb_swz(pp & 15);
-    prow[j] = x0p + ((size_t)(n * a.Hin + iy) * a.Win + ix) * a.Cin + g * E;
-  }
-
-  f32x4 acc[TC][TP];
-#pragma unroll
-  for (int i = 0; i < TC; ++i)
-#pragma unroll
-    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nc = a.Cin / KC, nt = a.ntaps;
-  const int niter = nc * nt;
-  auto issue_w = [&](int it, int st) {          // weights of iteration it = (chunk, tap): k offset tap*Cin + chunk*KC
-    const int c = it / nt, t = it - c * nt;
-    uint4* la = lds + st * ABUF;
-#pragma unroll
-    for (int j = 0; j < JA; ++j) dma16(wrow[j] + (size_t)(t * nc + c) * a.wp_rows * KC, la + (wave + 4 * j) * 64);
-  };
-  auto issue_p = [&](int c, int buf) {
-    uint4* lp = lpatch + buf * PBUF;
-#pragma unroll
-    for (int j = 0; j < JP; ++j)
-      if ((wave + 4 * j) * 16 < PMAX) dma16(pok[j] ? (const void*)(prow[j] + c * KC) : a.zeros, lp + (wave + 4 * j) * 64);
-  };
-
-  const int wc = wave / WP, wpi = wave - wc * WP;
-  const int blkA0 = wc * TC, rowB0 = wpi * TP;   // first pixel row (of 8) of this wave
-  const int i16 = lane & 15, g4 = lane >> 4;
-  const int aso = i16 * 4 + (g4 ^ rb_swz(i16));
-
-  issue_p(0, 0);
-  issue_w(0, 0);
-  if (niter > 1) issue_w(1, 1);
-  int st = 0;
-  for (int it = 0; it < niter; ++it) {
-    const int c = it / nt, t = it - c * nt;
-    if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (t == 0 && c + 1 < nc) issue_p(c + 1, (c + 1) & 1);      // older than the weight DMA below: waited one iteration later
-    if (it + 2 < niter) issue_w(it + 2, st == 0 ? 2 : st - 1);
-    // B fragments: pixel (row + dh - dh0, i + dw - dw0) of the patch
-    int tdh = 0, tdw = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) if (k == t) { tdh = a.taps[0].dh[k]; tdw = a.taps[0].dw[k]; }
-    const uint4* la = lds + st * ABUF;
-    const uint4* lp = lpatch + (c & 1) * PBUF;
-    uint4 fa[TC], fb[TP];
-#pragma unroll
-    for (int k = 0; k < TC; ++k) fa[k] = la[(blkA0 + k) * 64 + aso];
-#pragma unroll
-    for (int k = 0; k < TP; ++k) {
-      const int pp = (rowB0 + k + tdh - dh0) * PW + i16 + tdw - dw0;
-      fb[k] = lp[pp * 4 + (g4 ^ rb_swz(pp & 15))];
-    }
-#pragma unroll
-    for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-      for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], fb[tp], acc[tc][tp]);
-    st = st == 2 ? 0 : st + 1;
-  }
-
-  constexpr int RINGB = (3 * ABUF + 2 * PBUF) * 16;
-  constexpr int NPASS = (BP * (BC * 4 + 16) + BP * 8 <= RINGB) ? 1 : 2;
-  staged_epilogue<T, TC, TP, BC, BP, NPASS, 256>(a, PatchPix{a, n, y0, x0}, c_base, blkA0, rowB0, acc, smem);
 }
 
 // sums the split-K slabs in a fixed order (deterministic) and applies the igemm epilogue
@@ -1953,14 +1373,19 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
     IgemmArgs b = a;
     b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
     // register-direct epilogue: measured SLOWER than the LDS-staged one (64-byte store segments vs 256-byte rows): opt-in
+#ifdef VP_EXPERIMENTS
     static const bool direct_on = getenv("VP_DIRECT_EPI") != nullptr;
     b.direct_epi = (direct_on && a.rowperm && b.vec_epi) ? 1 : 0;
+#else
+    b.direct_epi = 0;
+#endif
     // scalar-stepped loader: every 64-byte K chunk inside one tap and one source tensor, sources below the 2 GiB lane-offset range
     constexpr int KCE = 16 * 4 / (int)sizeof(T);
     const size_t xb0 = (size_t)a.N * a.Hin * a.Win * a.x.C[0] * sizeof(T), xb1 = (size_t)a.N * a.Hin * a.Win * a.x.C[1] * sizeof(T);
     static const bool fast_on = !getenv("VP_NO_FASTK");
     b.fastk = (fast_on && a.Cin % KCE == 0 && a.x.C[0] % KCE == 0 && a.x.C[1] % KCE == 0 && a.x.C[0] + a.x.C[1] == a.Cin &&
                xb0 < 0x70000000ull && xb1 < 0x70000000ull) ? 1 : 0;
+#ifdef VP_EXPERIMENTS
     // 128-byte K chunks (plan-time decision: the packed weights are laid out for it)
     if (a.wide) {
       if constexpr (((BC + BP) / 8) % 4 == 0 && NW <= 8 && TC % 4 == 0) {
@@ -1982,6 +1407,10 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
       }
       return hipErrorInvalidValue;     // a wide plan must run on the wide kernel
     }
+#else
+    if (a.wide) return hipErrorInvalidValue;   // 128-byte-chunk plans exist only in the experiments build
+#endif
+#ifdef VP_EXPERIMENTS
     // resident-weight persistent kernel for 64-channel outputs with K <= 576 (conv1_2 and the 64-channel backward-data passes)
     if constexpr (BC == 64 && BP == 128) {
       static const bool wsr_on = getenv("VP_WSR") != nullptr;   // opt-in: measured SLOWER (conv1_2 0.66 vs 0.53 ms) - one 12-wave block per CU
@@ -2007,11 +1436,14 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         return hipGetLastError();
       }
     }
+#endif
+#ifdef VP_EXPERIMENTS
     // register-double-buffered kernel for the 128-accumulator tiles (256x256, 128x512): conv_db.hip
     if constexpr (NW == 8 && TC == 8 && TP == 4) {
       static const bool db_on = getenv("VP_DB") != nullptr;   // opt-in: measured no faster than the wave-specialised 256x256 kernel (round 2)
       if (db_on && b.vec_epi && b.fastk && a.splitk == 1) return launch_igemm_db(b, sizeof(T) == 2, BC, grid, st);
     }
+#endif
     // wave-specialised kernel, per tile shape (bit = launch_igemm cfg index): measured gains for 128x128 (cfg 0), 64x128 (cfg 1), 256x256 (cfg 7); 128x256 is faster without
     static const int ws_cfgs = getenv("VP_WS_CFG") ? atoi(getenv("VP_WS_CFG")) : ((1 << 0) | (1 << 1) | (1 << 7));
     constexpr int my_cfg = (BC == 128 && BP == 128) ? 0 : (BC == 64 && BP == 128) ? 1 : (BC == 128 && BP == 256) ? 6 : (BC == 256 && BP == 256) ? 7 :
@@ -2029,6 +1461,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         return hipGetLastError();
       }
     }
+#ifdef VP_EXPERIMENTS
     static const int regb_on = getenv("VP_REGB") ? atoi(getenv("VP_REGB")) : 0;   // measured slower (round 1): opt-in experiment
     if constexpr ((BC / 16) % NW == 0) {
       if (regb_on && b.vec_epi && b.fastk && a.splitk == 1 && !b.bn_part) {
@@ -2040,6 +1473,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         return hipGetLastError();
       }
     }
+#endif
     if (b.vec_epi && b.bn_part) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, true>), grid, dim3(NW * 64), smem, st, b);
     else if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(NW * 64), smem, st, b);
@@ -2050,6 +1484,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+#ifdef VP_EXPERIMENTS
 template <typename T, int WC, int WP, int TC, int TP>
 static hipError_t launch_patch_cfg(const IgemmArgs& a, hipStream_t st) {
   constexpr int BC = WC * TC * 16;
@@ -2073,6 +1508,8 @@ static bool patch_ok(const IgemmArgs& a, int kc) {
          a.Cin % kc == 0 && a.Cin == a.x.C[0] && a.Wg >= 16 && a.Hg >= 8 && a.Cout % 8 == 0 && a.ldY % 8 == 0 &&
          !a.x.aff_a[0] && a.x.act == ACT_NONE && a.Hof == a.Hg && a.Wof == a.Wg;
 }
+
+#endif
 
 template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int cfg, hipStream_t st) {
   hipError_t e;
@@ -2125,10 +1562,21 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       return hipGetLastError();
     }
   }
+  if (a.patch) {   // stride-1 convs with the input patch staged once per channel chunk (conv_patch.hip)
+    ProfScope prof("patch", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
+                   es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+    return launch_igemm_patch(a, sizeof(T) == 2, pbc, pbp, st);
+  }
+#ifdef VP_EXPERIMENTS
   const bool use_patch = (cfg == 0 || cfg == 1) && patch_ok(a, 4 * Elem<T>::E);
+#else
+  const bool use_patch = false;
+#endif
   ProfScope prof(use_patch ? "patch" : "igemm", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
                  es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+#ifdef VP_EXPERIMENTS
   if (use_patch) return cfg == 0 ? launch_patch_cfg<T, 2, 2, 4, 4>(a, st) : launch_patch_cfg<T, 1, 4, 4, 2>(a, st);
+#endif
   switch (cfg) {
     case 0: e = launch_igemm_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 ch x 128 px
     case 1: e = launch_igemm_cfg<T, 1, 4, 4, 2>(a, st); break;   //  64 ch x 128 px
@@ -2139,7 +1587,9 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     case 6: e = launch_igemm_cfg<T, 2, 4, 4, 4>(a, st); break;   // 128 ch x 256 px, 8 waves
     case 7: e = launch_igemm_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 ch x 256 px, 8 waves
     case 8: e = launch_igemm_cfg<T, 1, 4, 4, 4>(a, st); break;   //  64 ch x 256 px, 4 waves
-    case 9: e = launch_igemm_cfg<T, 1, 8, 8, 4>(a, st); break;   // 128 ch x 512 px, 8 waves
+#ifdef VP_EXPERIMENTS
+    case 9: e = launch_igemm_cfg<T, 1, 8, 8, 4>(a, st); break;   // 128 ch x 512 px, 8 waves (conv_db.hip)
+#endif
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -2158,7 +1608,8 @@ hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st
 }
 
 void igemm_tile(int cfg, int* bc, int* bp) {
-  static const int t[10][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}, {128, 256}, {256, 256}, {64, 256}, {128, 512}};
+  static const int t[16][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}, {128, 256}, {256, 256}, {64, 256}, {128, 512},
+                               {256, 256}, {128, 512}, {64, 512}, {128, 256}, {64, 256}, {256, 128}};     // 10..15: patch kernel tiles (conv_ops.h patch_tile_hw)
   *bc = t[cfg][0]; *bp = t[cfg][1];
 }
 
@@ -2193,8 +1644,10 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
   switch (cfg) {
     case 0: e = launch_wgrad_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 rows x 128 cols
     case 1: e = launch_wgrad_cfg<T, 2, 2, 4, 2>(a, st); break;   // 128 rows x  64 cols
-    case 3: e = launch_wgrad_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 rows x 256 cols, 8 waves
+#ifdef VP_EXPERIMENTS
+    case 3: e = launch_wgrad_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 rows x 256 cols, 8 waves (VP_WGBIG: measured no faster)
     case 4: e = launch_wgrad_cfg<T, 2, 4, 8, 2>(a, st); break;   // 256 rows x 128 cols, 8 waves
+#endif
     case 2: e = launch_wgrad_cfg<T, 4, 1, 2, 1>(a, st); break;   // 128 rows x  16 cols
     default: return hipErrorInvalidValue;
   }

@@ -39,11 +39,13 @@ inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
     if (rows % bc == 0) return force;
   }
   if (P >= 96) {
+#ifdef VP_EXPERIMENTS
     // 128-accumulator tiles on the register-double-buffered kernel (one 8-wave block per CU): VP_DBTILE bit 0: 256x256, bit 1: 128x512
     static const int dbt = getenv("VP_DBTILE") ? atoi(getenv("VP_DBTILE")) : 0;
     static const int dbk = getenv("VP_DB_MINK") ? atoi(getenv("VP_DB_MINK")) : 512;
     if ((dbt & 1) && rows % 256 == 0 && P >= 256 * 256 && Kpad >= dbk) return 7;
     if ((dbt & 2) && rows % 128 == 0 && rows % 256 != 0 && P >= 256 * 512 && Kpad >= dbk) return 9;
+#endif
     // 256x256 runs one block per CU: its prologue / epilogue are exposed, only long K loops amortise them
     if ((big & 2) && rows % 256 == 0 && P >= 256 * 256 && Kpad >= 4096) return 7;
     if ((big & 1) && rows % 128 == 0 && P >= 256 * 512) return 6;
@@ -129,6 +131,78 @@ inline void plan_make_wide(IgemmPlan& p, int is_bf16) {
   p.pack.Kpad = a.Kpad;
   p.pack.kc = kcw;
   p.pack_elems = (size_t)a.nclass * a.wp_rows * a.Kpad;
+}
+
+// Patch kernel (conv_patch.hip) for stride-1 convolutions and their backward-data passes: a plan-time decision because the packed
+// weights are stored with PackDesc::kswap.  single_src: the layer reads one tensor (no virtual concat).
+// tuning knobs that tests and experiments may change at run time (vp_tune): which patch tiles are allowed (bit 0: 256-row, bit 1:
+// 128-row, bit 2: 64-row) and the smallest grid worth one 8-wave block per CU
+inline int& patch_tiles_knob() { static int v = getenv("VP_PATCH2") ? atoi(getenv("VP_PATCH2")) : 7; return v; }
+inline int& patch_small_knob() { static int v = getenv("VP_PATCH2_SMALL") ? atoi(getenv("VP_PATCH2_SMALL")) : 3; return v; }   // two-blocks-per-CU tiles (see patch_tile_pixels)
+inline int& patch_longk_knob() { static int v = getenv("VP_PATCH2_LONGK") ? atoi(getenv("VP_PATCH2_LONGK")) : 1; return v; }      // 1: long-K 512-row layers stay on the 256x256 tile
+inline int& patch_minblk_knob() { static int v = getenv("VP_PATCH2_MINBLK") ? atoi(getenv("VP_PATCH2_MINBLK")) : 384; return v; }
+
+// pixel tile of a patch-kernel plan: bp = 512 -> 16 x 32, 256 -> 16 x 16, 128 -> 8 x 16
+inline void patch_tile_hw(int bp, int* th, int* tw) { *th = bp == 128 ? 8 : 16; *tw = bp == 512 ? 32 : 16; }
+// pixels of the tile chosen for `bc` channel rows: knob bit 0: two-blocks-per-CU 16 x 16 tiles for the 128- / 64-row variants
+// (else 16 x 32, one block per CU); bit 1: 8 x 16 tiles, two blocks per CU, for the 256-row variant (else 16 x 16, one block)
+inline int patch_tile_pixels(int bc) {
+  const int k = patch_small_knob();
+  if (bc == 256) return (k & 2) ? 128 : 256;
+  return (k & 1) ? 256 : 512;
+}
+
+// channel rows of the patch tile for a layer of `rows` output channels: the largest enabled tile that divides it (0: none)
+inline int patch_tile_rows(int rows, int on) {
+  if ((on & 1) && rows % 256 == 0) return 256;
+  if ((on & 2) && rows % 128 == 0) return 128;
+  if ((on & 4) && rows % 64 == 0) return 64;
+  return 0;
+}
+
+inline bool plan_patch_eligible(const IgemmPlan& p, int rows, int is_bf16, bool single_src) {
+  const int on = patch_tiles_knob();
+  const int minblk = patch_minblk_knob();
+  const IgemmArgs& a = p.a;
+  const int kc = kc_elems(is_bf16);
+  if (!on || !single_src || a.nclass != 1 || a.sh != 1 || a.sw != 1 || a.os != 1 || a.ntaps < 9 || a.Cin % kc || a.Cin < kc) return false;
+  if (rows % 64 || a.Cout % 8 || a.ldY % 8 || a.Hg < 16 || a.Wg < 16 || a.Hof != a.Hg || a.Wof != a.Wg) return false;
+  // >= 512 output channels with a long K loop (discriminator layer_4 forward): measured faster on the wave-specialised 256x256 tile
+  // (0.32 vs 0.36 ms at N = 32), whose exposed prologue / epilogue that loop amortises
+  if (patch_longk_knob() && rows >= 512 && rows % 256 == 0 && a.ntaps * a.Cin >= 4096 && (long long)a.N * a.Hg * a.Wg >= 256 * 256) return false;
+  const int bc = patch_tile_rows(rows, on);
+  if (!bc) return false;
+  int th, tw;
+  patch_tile_hw(patch_tile_pixels(bc), &th, &tw);
+  const long long blocks = (long long)a.N * ((a.Hg + th - 1) / th) * ((a.Wg + tw - 1) / tw) * (rows / bc);
+  if (blocks < minblk) return false;
+  if ((size_t)a.N * a.Hin * a.Win * a.Cin * (is_bf16 ? 2 : 4) >= 0x70000000ull) return false;     // lane offsets of the buffer loads
+  // taps on a regular grid
+  int ks = 0;
+  while (ks * ks < a.ntaps) ++ks;
+  if (ks * ks != a.ntaps) return false;
+  const int sh = a.taps[0].dh[ks] - a.taps[0].dh[0], sw = a.taps[0].dw[1] - a.taps[0].dw[0];
+  if ((sh != 1 && sh != -1) || (sw != 1 && sw != -1)) return false;
+  for (int t = 0; t < a.ntaps; ++t)
+    if (a.taps[0].dh[t] != a.taps[0].dh[0] + (t / ks) * sh || a.taps[0].dw[t] != a.taps[0].dw[0] + (t % ks) * sw) return false;
+  return true;
+}
+inline void plan_make_patch(IgemmPlan& p, int rows, int is_bf16) {
+  IgemmArgs& a = p.a;
+  const int bc = patch_tile_rows(rows, patch_tiles_knob());
+  int ks = 0;
+  while (ks * ks < a.ntaps) ++ks;
+  a.patch = 1; a.p_kw = ks;
+  a.p_dhf = a.taps[0].dh[0]; a.p_dwf = a.taps[0].dw[0];
+  a.p_dhs = a.taps[0].dh[ks] - a.taps[0].dh[0]; a.p_dws = a.taps[0].dw[1] - a.taps[0].dw[0];
+  const int bp = patch_tile_pixels(bc);
+  p.cfg = bc == 256 ? (bp == 128 ? 15 : 10) : (bc == 128 ? (bp == 256 ? 13 : 11) : (bp == 256 ? 14 : 12));
+  a.CoutPad = round_up(rows, bc);
+  a.splitk = 1;
+  p.partial_bytes = 0;
+  a.rowperm = 1;
+  p.pack.perm = 1;
+  p.pack.kswap = 1;
 }
 
 // x (PixSrc, total channels g.Cin) -> y [N,Hout,Wout,ldY]

@@ -119,6 +119,7 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
   }
 }
 
+#ifdef VP_EXPERIMENTS
 // Direct epilogue (opt-in, IgemmArgs::direct_epi; measured slower than the staged one): with the permuted weight rows a lane's accumulators ARE two runs of 8 consecutive channels
 // per pixel and 64-row block, so the tile needs no LDS round trip: per pixel tile the lane finishes and stores its 16-byte runs
 // straight from registers (the four lanes of a pixel write 64 contiguous bytes per store).  Only the per-row output offsets come
@@ -145,6 +146,8 @@ __device__ __forceinline__ void direct_epilogue(const IgemmArgs& a, const long l
       }
   }
 }
+
+#endif
 
 // STATS (a batch-normalised layer): the epilogue also produces the layer's batch statistics.  While a pass's f32 tile sits in
 // LDS, thread t sums column (channel) t % BC over its share of the rows - of the values AS STORED, i.e. rounded to T - into two

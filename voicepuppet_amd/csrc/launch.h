@@ -9,6 +9,7 @@ namespace vp {
 
 hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st);
 void igemm_tile(int cfg, int* bc, int* bp);
+hipError_t launch_igemm_patch(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                    // conv_patch.hip
 hipError_t launch_igemm_db(const IgemmArgs& b, int is_bf16, int bc, dim3 grid, hipStream_t st);   // conv_db.hip
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
 void wgrad_tile(int cfg, int* bm, int* bn);
@@ -31,6 +32,7 @@ hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int
                             void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st);
 hipError_t launch_tap_gather(const TapArgs& a, hipStream_t st);
 hipError_t launch_tap_spread(const TapArgs& a, int is_bf16, hipStream_t st);
+hipError_t launch_frame_pack(const FramePackArgs& a, hipStream_t st);
 hipError_t launch_pack_inputs(const PackInputsArgs& a, int is_bf16, hipStream_t st);
 int composite_nblocks(int N, int HW);
 hipError_t launch_composite_fwd(const CompositeArgs& a, int is_bf16, hipStream_t st);

@@ -1,6 +1,8 @@
 // Stand-alone op entry points of the C ABI (parity tests drive the same kernels the step executor uses).
 #include <string.h>
 
+#include <string>
+
 #include "conv_ops.h"
 #include "errors.h"
 #include "audio_args.h"
@@ -38,13 +40,38 @@ const void* zero_page(char* ws, size_t used, hipStream_t st) {
 
 extern "C" {
 
+int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned char* current_frames, const int* crops,
+                            int n, int img_size, float* inputs, float* fg_inputs, float* targets, float* masks, void* stream) {
+  if (!example_frames || !current_frames || !crops || !inputs || !fg_inputs || !targets || !masks || n < 1 || img_size < 2) {
+    set_err("vp_pixrefer_pack_frames: bad argument");
+    return VP_ERR_ARG;
+  }
+  FramePackArgs a;
+  a.ex = example_frames; a.cur = current_frames; a.crops = crops;
+  a.inputs = inputs; a.fg_inputs = fg_inputs; a.targets = targets; a.masks = masks;
+  a.N = n; a.S = img_size;
+  VP_HIP_CHECK(launch_frame_pack(a, (hipStream_t)stream));
+  return VP_OK;
+}
+
+int vp_tune(const char* key, int value) {
+  if (!key) return VP_ERR_ARG;
+  const std::string k(key);
+  if (k == "patch_tiles") { patch_tiles_knob() = value; return VP_OK; }
+  if (k == "patch_min_blocks") { patch_minblk_knob() = value; return VP_OK; }
+  if (k == "patch_small_tiles") { patch_small_knob() = value; return VP_OK; }
+  if (k == "patch_long_k_on_256") { patch_longk_knob() = value; return VP_OK; }
+  set_err("vp_tune: unknown key %s", key);
+  return VP_ERR_ARG;
+}
+
 size_t vp_conv_workspace_bytes(const vp_conv_desc* d) {
   if (!conv_desc_ok(d)) return 0;
   const int bf = d->dtype == VP_BF16, es = bf ? 2 : 4;
   const ConvGeomX g = geom_of(d);
   size_t best = 0;
   {
-    IgemmPlan p = plan_fwd(g, 0, bf);
+    IgemmPlan p = plan_fwd(g, 0, bf);      // (the patch-kernel plan of the same layer needs no more: same packed block, no split-K slab)
     best = align256(p.pack_elems * es) + p.partial_bytes;
   }
   if ((d->cout & (d->cout - 1)) == 0 && d->cout >= 8) {
@@ -64,6 +91,8 @@ int vp_conv_fwd(const vp_conv_desc* d, const void* x, const float* in_scale, con
   hipStream_t st = (hipStream_t)stream;
   const ConvGeomX g = geom_of(d);
   IgemmPlan p = plan_fwd(g, 0, bf);
+  // the patch kernel moves plain bytes (LDS-DMA): only inputs that need no deferred affine / activation
+  if (d->in_act == ACT_NONE && !in_scale && plan_patch_eligible(p, g.Cout, bf, true)) plan_make_patch(p, g.Cout, bf);
   char* ws = (char*)workspace;
   VP_HIP_CHECK(launch_pack_weights_one(p.pack, w, ws, bf, st));
   IgemmArgs a = p.a;
@@ -83,6 +112,7 @@ int vp_conv_bwd_data(const vp_conv_desc* d, const void* dy, const float* w, void
   hipStream_t st = (hipStream_t)stream;
   const ConvGeomX g = geom_of(d);
   IgemmPlan p = plan_bwd_data(g, 0, 0, d->cin, d->cin, d->cin, bf);
+  if (plan_patch_eligible(p, d->cin, bf, true)) plan_make_patch(p, d->cin, bf);
   char* ws = (char*)workspace;
   VP_HIP_CHECK(launch_pack_weights_one(p.pack, w, ws, bf, st));
   IgemmArgs a = p.a;

@@ -42,7 +42,7 @@ struct Arena {
   }
 };
 
-struct BnBuf { float *a, *b, *mu, *rstd, *c1, *c2; };
+struct BnBuf { float *a, *b, *mu, *rstd, *c1, *c2, *c1g, *c2g; };   // c1g / c2g: the generator-loss pass through the discriminator
 
 struct Tens {
   std::string name;
@@ -53,6 +53,8 @@ struct Tens {
   bool has_bn = false;
   bool is_input = false;
   bool dz_written = false;
+  void* dz2 = nullptr;    // discriminator tensors: gradient buffer of the generator-loss pass (fake group only), so that pass can run
+  bool dz2_written = false;   // concurrently with the discriminator-loss pass, which owns dz
   void* xa[3] = {nullptr, nullptr, nullptr};   // materialised act(bn(y)) per vp::Act (lrelu, relu) for the consumers
   bool need_act[3] = {false, false, false};
   BnBuf bn{};
@@ -69,7 +71,7 @@ struct Layer {
   int out = -1;
   bool has_bn = false;
   size_t w_off = 0, b_off = 0, gamma_off = 0, beta_off = 0;
-  size_t pk_fwd = 0, pk_bwd[2] = {0, 0};
+  size_t pk_fwd = 0, pk_bwd[2] = {0, 0}, pk_bwd_alt[2] = {0, 0};   // pk_bwd_alt == pk_bwd unless the two batch sizes run different kernel families
   bool need_bwd[2] = {false, false};
   IgemmPlan fwd, bwd[2], bwd_alt[2];   // bwd_alt: discriminator G-loss pass (batch N)
   WgradPlan wg;
@@ -110,6 +112,11 @@ struct vp_pixrefer {
   void *vpool1, *vpool2, *d_vpool1, *d_vpool2;
   double *comp_partial, *perc_partial, *bn_partial;
   char* scratch;
+  char* scratch2;             // split-K / slab scratch and batch-norm partials of the side stream (backward_d when overlapped)
+  double* bn_partial2;
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
+  bool overlap;
   void* zeros;
   size_t scratch_bytes;
   int n_comp, n_perc;
@@ -253,6 +260,7 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       bool srcs_ok = true;
       for (int s = 0; s < L.nsrc; ++s) srcs_ok = srcs_ok && n.t[L.src[s]].C % (2 * kc_elems(bf16)) == 0;
       if (plan_wide_eligible(L.fwd, bf16, srcs_ok, true) && !(L.g.Cout < 8)) plan_make_wide(L.fwd, bf16);
+      else if (plan_patch_eligible(L.fwd, L.g.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == L.g.Cin)) plan_make_patch(L.fwd, L.g.Cout, bf16);
     }
     take(L.fwd);
     L.pk_fwd = L.fwd.pack.dst_off;
@@ -282,12 +290,23 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
           bool wide = plan_wide_eligible(L.bwd[s], bf16, dy_ok, true);
           if (alt_batch > 0) wide = wide && plan_wide_eligible(L.bwd_alt[s], bf16, dy_ok, true);
           if (wide) { plan_make_wide(L.bwd[s], bf16); if (alt_batch > 0) plan_make_wide(L.bwd_alt[s], bf16); }
+          else {
+            // backward-data of a stride-1 conv is a stride-1 conv over dY (one tensor of CoutT channels): patch kernel, per batch size
+            if (plan_patch_eligible(L.bwd[s], rows, bf16, true)) plan_make_patch(L.bwd[s], rows, bf16);
+            if (alt_batch > 0 && plan_patch_eligible(L.bwd_alt[s], rows, bf16, true)) plan_make_patch(L.bwd_alt[s], rows, bf16);
+          }
         }
         take(L.bwd[s]);
-        L.pk_bwd[s] = L.bwd[s].pack.dst_off;
+        L.pk_bwd[s] = L.pk_bwd_alt[s] = L.bwd[s].pack.dst_off;
         if (alt_batch > 0) {
-          L.bwd_alt[s].pack.dst_off = L.pk_bwd[s];
-          if (L.bwd_alt[s].partial_bytes > *scratch_max) *scratch_max = L.bwd_alt[s].partial_bytes;
+          const PackDesc &pa = L.bwd[s].pack, &pb = L.bwd_alt[s].pack;
+          if (pa.kswap != pb.kswap || pa.perm != pb.perm || pa.kc != pb.kc || pa.Kpad != pb.Kpad) {
+            take(L.bwd_alt[s]);                       // the two batch sizes run different kernel families: one packed block each
+            L.pk_bwd_alt[s] = L.bwd_alt[s].pack.dst_off;
+          } else {
+            L.bwd_alt[s].pack.dst_off = L.pk_bwd[s];
+            if (L.bwd_alt[s].partial_bytes > *scratch_max) *scratch_max = L.bwd_alt[s].partial_bytes;
+          }
         }
       }
       row0 += rows;
@@ -319,6 +338,7 @@ static void carve_net(Net& n, Arena& ar, int es, bool training) {
       t.bn.a = (float*)ar.alloc(gc); t.bn.b = (float*)ar.alloc(gc);
       t.bn.mu = (float*)ar.alloc(gc); t.bn.rstd = (float*)ar.alloc(gc);
       t.bn.c1 = (float*)ar.alloc(gc); t.bn.c2 = (float*)ar.alloc(gc);
+      t.bn.c1g = (float*)ar.alloc(gc); t.bn.c2g = (float*)ar.alloc(gc);
     }
   }
   for (Layer& L : n.l) {
@@ -363,7 +383,7 @@ static size_t carve_all(vp_pixrefer* h, char* base, size_t cap) {
     carve_net(h->V, ar, es, true);
     // gradient buffers.  generator + discriminator: one per non-input tensor.
     for (Tens& t : h->G.t) if (!t.is_input && t.name != "decoder_1") t.dz = ar.alloc(t.elems() * es);
-    for (Tens& t : h->D.t) if (!t.is_input && t.name != "layer_5") t.dz = ar.alloc(t.elems() * es);
+    for (Tens& t : h->D.t) if (!t.is_input && t.name != "layer_5") { t.dz = ar.alloc(t.elems() * es); t.dz2 = ar.alloc(t.elems() / 3 * es); }
     // VGG backward runs on the fake half only
     for (Tens& t : h->V.t) if (!t.is_input) t.dz = ar.alloc(t.elems() / 2 * es);
     h->n_comp = composite_nblocks(N, H * H);
@@ -374,6 +394,10 @@ static size_t carve_all(vp_pixrefer* h, char* base, size_t cap) {
   h->zeros = ar.alloc(256);
   h->bn_partial = (double*)ar.alloc((size_t)1024 * 2 * 512 * sizeof(double));
   h->scratch = (char*)ar.alloc(h->scratch_bytes);
+  if (d.training) {
+    h->bn_partial2 = (double*)ar.alloc((size_t)1024 * 2 * 512 * sizeof(double));
+    h->scratch2 = (char*)ar.alloc(h->scratch_bytes);
+  }
   return ar.off + 256;
 }
 
@@ -473,8 +497,11 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
     int bc, bp;
     igemm_tile(L.fwd.cfg, &bc, &bp);
     const int pg = (n.batch / n.groups) * a.Hg * a.Wg;            // pixels of one group, per class
-    if (n.groups == 1 || pg % bp == 0) {
-      const int tpg = (pg + bp - 1) / bp;
+    if (a.patch || n.groups == 1 || pg % bp == 0) {
+      // patch kernel: 2-D tiles of one image each (16 x 16 or 16 x 32 pixels), never across images or groups
+      int pth = 16, ptw = 16;
+      patch_tile_hw(bp, &pth, &ptw);
+      const int tpg = a.patch ? (n.batch / n.groups) * ((a.Hg + pth - 1) / pth) * ((a.Wg + ptw - 1) / ptw) : (pg + bp - 1) / bp;
       stat_chunks = a.nclass * tpg;
       if ((size_t)n.groups * stat_chunks * 2 * to.C <= (size_t)1024 * 2 * 512) {
         a.bn_part = h->bn_partial; a.bn_tpg = tpg; a.bn_nchunk = stat_chunks;
@@ -508,9 +535,12 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
 // backward of one layer given dL/dy in `dy` (dtype T, channel stride g.CoutT):
 //   weight/bias/BN gradients (when grads != null) and dz of every source tensor.
 // sample0/nb/group0/ng select a sub-batch (discriminator G-loss pass: the fake group only).
+// side: the call runs on the side stream (its own scratch); gpass: generator-loss pass through the discriminator (dz2 buffers)
 static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool want_dw, bool alt,
-                         int sample0, int nb, int group0, hipStream_t st) {
+                         int sample0, int nb, int group0, hipStream_t st, bool side = false, bool gpass = false) {
   const int es = h->es;
+  char* scratch = side ? h->scratch2 : h->scratch;
+  double* bn_partial = side ? h->bn_partial2 : h->bn_partial;
   const int group_n = n.batch / n.groups;
   if (want_dw) {
     WgradArgs w = L.wg.a;
@@ -528,7 +558,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       set_single_src(w.g, L.tap_dyS, 16, nullptr, nullptr, ACT_NONE, 0);
       w.d = xs;
     }
-    w.partial = (float*)h->scratch;
+    w.partial = (float*)scratch;
     w.dW = n.grads + L.w_off;
     w.accumulate = 0;
     w.zeros = h->zeros;
@@ -542,7 +572,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       memset(&b, 0, sizeof(b));
       b.y = dy; b.C = L.g.CoutT; b.G = 1; b.Pg = nb * L.g.Hout * L.g.Wout;
       b.nchunk = bn_nchunk(b.Pg, b.C, 1, h->bf16);
-      b.partial = h->bn_partial;
+      b.partial = bn_partial;
       VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
     }
   }
@@ -551,15 +581,16 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     Tens& ts = n.t[L.src[s]];
     IgemmArgs a = alt ? L.bwd_alt[s].a : L.bwd[s].a;
     set_single_src(a.x, dy, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
-    a.Wp = n.packed + L.pk_bwd[s] * es;
-    a.partial = (float*)h->scratch;
+    a.Wp = n.packed + (alt ? L.pk_bwd_alt[s] : L.pk_bwd[s]) * es;
+    a.partial = (float*)scratch;
     if (ts.is_input) {
       a.Y = (n.groups == 3) ? h->d_din : h->d_vin;
       a.accumulate = 0;
     } else {
-      a.Y = ts.dz;
-      a.accumulate = ts.dz_written ? 1 : 0;
-      ts.dz_written = true;
+      a.Y = gpass ? ts.dz2 : ts.dz;
+      bool& written = gpass ? ts.dz2_written : ts.dz_written;
+      a.accumulate = written ? 1 : 0;
+      written = true;
       // chain rule through the consumer's activation and (for BN tensors) up to the normalised value
       // lrelu'/relu' only depend on the sign of the pre-activation == the sign of the materialised x~
       a.ref = (const char*)ts.xa[L.in_act] + (size_t)sample0 * ts.H * ts.W * ts.C * es;
@@ -574,18 +605,19 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
 }
 
 // dz -> dy through the training-mode batch norm of tensor t (in place), + dgamma/dbeta
-static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample0, int nb, int group0, int ng, hipStream_t st) {
+static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample0, int nb, int group0, int ng, hipStream_t st,
+                      bool side = false, bool gpass = false) {
   Tens& t = n.t[L.out];
   BnArgs b;
   memset(&b, 0, sizeof(b));
   b.y = (const char*)t.y + (size_t)sample0 * t.H * t.W * t.C * h->es;
-  b.dz = t.dz; b.dy = t.dz;
+  b.dy = gpass ? t.dz2 : t.dz; b.dz = b.dy;
   b.C = t.C; b.G = ng; b.Pg = (nb / ng) * t.H * t.W;
   b.nchunk = bn_nchunk(b.Pg, b.C, b.G, h->bf16);
-  b.partial = h->bn_partial;
+  b.partial = side ? h->bn_partial2 : h->bn_partial;
   b.gamma = n.params + L.gamma_off;
   b.mu = t.bn.mu + (size_t)group0 * t.C; b.rstd = t.bn.rstd + (size_t)group0 * t.C;
-  b.c1 = t.bn.c1; b.c2 = t.bn.c2;
+  b.c1 = gpass ? t.bn.c1g : t.bn.c1; b.c2 = gpass ? t.bn.c2g : t.bn.c2;
   if (want_dw) { b.dgamma = n.grads + L.gamma_off; b.dbeta = n.grads + L.beta_off; b.dbias_zero = n.grads + L.b_off; }
   if (bn_small(b)) { VP_HIP_CHECK(launch_bn_small_bwd(b, h->bf16, st)); return VP_OK; }
   VP_HIP_CHECK(launch_bn_bwd(b, h->bf16, st));
@@ -662,11 +694,27 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     VP_HIP_CHECK(hipMemcpyAsync(n->d_descs, n->descs.data(), n->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
   }
   VP_HIP_CHECK(hipStreamSynchronize(st));   // descs are host vectors owned by the handle; copy is complete
+  h->overlap = false;
+  if (d->training && !getenv("VP_NO_OVERLAP")) {
+    VP_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    h->overlap = true;
+  }
   *out = h;
   return VP_OK;
 }
 
-void vp_pixrefer_destroy(vp_pixrefer_t* h) { delete h; }
+void vp_pixrefer_destroy(vp_pixrefer_t* h) {
+  if (!h) return;
+  if (h->overlap) {
+    (void)hipStreamSynchronize(h->side);
+    (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_join);
+    (void)hipStreamDestroy(h->side);
+  }
+  delete h;
+}
 
 int vp_pixrefer_params_changed(vp_pixrefer_t* h) {
   if (!h) return VP_ERR_ARG;
@@ -741,15 +789,58 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   return VP_OK;
 }
 
+static int backward_d_on(vp_pixrefer_t* h, hipStream_t st, bool side);
+
+// Both gradient passes.  They are independent of each other (the discriminator-loss pass writes only the discriminator's gradient
+// arena and its own dz / scratch buffers, the generator-loss pass the generator's), so the discriminator-loss pass runs on a second
+// HIP stream: its large kernels fill the CUs that the generator's launch-bound bottleneck layers leave idle.  Fork / join by events;
+// nothing here blocks the host.  Results are bit-identical to running the two passes one after the other.
 int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
-  int rc = vp_pixrefer_backward_d(h, stream);
+  if (!h || !h->d.training) { set_err("vp_pixrefer_backward: needs a training plan"); return VP_ERR_STATE; }
+  hipStream_t st = (hipStream_t)stream;
+  if (!h->overlap) {
+    int rc = vp_pixrefer_backward_d(h, stream);
+    if (rc) return rc;
+    return vp_pixrefer_backward_g(h, stream);
+  }
+  VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+  VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  int rc = backward_d_on(h, h->side, true);
   if (rc) return rc;
-  return vp_pixrefer_backward_g(h, stream);
+  VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+  rc = vp_pixrefer_backward_g(h, stream);
+  if (rc) return rc;
+  VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+  return VP_OK;
 }
 
 int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d: needs a training plan"); return VP_ERR_STATE; }
+  return backward_d_on(h, (hipStream_t)stream, false);
+}
+
+// The two halves of vp_pixrefer_backward for a host that has work of its own between them (data parallel: the staged generator
+// backward with its bucketed all-reduces): _fork starts the discriminator-loss pass on the side stream behind everything already
+// enqueued on `stream`; _join makes `stream` wait for it (the discriminator gradient arena is final after the join).
+int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream) {
+  if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d_fork: needs a training plan"); return VP_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
+  if (!h->overlap) return backward_d_on(h, st, false);
+  VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+  VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  const int rc = backward_d_on(h, h->side, true);
+  if (rc) return rc;
+  VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+  return VP_OK;
+}
+
+int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream) {
+  if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d_join: needs a training plan"); return VP_ERR_STATE; }
+  if (h->overlap) VP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0));
+  return VP_OK;
+}
+
+static int backward_d_on(vp_pixrefer_t* h, hipStream_t st, bool side) {
   const int N = h->d.batch;
   int rc;
   Net& D = h->D;
@@ -759,10 +850,10 @@ int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream) {
   for (int i = (int)D.l.size() - 1; i >= 0; --i) {
     Layer& L = D.l[i];
     Tens& to = D.t[L.out];
-    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, true, 0, 3 * N, 0, 3, st))) return rc;
+    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, true, 0, 3 * N, 0, 3, st, side))) return rc;
     const bool save = L.need_bwd[0];
     if (i == 0) L.need_bwd[0] = false;          // no gradient w.r.t. the images for the D loss
-    rc = run_layer_bwd(h, D, L, to.dz, true, false, 0, 3 * N, 0, st);
+    rc = run_layer_bwd(h, D, L, to.dz, true, false, 0, 3 * N, 0, st, side);
     L.need_bwd[0] = save;
     if (rc) return rc;
   }
@@ -799,13 +890,13 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   if (stage <= 0) {
   // ---- Gen_loss -> generator* (pixrefer.py:402-407) ----
   // (a) GAN term through the fake application of the discriminator (dX only, pre-update weights)
-  for (Tens& t : D.t) t.dz_written = false;
+  for (Tens& t : D.t) t.dz2_written = false;
   for (int i = (int)D.l.size() - 1; i >= 0; --i) {
     Layer& L = D.l[i];
     Tens& to = D.t[L.out];
-    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, false, 2 * N, N, 2, 1, st))) return rc;
-    const void* dy = (i == (int)D.l.size() - 1) ? h->dl_g : to.dz;
-    if ((rc = run_layer_bwd(h, D, L, dy, false, true, 2 * N, N, 2, st))) return rc;
+    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, false, 2 * N, N, 2, 1, st, false, true))) return rc;
+    const void* dy = (i == (int)D.l.size() - 1) ? h->dl_g : to.dz2;
+    if ((rc = run_layer_bwd(h, D, L, dy, false, true, 2 * N, N, 2, st, false, true))) return rc;
   }
   // (b) perceptual term through the VGG trunk, fake half only (dX only: VGG is frozen)
   for (Tens& t : V.t) t.dz_written = false;
@@ -816,7 +907,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     // dz of a conv output here is already w.r.t. the pre-relu value (perceptual seed / epilogue / pool bwd)
     IgemmArgs a = L.bwd_alt[0].a;
     set_single_src(a.x, to.dz, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
-    a.Wp = V.packed + L.pk_bwd[0] * es;
+    a.Wp = V.packed + L.pk_bwd_alt[0] * es;
     a.partial = (float*)h->scratch;
     const bool from_pool = (ti.name == "pool1" || ti.name == "pool2");
     if (ti.is_input) {

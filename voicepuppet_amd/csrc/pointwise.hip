@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* __res
     }
     const int prow = d.perm ? perm_row(row) : row;
     T* o = dst + (((size_t)cls * (d.Kpad / d.kc) + k0 / d.kc) * d.rows_pad + prow) * d.kc + k0 % d.kc;
+    if (d.kswap && (piece & 1)) {
+#pragma unroll
+      for (int e = 0; e < E / 2; ++e) { const float tmp = v[e]; v[e] = v[e + E / 2]; v[e + E / 2] = tmp; }
+    }
     *reinterpret_cast<uint4*>(o) = Elem<T>::pack(v);
   }
 }
@@ -86,7 +90,12 @@ __global__ __launch_bounds__(256) void pack_weights_one_kernel(const PackDesc d,
           if (cc == cls && tt == tap) { kh = d.kh[cc][tt]; kw = d.kw[cc][tt]; }
       v = src[(size_t)kh * d.s_kh + (size_t)kw * d.s_kw + (size_t)row * d.s_row + (size_t)c * d.s_ch];
     }
-    Elem<T>::st(dst + (((size_t)cls * (d.Kpad / d.kc) + k / d.kc) * d.rows_pad + (d.perm ? perm_row(row) : row)) * d.kc + k % d.kc, v);
+    int kk = k % d.kc;
+    if (d.kswap) {   // odd pieces: halves swapped
+      constexpr int E = Elem<T>::E;
+      if ((kk / E) & 1) kk = (kk / E) * E + ((kk % E) + E / 2) % E;
+    }
+    Elem<T>::st(dst + (((size_t)cls * (d.Kpad / d.kc) + k / d.kc) * d.rows_pad + (d.perm ? perm_row(row) : row)) * d.kc + kk, v);
   }
 }
 
@@ -470,6 +479,57 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const PackInputsArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
+// frame_pack_kernel: the host input pipeline of generator.py:956-1019 as one kernel.  One thread per output pixel and frame
+// role; source coordinate of cv2.resize(INTER_LINEAR): f = (d + 0.5) * (rsize / S) - 0.5, clamped at the crop borders;
+// horizontal interpolation first, then vertical, in float32 on data already divided by 255 (ImageLoader: loader.py:85-89).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resize_coord(int d, int rsize, int S, int& s0, int& s1, float& w1) {
+  const float f = (float)(((double)d + 0.5) * ((double)rsize / (double)S) - 0.5);
+  int s = (int)floorf(f);
+  float w = f - (float)s;
+  if (s < 0) { s = 0; w = 0.f; }
+  if (s >= rsize - 1) { s = rsize - 1; w = 0.f; }
+  s0 = s; s1 = min(s + 1, rsize - 1); w1 = w;
+}
+
+__global__ __launch_bounds__(256) void frame_pack_kernel(const FramePackArgs a) {
+  const int S = a.S;
+  const size_t total = (size_t)a.N * S * S * 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int role = (int)(i & 1);                  // 0: example frame, 1: current frame
+    const size_t pix = i >> 1;
+    const int x = (int)(pix % S), y = (int)((pix / S) % S), n = (int)(pix / ((size_t)S * S));
+    const int* cr = a.crops + (n * 2 + role) * 3;
+    const int rx = cr[0], ry = cr[1], rsize = cr[2];
+    int y0, y1, x0, x1;
+    float wy, wx;
+    resize_coord(y, rsize, S, y0, y1, wy);
+    resize_coord(x, rsize, S, x0, x1, wx);
+    const unsigned char* f = (role ? a.cur : a.ex) + (size_t)n * S * 3 * S * 3;
+    float v[3][3];                                  // [panel][rgb]
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const unsigned char* r0 = f + ((size_t)(rx + y0) * 3 * S + p * S + ry) * 3;
+      const unsigned char* r1 = f + ((size_t)(rx + y1) * 3 * S + p * S + ry) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int b = 2 - c;                        // BGR -> RGB (cv2.cvtColor, generator.py:981)
+        const float a00 = r0[x0 * 3 + b] / 255.0f, a01 = r0[x1 * 3 + b] / 255.0f;
+        const float a10 = r1[x0 * 3 + b] / 255.0f, a11 = r1[x1 * 3 + b] / 255.0f;
+        const float h0 = a00 * (1.f - wx) + a01 * wx, h1 = a10 * (1.f - wx) + a11 * wx;
+        v[p][c] = h0 * (1.f - wy) + h1 * wy;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a.inputs[pix * 6 + role * 3 + c] = v[1][c];
+      a.fg_inputs[pix * 6 + role * 3 + c] = v[0][c] * v[2][c];
+      if (role) { a.targets[pix * 3 + c] = v[0][c]; a.masks[pix * 3 + c] = v[2][c]; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // alpha composite (pixrefer.py:281-286) fused with tanh, the L1 / matte loss partial sums and the
 // hand-over of Outputs_FG to the discriminator and VGG batches
 // ------------------------------------------------------------------------------------------------
@@ -823,6 +883,11 @@ hipError_t launch_tap_spread(const TapArgs& a, int is_bf16, hipStream_t st) {
 
 hipError_t launch_pack_inputs(const PackInputsArgs& a, int is_bf16, hipStream_t st) {
   VP_DISPATCH(is_bf16, pack_inputs_kernel, dim3(nblocks((size_t)a.N * a.HW)), dim3(256), st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_frame_pack(const FramePackArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(frame_pack_kernel, dim3(nblocks((size_t)a.N * a.S * a.S * 2)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

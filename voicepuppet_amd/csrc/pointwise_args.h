@@ -15,6 +15,8 @@ struct PackDesc {
   int nclass, rows_real, rows_pad, ntaps, C, C_real, Kpad;
   int kc;                   // elements per 64-byte K chunk; packed layout is [class][K chunk][row][kc]
   int perm;                 // rows permuted inside every 64-row block (see IgemmArgs::rowperm): packed row of channel c = perm_row(c)
+  int kswap;                // odd 16-byte k-pieces of every 64-byte chunk are stored with their two halves swapped (conv_patch.hip reads
+                            // the pixel operand that way; a permutation of k common to both operands leaves the product unchanged)
   int s_kh, s_kw, s_row, s_ch;
   int8_t kh[4][16];
   int8_t kw[4][16];
@@ -50,6 +52,20 @@ struct PackInputsArgs {
   void* din;                // [3N,H,W,8]  discriminator batch: real1 | real2 | fake(cond only)
   void* vin;                // [2N,H,W,8]  VGG batch: real fg | (fake, written by composite)
   int N, HW, train;
+};
+
+// On-device form of PixReferDataGenerator.iterator (generator/generator.py:956-1019): per sample two decoded jpg triptychs
+// (target | 3-D face | matte, S x 3S, uint8 BGR as cv2.imread returns them), each with its own random square crop
+// (rx rows, ry columns, rsize), bilinear-resized back to S x S (cv2.resize INTER_LINEAR on float data) and packed.
+struct FramePackArgs {
+  const unsigned char* ex;    // [N][S][3S][3]  example frame
+  const unsigned char* cur;   // [N][S][3S][3]  current frame
+  const int* crops;           // [N][2][3]      (rx, ry, rsize) of the example and of the current frame
+  float* inputs;              // [N][S][S][6]   3-D face of (example, current)
+  float* fg_inputs;           // [N][S][S][6]   target * matte of (example, current)
+  float* targets;             // [N][S][S][3]   target of the current frame
+  float* masks;               // [N][S][S][3]   matte of the current frame
+  int N, S;
 };
 
 struct CompositeArgs {

@@ -186,14 +186,18 @@ class PixReferEngine:
     with the generator backward), Adam(D) then Adam(G)."""
     from .parallel import allreduce_mean
     self.forward(inputs, fg_inputs, targets, masks)
-    self.backward_d()
     if group is None:
-      self.backward_g()
+      self.backward()          # both passes, the discriminator-loss pass on the executor's side stream
     else:
-      # the discriminator bucket and the first two generator buckets travel while later stages still compute
-      works = [allreduce_mean(self.grads_d, group, async_op=True)]
+      # the discriminator-loss pass runs on the side stream under stage 0 of the generator backward; its bucket and the first
+      # two generator buckets travel while later stages still compute
+      _lib.check(self.L.vp_pixrefer_backward_d_fork(self.h, _stream()), "vp_pixrefer_backward_d_fork")
+      works = []
       for stage, (lo, hi) in enumerate(self.grad_buckets_g()):
         self.backward_g_stage(stage)
+        if stage == 0:
+          _lib.check(self.L.vp_pixrefer_backward_d_join(self.h, _stream()), "vp_pixrefer_backward_d_join")
+          works.append(allreduce_mean(self.grads_d, group, async_op=True))
         works.append(allreduce_mean(self.grads_g[lo:hi], group, async_op=True))
       for w in works:
         w.wait()

@@ -1,0 +1,131 @@
+"""PixReferNet input pipeline on the device (reference: generator/generator.py:956-1019).
+
+The reference prepares every training sample on the host: two cv2.imread's, BGR->RGB, a random square crop of the S x 3S
+triptych, cv2.resize back to S x S and the 6-channel packing - float32, 18 * S * S values per sample, then a host-to-device
+copy of all of it.  At thousands of frames per second that thread is the bottleneck.  Here the host only hands over the decoded
+uint8 frames (2 * 9 * S * S bytes per sample: 8x fewer bytes over PCIe) and three integers per crop; libvp_hip.so's
+vp_pixrefer_pack_frames does the rest in one kernel, and `FramePrefetcher` overlaps the copies of batch k+1 with step k on a
+second HIP stream (pinned staging buffers, event hand-off).
+"""
+import ctypes
+import random
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def draw_crop(img_size, crop_ratio, rng=random):
+  """(rx, ry, rsize) exactly as generator.py:975-977 / 994-996 draws them."""
+  rsize = rng.randint(int(img_size * crop_ratio), img_size)
+  rx = rng.randint(0, img_size - rsize)
+  ry = rng.randint(0, img_size - rsize)
+  return rx, ry, rsize
+
+
+class DeviceFramePacker:
+  """uint8 triptych frames + crops -> (inputs, fg_inputs, targets, masks) float32 device tensors."""
+
+  def __init__(self, batch, img_size, device=None):
+    if not torch.cuda.is_available():
+      raise RuntimeError("DeviceFramePacker needs an MI355X (no CPU fallback)")
+    self.L = _lib.lib()
+    self.batch, self.S = batch, img_size
+    self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    f = lambda c: torch.empty(batch, img_size, img_size, c, dtype=torch.float32, device=self.device)
+    self.out = (f(6), f(6), f(3), f(3))
+
+  def __call__(self, ex_u8, cur_u8, crops):
+    """ex_u8 / cur_u8: [N, S, 3S, 3] uint8 device tensors (BGR, as cv2.imread); crops: [N, 2, 3] int32 device tensor."""
+    N, S = self.batch, self.S
+    assert ex_u8.shape == (N, S, 3 * S, 3) and cur_u8.shape == ex_u8.shape and ex_u8.dtype == torch.uint8 and cur_u8.dtype == torch.uint8
+    assert crops.shape == (N, 2, 3) and crops.dtype == torch.int32
+    ex_u8, cur_u8, crops = ex_u8.contiguous(), cur_u8.contiguous(), crops.contiguous()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(self.L.vp_pixrefer_pack_frames(p(ex_u8), p(cur_u8), p(crops), N, S, p(self.out[0]), p(self.out[1]), p(self.out[2]),
+                                              p(self.out[3]), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "vp_pixrefer_pack_frames")
+    return self.out
+
+
+class FramePrefetcher:
+  """Double-buffered host -> device hand-over of uint8 frame batches on a side stream.
+
+  `source` yields (ex [N,S,3S,3] uint8, cur [N,S,3S,3] uint8, crops [N,2,3] int32) numpy arrays.  next() returns the four packed
+  float32 tensors of the oldest batch in flight (valid until the next call) and starts the copies of a following one; the
+  copies and the pack kernel of batch k+1 overlap the training step of batch k.
+  """
+
+  def __init__(self, source, batch, img_size, depth=2, device=None):
+    self.source = iter(source)
+    self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    self.stream = torch.cuda.Stream(device=self.device)
+    S = img_size
+    self.slots = []
+    for _ in range(depth):
+      host = (torch.empty(batch, S, 3 * S, 3, dtype=torch.uint8).pin_memory(), torch.empty(batch, S, 3 * S, 3, dtype=torch.uint8).pin_memory(),
+              torch.empty(batch, 2, 3, dtype=torch.int32).pin_memory())
+      dev = tuple(torch.empty_like(h, device=self.device) for h in host)
+      self.slots.append({"host": host, "dev": dev, "packer": DeviceFramePacker(batch, img_size, self.device),
+                         "ready": torch.cuda.Event(), "free": torch.cuda.Event(), "busy": False})
+    self.head = self.tail = 0
+    for _ in range(depth):
+      self._fill()
+
+  def _fill(self):
+    slot = self.slots[self.head % len(self.slots)]
+    try:
+      ex, cur, crops = next(self.source)
+    except StopIteration:
+      return False
+    if slot["busy"]:
+      slot["ready"].synchronize()                     # the previous copies out of this slot's pinned buffers have completed
+    for h, a in zip(slot["host"], (ex, cur, crops)):
+      h.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+    with torch.cuda.stream(self.stream):
+      if slot["busy"]:
+        self.stream.wait_event(slot["free"])          # the consumer of this slot's previous batch has been enqueued past it
+      for d, h in zip(slot["dev"], slot["host"]):
+        d.copy_(h, non_blocking=True)
+      slot["packer"](*slot["dev"])
+      slot["ready"].record(self.stream)
+    slot["busy"] = True
+    self.head += 1
+    return True
+
+  def next(self):
+    if self.tail == self.head:
+      raise StopIteration
+    # the slot handed out by the previous call is free once everything enqueued so far on the compute stream has run
+    if self.tail > 0:
+      prev = self.slots[(self.tail - 1) % len(self.slots)]
+      prev["free"].record(torch.cuda.current_stream())
+      self._fill()
+    slot = self.slots[self.tail % len(self.slots)]
+    torch.cuda.current_stream().wait_event(slot["ready"])
+    self.tail += 1
+    return slot["packer"].out
+
+  __next__ = next
+
+  def __iter__(self):
+    return self
+
+
+def host_pack_reference(ex_u8, cur_u8, crops, img_size):
+  """The reference's host arithmetic for ONE sample with PIL standing in for cv2.resize (float planes, bilinear): what
+  PixReferDataGenerator._load_triptych + pack_sample compute.  Used by the fixture generator and the parity test."""
+  from PIL import Image
+  from .generator import pack_sample
+  S = img_size
+
+  def trip(u8, crop):
+    rx, ry, rsize = [int(v) for v in crop]
+    img = (u8.astype(np.float32) / 255.0)[:, :, ::-1]
+    img = np.concatenate([img[:, :S, :], img[:, S:S * 2, :], img[:, S * 2:, :]], axis=-1)
+    img = img[rx:rsize + rx, ry:rsize + ry, :]
+    planes = [np.asarray(Image.fromarray(np.ascontiguousarray(img[:, :, c]), mode="F").resize((S, S), Image.BILINEAR)) for c in range(9)]
+    img = np.stack(planes, axis=-1)
+    return np.concatenate([img[:, :, :3], img[:, :, 3:6], img[:, :, 6:]], axis=1)
+  return pack_sample(trip(ex_u8, crops[0]), trip(cur_u8, crops[1]), S)
