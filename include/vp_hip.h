@@ -128,7 +128,8 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
  * the call see the new value.  Keys: "patch_tiles" (bit 0 / 1 / 2: allow the 256- / 128- / 64-row tiles of the stride-1 patch
  * kernel, default 7), "patch_min_blocks" (smallest grid that runs on it, default 384), "patch_small_tiles" (bit 0: 16x16-pixel
  * tiles for the 128- / 64-row variants, bit 1: 8x16 for the 256-row variant - two blocks per CU; default 3), "patch_long_k_on_256"
- * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile).  No counterpart in the reference. */
+ * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile), "overlap" (default 1; 0: the step
+ * executor keeps everything on the caller's stream - needed for per-kernel timing).  No counterpart in the reference. */
 int vp_tune(const char* key, int value);
 
 /* theta -= lr_t * m / (sqrt(v) + eps) with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) (TF formulation) */

@@ -54,6 +54,8 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
   return VP_OK;
 }
 
+extern "C" void vp_overlap_enable(int on);   // plan_pixrefer.hip
+
 int vp_tune(const char* key, int value) {
   if (!key) return VP_ERR_ARG;
   const std::string k(key);
@@ -61,6 +63,7 @@ int vp_tune(const char* key, int value) {
   if (k == "patch_min_blocks") { patch_minblk_knob() = value; return VP_OK; }
   if (k == "patch_small_tiles") { patch_small_knob() = value; return VP_OK; }
   if (k == "patch_long_k_on_256") { patch_longk_knob() = value; return VP_OK; }
+  if (k == "overlap") { vp_overlap_enable(value); return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
   return VP_ERR_ARG;
 }

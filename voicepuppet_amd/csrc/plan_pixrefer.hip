@@ -74,6 +74,9 @@ struct Layer {
   size_t pk_fwd = 0, pk_bwd[2] = {0, 0}, pk_bwd_alt[2] = {0, 0};   // pk_bwd_alt == pk_bwd unless the two batch sizes run different kernel families
   bool need_bwd[2] = {false, false};
   IgemmPlan fwd, bwd[2], bwd_alt[2];   // bwd_alt: discriminator G-loss pass (batch N)
+  IgemmPlan fwd_half;                  // VGG: forward of one half (N) of the [real | fake] batch, so the real half can run early on the side stream
+  size_t pk_fwd_half = 0;
+  bool has_fwd_half = false;
   WgradPlan wg;
   // one-output-channel stride-1 conv (D layer_5) run as a GEMM over taps (TapArgs): x is read once per pass, not 16 times
   bool tapgemm = false;
@@ -116,7 +119,7 @@ struct vp_pixrefer {
   double* bn_partial2;
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;
-  bool overlap;
+  bool overlap, forked;
   void* zeros;
   size_t scratch_bytes;
   int n_comp, n_perc;
@@ -238,7 +241,7 @@ static void build_vgg(Net& n, int N, int H) {
 }
 
 // plans + packed-weight layout for one net.  alt_batch > 0: also plan bwd-data for that batch (D, G-loss pass)
-static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_batch, size_t* scratch_max) {
+static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_batch, size_t* scratch_max, bool fwd_halves = false) {
   size_t pk = 0;
   auto take = [&](IgemmPlan& p) {
     p.pack.dst_off = pk;
@@ -264,6 +267,22 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
     }
     take(L.fwd);
     L.pk_fwd = L.fwd.pack.dst_off;
+    if (fwd_halves && alt_batch > 0 && !L.tapgemm && !L.has_bn) {
+      ConvGeomX g2 = L.g;
+      g2.N = alt_batch;
+      L.fwd_half = plan_fwd(g2, L.w_off, bf16);
+      if (plan_patch_eligible(L.fwd_half, g2.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == g2.Cin)) plan_make_patch(L.fwd_half, g2.Cout, bf16);
+      const PackDesc &pa = L.fwd.pack, &pb = L.fwd_half.pack;
+      if (L.fwd_half.a.splitk == 1 && !L.fwd_half.a.wide) {
+        if (pa.kswap != pb.kswap || pa.perm != pb.perm || pa.kc != pb.kc || pa.Kpad != pb.Kpad || pa.rows_pad != pb.rows_pad) {
+          take(L.fwd_half);
+          L.pk_fwd_half = L.fwd_half.pack.dst_off;
+        } else {
+          L.pk_fwd_half = L.pk_fwd;
+        }
+        L.has_fwd_half = true;
+      }
+    }
     if (!training) continue;
     int row0 = 0;
     for (int s = 0; s < L.nsrc; ++s) {
@@ -414,7 +433,7 @@ static void init_handle(vp_pixrefer* h, const vp_pixrefer_desc* d) {
     build_vgg(h->V, d->batch, d->height);
     // VGG backward (dX only) is planned for the fake half: batch N
     for (Layer& L : h->V.l) L.g.N = 2 * d->batch;
-    plan_net(h->V, h->bf16, true, false, d->batch, &smax);
+    plan_net(h->V, h->bf16, true, false, d->batch, &smax, true);
   }
   h->scratch_bytes = smax + 256;
   h->params_dirty = true;
@@ -473,6 +492,23 @@ static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, int fused_chunks, hipS
     return 1;
   }
   VP_HIP_CHECK(launch_bn_stats(b, h->bf16, st));
+  return VP_OK;
+}
+
+// forward of one half of the batch of a plain conv layer (VGG: no batch-norm, activation in the epilogue): half 0 / 1
+static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStream_t st) {
+  IgemmArgs a = L.fwd_half.a;
+  const int nb = a.N;
+  fill_src(n, L, a.x, nb, half * nb, 0, h->es);
+  a.Wp = n.packed + L.pk_fwd_half * h->es;
+  Tens& to = n.t[L.out];
+  a.Y = (char*)to.y + (size_t)half * nb * to.H * to.W * to.C * h->es; a.ldY = to.C; a.y_f32 = 0;
+  a.bias = n.params + L.b_off;
+  a.out_act = L.out_act;
+  a.partial = nullptr;        // (no K split on this path)
+  a.zeros = h->zeros;
+  profile_tag((L.scope + (half ? ":fwd1" : ":fwd0")).c_str());
+  VP_HIP_CHECK(launch_igemm(a, h->bf16, L.fwd_half.cfg, st));
   return VP_OK;
 }
 
@@ -631,6 +667,9 @@ static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+static bool g_overlap_on = true;     // vp_tune("overlap", 0 / 1): per-kernel timing (bench.py's profile pass) needs one stream
+void vp_overlap_enable(int on) { g_overlap_on = on != 0; }
+
 int vp_version(void) { return 100; }
 const char* vp_last_error(void) { return g_err; }
 
@@ -694,9 +733,12 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     VP_HIP_CHECK(hipMemcpyAsync(n->d_descs, n->descs.data(), n->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
   }
   VP_HIP_CHECK(hipStreamSynchronize(st));   // descs are host vectors owned by the handle; copy is complete
-  h->overlap = false;
+  h->overlap = false; h->forked = false;
   if (d->training && !getenv("VP_NO_OVERLAP")) {
-    VP_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    // lowest priority: the side stream only fills the CUs the main stream's (longer, critical-path) passes leave idle
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    VP_HIP_CHECK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     h->overlap = true;
@@ -745,6 +787,25 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   pi.N = N; pi.HW = H * H; pi.train = d.training;
   VP_HIP_CHECK(launch_pack_inputs(pi, bf, st));
 
+  // the real half of the perceptual trunk only needs the packed inputs: side stream, under the generator forward
+  bool split_vgg = d.training && h->overlap && g_overlap_on;
+  if (split_vgg) for (Layer& L : h->V.l) split_vgg = split_vgg && L.has_fwd_half;
+  if (split_vgg) {
+    VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+    VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    Net& Vs = h->V;
+    for (size_t i = 0; i < Vs.l.size(); ++i) {
+      Layer& L = Vs.l[i];
+      if ((rc = run_layer_fwd_half(h, Vs, L, 0, h->side))) return rc;
+      if (L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2") {
+        const Tens& ti = Vs.t[L.out];
+        Tens& tp = Vs.t[L.out + 1];
+        VP_HIP_CHECK(launch_maxpool_fwd(ti.y, tp.y, N, ti.H, ti.W, ti.C, bf, h->side));
+      }
+    }
+    VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+  }
+
   for (Layer& L : h->G.l) if ((rc = run_layer_fwd(h, h->G, L, st))) return rc;
 
   CompositeArgs ca;
@@ -763,15 +824,35 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   ga.M = N * hd * hd; ga.gan_weight = d.gan_weight;
   VP_HIP_CHECK(launch_gan_loss(ga, bf, st));
 
-  // VGG trunk on [real fg | Outputs_FG] (pixrefer.py:321)
+  // VGG trunk on [real fg | Outputs_FG] (pixrefer.py:321).  The real half does not depend on the generator: when every layer has
+  // a half-batch plan it was started on the side stream right after pack_inputs (below, `vgg_half`) and only the fake half runs here
   Net& V = h->V;
-  for (size_t i = 0; i < V.l.size(); ++i) {
-    Layer& L = V.l[i];
-    if ((rc = run_layer_fwd(h, V, L, st))) return rc;
-    if (L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2") {
-      const Tens& ti = V.t[L.out];
-      Tens& tp = V.t[L.out + 1];   // pool tensor follows in creation order
-      VP_HIP_CHECK(launch_maxpool_fwd(ti.y, tp.y, ti.N, ti.H, ti.W, ti.C, bf, st));
+  auto vgg_half = [&](int half, hipStream_t s2) -> int {
+    for (size_t i = 0; i < V.l.size(); ++i) {
+      Layer& L = V.l[i];
+      int rc2;
+      if ((rc2 = run_layer_fwd_half(h, V, L, half, s2))) return rc2;
+      if (L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2") {
+        const Tens& ti = V.t[L.out];
+        Tens& tp = V.t[L.out + 1];   // pool tensor follows in creation order
+        const size_t oi = (size_t)half * N * ti.H * ti.W * ti.C * h->es, op = (size_t)half * N * tp.H * tp.W * tp.C * h->es;
+        VP_HIP_CHECK(launch_maxpool_fwd((const char*)ti.y + oi, (char*)tp.y + op, N, ti.H, ti.W, ti.C, bf, s2));
+      }
+    }
+    return VP_OK;
+  };
+  if (split_vgg) {
+    if ((rc = vgg_half(1, st))) return rc;
+    VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));      // the real half (side stream) is complete
+  } else {
+    for (size_t i = 0; i < V.l.size(); ++i) {
+      Layer& L = V.l[i];
+      if ((rc = run_layer_fwd(h, V, L, st))) return rc;
+      if (L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2") {
+        const Tens& ti = V.t[L.out];
+        Tens& tp = V.t[L.out + 1];   // pool tensor follows in creation order
+        VP_HIP_CHECK(launch_maxpool_fwd(ti.y, tp.y, ti.N, ti.H, ti.W, ti.C, bf, st));
+      }
     }
   }
   const Tens& f3 = V.t.back();
@@ -798,7 +879,7 @@ static int backward_d_on(vp_pixrefer_t* h, hipStream_t st, bool side);
 int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward: needs a training plan"); return VP_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
-  if (!h->overlap) {
+  if (!h->overlap || !g_overlap_on) {
     int rc = vp_pixrefer_backward_d(h, stream);
     if (rc) return rc;
     return vp_pixrefer_backward_g(h, stream);
@@ -825,7 +906,8 @@ int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream) {
 int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d_fork: needs a training plan"); return VP_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
-  if (!h->overlap) return backward_d_on(h, st, false);
+  h->forked = h->overlap && g_overlap_on;
+  if (!h->forked) return backward_d_on(h, st, false);
   VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
   VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
   const int rc = backward_d_on(h, h->side, true);
@@ -836,7 +918,8 @@ int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream) {
 
 int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d_join: needs a training plan"); return VP_ERR_STATE; }
-  if (h->overlap) VP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0));
+  if (h->forked) VP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0));
+  h->forked = false;
   return VP_OK;
 }
 

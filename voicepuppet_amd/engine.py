@@ -229,7 +229,10 @@ class PixReferEngine:
     return self.workspace[off:off + nbytes].view(tdt).view(shape)
 
   def profile(self, on):
+    """Per-launch HIP-event timing of the conv kernels; while it is on the executor keeps every kernel on one stream (timing a
+    kernel that shares the GPU with another stream's kernels measures the sharing, not the kernel)."""
     self.L.vp_profile_enable(int(on))
+    self.L.vp_tune(b"overlap", 0 if on else 1)
 
   def profile_collect(self):
     import json
