@@ -44,6 +44,9 @@ FWD_CASES = [
     (0, 2, 33, 70, 32, 128, 4, 1, 1, 0, 0, False),    # 128 ch x 16x32 px tiles, 4x4 stride 1 (32 x 69 outputs), one chunk
     (0, 1, 48, 64, 128, 64, 3, 1, 1, 0, 2, False),    # 64 ch x 16x32 px tiles (half-instruction weight DMAs), four chunks
     (0, 3, 31, 31, 64, 64, 4, 1, 1, 0, 0, False),     # D layer_4 geometry at a small width: 30 x 30 outputs
+    # transpose-read weight gradient (wgrad_tr.hip): 16 * Cin a multiple of 256, >= 128 output channels, plain operands
+    (0, 3, 17, 19, 64, 128, 4, 1, 1, 0, 0, False),    # odd 16 x 18 output grid inside a 16 x 32 padded K grid, stride 1
+    (1, 2, 8, 8, 128, 64, 4, 2, 1, 0, 0, False),      # transposed conv: the gathered operand is dY
 ]
 
 

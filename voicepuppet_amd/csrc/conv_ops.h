@@ -301,7 +301,10 @@ struct WgradPlan {
   size_t partial_bytes;
 };
 
-inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16) {
+inline int& wgrad_tr_knob() { static int v = getenv("VP_WGRAD_TR") ? atoi(getenv("VP_WGRAD_TR")) : 1; return v; }   // LDS-DMA + transpose-read weight gradient (wgrad_tr.hip)
+
+// plain_operands: both tensors are read as stored (no deferred affine / activation): required by the LDS-DMA kernel
+inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands = true) {
   WgradPlan p;
   memset(&p, 0, sizeof(p));
   WgradArgs& a = p.a;
@@ -329,16 +332,19 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16) {
       else if ((big & 2) && a.Dc % 128 == 0) p.cfg = 4;
     }
   }
+  a.lw = ilog2(a.Wb); a.lh = ilog2(a.Hb);
+  const bool tr = is_bf16 && plain_operands && wgrad_tr_knob() && (a.ntaps * a.Gc) % 256 == 0 && a.Dc % 128 == 0 &&
+                  (((long long)a.N << (a.lw + a.lh)) % 32) == 0;
+  if (tr) p.cfg = 5;
   int bm, bn;
   wgrad_tile(p.cfg, &bm, &bn);
   a.Mpad = round_up(a.ntaps * a.Gc, bm);
   a.Dpad = round_up(a.Dc, bn);
-  a.lw = ilog2(a.Wb); a.lh = ilog2(a.Hb);
-  const int kiter = kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of wgrad_kernel
+  const int kiter = tr ? 32 : kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of the kernel
   // padded-grid K walk: rows of 2^lw slots, at least one 16-byte pixel group and at most one iteration long
   static const bool fastw_on = !getenv("VP_NO_FASTW");
-  a.fastw = (fastw_on && (1 << a.lw) >= (is_bf16 ? 8 : 4) && (1 << a.lw) <= kiter) ? 1 : 0;
-  const int P = a.fastw ? (a.N << (a.lw + a.lh)) : a.N * a.Hb * a.Wb;
+  a.fastw = (fastw_on && !tr && (1 << a.lw) >= (is_bf16 ? 8 : 4) && (1 << a.lw) <= kiter) ? 1 : 0;
+  const int P = (a.fastw || tr) ? (a.N << (a.lw + a.lh)) : a.N * a.Hb * a.Wb;
   const int nchunk = (P + kiter - 1) / kiter;
   const int tiles = (a.Mpad / bm) * (a.Dpad / bn);
   // K split: minimise (rounds of the ~512 resident blocks) x (iterations per block + fixed per-block cost),

@@ -64,6 +64,7 @@ int vp_tune(const char* key, int value) {
   if (k == "patch_small_tiles") { patch_small_knob() = value; return VP_OK; }
   if (k == "patch_long_k_on_256") { patch_longk_knob() = value; return VP_OK; }
   if (k == "overlap") { vp_overlap_enable(value); return VP_OK; }
+  if (k == "wgrad_tr") { wgrad_tr_knob() = value; return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
   return VP_ERR_ARG;
 }
@@ -81,8 +82,10 @@ size_t vp_conv_workspace_bytes(const vp_conv_desc* d) {
     IgemmPlan p = plan_bwd_data(g, 0, 0, d->cin, d->cin, d->cin, bf);
     size_t b = align256(p.pack_elems * es) + p.partial_bytes;
     if (b > best) best = b;
-    WgradPlan w = plan_wgrad(g, bf);
-    if (w.partial_bytes + 512 > best) best = w.partial_bytes + 512;
+    for (int plain = 0; plain < 2; ++plain) {      // the LDS-DMA weight-gradient kernel (plain operands) tiles and splits differently
+      WgradPlan w = plan_wgrad(g, bf, plain != 0);
+      if (w.partial_bytes + 512 > best) best = w.partial_bytes + 512;
+    }
   }
   return best + 1024;
 }
@@ -135,7 +138,7 @@ int vp_conv_bwd_weight(const vp_conv_desc* d, const void* x, const float* in_sca
   const int bf = d->dtype == VP_BF16;
   hipStream_t st = (hipStream_t)stream;
   const ConvGeomX g = geom_of(d);
-  WgradPlan p = plan_wgrad(g, bf);
+  WgradPlan p = plan_wgrad(g, bf, !in_scale && d->in_act == ACT_NONE);
   WgradArgs a = p.a;
   PixSrc xs, ds;
   set_single_src(xs, x, d->cin, in_scale, in_shift, d->in_act, 0);

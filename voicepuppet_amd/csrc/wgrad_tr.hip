@@ -1,0 +1,206 @@
+// wgrad_tr_kernel: backward-weight as an LDS-DMA GEMM with hardware transpose reads (bf16).
+//
+//   dW[tap][g][d] = sum over pixels k = (n, q, r) of  G[pixel (+) tap, g] * D[pixel, d]
+//
+// The reduction index is the PIXEL - the slow index of both NHWC operands - while an MFMA lane needs 8 consecutive k of one row.
+// wgrad_kernel (conv_kernels.hip) gets there with register loads, 8x8 v_perm transposes and ds_writes in the loop.  Here both tiles
+// go global -> LDS by LDS-DMA exactly as they lie in memory ([pixel][channel]: whole 256 / 512-byte rows per pixel, no vector ALU on
+// the data, no ds_write), and the fragments come out of LDS with ds_read_b64_tr_b16: in each 16-lane group, lane a supplies the
+// address of ONE 8-byte chunk (4 channels of one pixel) and lane t receives element t % 4 of the chunks of lanes 4j + t / 4,
+// j = 0..3 - so with lane a addressing (pixel k0 + a / 4, channels 4 (a % 4) ..) lane t ends up with channel t of pixels k0 .. k0+3:
+// two reads give the 8 consecutive k of an MFMA 16x16x32 fragment (scripts/probes/tr_wgrad_probe.hip checks this chain on the GPU).
+//
+// LDS image of a tile: pixel p (0..31 inside the K chunk) owns one row of 16-byte pieces, piece c stored at slot c ^ swz(p),
+// swz(p) = ((p & 3) | ((p >> 3) & 1) << 2) << 1: the 32 lanes of a read group touch 8 pixels x 2 pieces x 2 halves = all 64 banks
+// (conflict-free for both tile widths); the DMA lanes apply the same permutation to their SOURCE addresses.
+//
+// K walks the padded grid [N][2^lh][2^lw] (slots outside the image, padding taps and ragged channels read the zero page), split
+// over gridDim.z with the same slab + deterministic reduce as wgrad_kernel.  Tile 256 rows (tap, g) x 128 columns d, 8 waves of
+// 64 x 64, 64 accumulator registers, 3-deep ring of 24 KB stages, counted vmcnt, one barrier per chunk, two blocks per CU.
+#include <stdlib.h>
+
+#include "igemm_device.h"
+#include "launch.h"
+
+namespace vp {
+
+__device__ __forceinline__ int tr_swz(int p) { return ((p & 3) | (((p >> 3) & 1) << 2)) << 1; }
+
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+
+// fragment reads behind a __restrict__ parameter (see conv_db.hip: keeps the waitcnt pass from draining vmcnt in front of LDS reads
+// while LDS-DMAs are in flight); `off`: byte offset of the first 4-pixel group of this lane's 8 consecutive k, the second one is
+// four pixel rows further
+template <int ROWB>   // bytes of one pixel row of the tile
+__device__ __forceinline__ uint4 tr_frag8(const char* __restrict__ stage, int off) {
+  typedef __attribute__((address_space(3))) v4s16 lds_v4;
+  const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(stage + off));
+  const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(stage + off + 4 * ROWB));
+  union { v4s16 v[2]; uint4 u; } f;
+  f.v[0] = lo; f.v[1] = hi;
+  return f.u;
+}
+
+// one DMA lane's share of an operand tile, fixed over the K loop: which tensor / channels / tap; only the pixel moves
+struct TrTask {
+  const bf16* base;     // source pointer + channel offset
+  int C;                // channels of that source (pixel stride)
+  int s, dh, dw;        // source pixel = (q * s + dh, r * s + dw)
+  int Hs, Ws;
+  int p;                // pixel slot inside the 32-pixel chunk
+  bool ok;
+};
+
+__device__ __forceinline__ TrTask tr_task(const PixSrc& src, int ch, bool ok, int s, int dh, int dw, int Hs, int Ws, int p, const void* zeros) {
+  TrTask t;
+  const bool second = ch >= src.C[0];
+  t.C = second ? src.C[1] : src.C[0];
+  t.base = reinterpret_cast<const bf16*>(second ? src.ptr[1] : src.ptr[0]) + (second ? ch - src.C[0] : ch);
+  t.s = s; t.dh = dh; t.dw = dw; t.Hs = Hs; t.Ws = Ws; t.p = p; t.ok = ok;
+  if (!ok) { t.base = reinterpret_cast<const bf16*>(zeros); t.C = 0; }
+  return t;
+}
+
+__device__ __forceinline__ const void* tr_src(const WgradArgs& a, const TrTask& t, int it) {
+  const int slot = it * 32 + t.p;
+  const int r = slot & ((1 << a.lw) - 1), q = (slot >> a.lw) & ((1 << a.lh) - 1), n = slot >> (a.lw + a.lh);
+  const int ih = q * t.s + t.dh, iw = r * t.s + t.dw;
+  const bool ok = t.ok && n < a.N && q < a.Hb && r < a.Wb && (unsigned)ih < (unsigned)t.Hs && (unsigned)iw < (unsigned)t.Ws;
+  return ok ? (const void*)(t.base + ((size_t)(n * t.Hs + ih) * t.Ws + iw) * t.C) : a.zeros;
+}
+
+template <int WM, int WN, int TC, int TP, int NST>
+__global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradArgs a) {
+  constexpr int NW = WM * WN;
+  static_assert(NW == 8, "eight waves");
+  constexpr int BM = WM * TC * 16, BN = WN * TP * 16;
+  constexpr int PA = BM / 8, PB = BN / 8;                 // 16-byte pieces per pixel row
+  constexpr int ASTG = 32 * PA, BSTG = 32 * PB, STG = ASTG + BSTG;   // uint4 slots
+  constexpr int JA = ASTG / 64 / NW, JB = BSTG / 64 / NW;            // DMA instructions per wave per chunk
+  static_assert(JA * NW * 64 == ASTG && JB * NW * 64 == BSTG, "whole DMA instructions per wave");
+  constexpr int J = JA + JB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m_base = blockIdx.x * BM, d_base = blockIdx.y * BN, split = blockIdx.z;
+  const int niter = (a.N << (a.lw + a.lh)) / 32;          // host guarantees 2^(lw+lh) * N is a multiple of 32
+  const int per = (niter + a.splitk - 1) / a.splitk;
+  const int it0 = split * per, it1 = min(niter, it0 + per);
+
+  // ---- this lane's DMA tasks ----
+  TrTask ta[JA], tb[JB];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int idx = (wave + NW * j) * 64 + lane;          // slot index inside the A stage
+    const int p = idx / PA, c = (idx % PA) ^ tr_swz(p);
+    const int m = m_base + c * 8;
+    const int tap = m >> a.log2Gc, ch = m & (a.Gc - 1);
+    int tdh = 0, tdw = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) if (t == tap) { tdh = a.taps.dh[t]; tdw = a.taps.dw[t]; }
+    ta[j] = tr_task(a.g, ch, tap < a.ntaps && ch < a.g.C[0] + a.g.C[1], a.s, tdh, tdw, a.Hgin, a.Wgin, p, a.zeros);
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int idx = (wave + NW * j) * 64 + lane;
+    const int p = idx / PB, c = (idx % PB) ^ tr_swz(p);
+    const int ch = d_base + c * 8;
+    tb[j] = tr_task(a.d, ch, ch < a.Dc, 1, 0, 0, a.Hb, a.Wb, p, a.zeros);
+  }
+  auto issue = [&](int it, int stage) {
+    uint4* la = lds + stage * STG;
+    uint4* lb = la + ASTG;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) dma16(tr_src(a, ta[j], it), la + (wave + NW * j) * 64);
+#pragma unroll
+    for (int j = 0; j < JB; ++j) dma16(tr_src(a, tb[j], it), lb + (wave + NW * j) * 64);
+  };
+
+  // ---- fragment addresses of this lane ----
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int g = lane >> 4, t16 = lane & 15;
+  const int fp = 8 * g + (t16 >> 2), q2 = t16 & 3, fsw = tr_swz(fp);
+  int offA[TC], offB[TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc) offA[tc] = fp * (BM * 2) + (((2 * (wm * TC + tc) + (q2 >> 1)) ^ fsw) << 4) + (q2 & 1) * 8;
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) offB[tp] = ASTG * 16 + fp * (BN * 2) + (((2 * (wn * TP + tp) + (q2 >> 1)) ^ fsw) << 4) + (q2 & 1) * 8;
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (it0 < it1) {
+#pragma unroll
+    for (int dd = 0; dd < NST - 1; ++dd) if (it0 + dd < it1) issue(it0 + dd, dd);
+    int st = 0;
+    for (int it = it0; it < it1; ++it) {
+      if (it + NST - 2 < it1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * J) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int stn = st == 0 ? NST - 1 : st - 1;           // the stage chunk it-1 used
+      if (it + NST - 1 < it1) issue(it + NST - 1, stn);
+      const char* stage = smem + (size_t)st * STG * 16;
+      uint4 fa[TC], fb[TP];
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) fb[tp] = tr_frag8<BN * 2>(stage, offB[tp]);
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc) fa[tc] = tr_frag8<BM * 2>(stage, offA[tc]);
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<bf16>(fa[tc], fb[tp], acc[tc][tp]);
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+  }
+
+  // lane holds d column (lane & 15), rows 4 * (lane >> 4) .. + 3 of every 16 x 16 tile
+  if (a.splitk == 1) {
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        const int m0 = m_base + (wm * TC + tc) * 16 + 4 * (lane >> 4);
+        const int d = d_base + (wn * TP + tp) * 16 + (lane & 15);
+        if (d >= a.Dreal) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + e, tap = m >> a.log2Gc, gc = m & (a.Gc - 1);
+          if (tap < a.ntaps && gc < a.Greal) {
+            float* o = a.dW + ((size_t)tap * a.Greal + gc) * a.Dreal + d;
+            *o = acc[tc][tp][e] + (a.accumulate ? *o : 0.f);
+          }
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {
+      const int m0 = m_base + (wm * TC + tc) * 16 + 4 * (lane >> 4);
+      const int d = d_base + (wn * TP + tp) * 16 + (lane & 15);
+      float* pp = a.partial + ((size_t)split * a.Mpad + m0) * a.Dpad + d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pp[(size_t)e * a.Dpad] = acc[tc][tp][e];
+    }
+}
+
+// 256 rows x 128 columns (wgrad cfg 5)
+hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st) {
+  constexpr int NST = 3;
+  constexpr int BM = 256, BN = 128;
+  const size_t smem = (size_t)NST * 32 * (BM / 8 + BN / 8) * 16;
+  dim3 grid(a.Mpad / BM, a.Dpad / BN, a.splitk);
+  auto kern = wgrad_tr_kernel<4, 2, 4, 4, NST>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace vp
