@@ -69,7 +69,7 @@ __device__ __forceinline__ const void* tr_src(const WgradArgs& a, const TrTask& 
   return ok ? (const void*)(t.base + ((size_t)(n * t.Hs + ih) * t.Ws + iw) * t.C) : a.zeros;
 }
 
-template <int WM, int WN, int TC, int TP, int NST>
+template <int WM, int WN, int TC, int TP, int NST, bool FAST>
 __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradArgs a) {
   constexpr int NW = WM * WN;
   static_assert(NW == 8, "eight waves");
@@ -109,7 +109,68 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradAr
     const int ch = d_base + c * 8;
     tb[j] = tr_task(a.d, ch, ch < a.Dc, 1, 0, 0, a.Hb, a.Wb, p, a.zeros);
   }
+  // ---- fast path: buffer-descriptor DMAs with a SCALAR per-chunk offset ----
+  // A chunk is 32 consecutive slots starting at a multiple of 32, so slot = u + p splits into a block-uniform part
+  // (nu, qu, ru) and a lane-constant part (pq, pr) without carries; the address splits the same way:
+  //   [(nu*Hs + qu*s)*Ws + ru*s]*C  (scalar, per chunk)  +  [(pq*s + dh)*Ws + pr*s + dw]*C + ch  (per lane, once)
+  // and only the four range checks remain vector work per chunk (invalid lanes get an out-of-range offset: the DMA writes zeros).
+  // Needs ONE source tensor per operand tile (the channel tile does not straddle a virtual concat) and offsets below 2 GiB; the
+  // descriptor base sits `guard` bytes in front of the tensor so that lane offsets of negative taps stay non-negative.
+  const int W2 = 1 << a.lw;
+  const bool gsecond = a.g.C[1] > 0 && (m_base & (a.Gc - 1)) >= a.g.C[0];
+  const bool dsecond = a.d.C[1] > 0 && d_base >= a.d.C[0];
+  const int gC = gsecond ? a.g.C[1] : a.g.C[0], dC = dsecond ? a.d.C[1] : a.d.C[0];
+  constexpr bool fast = FAST;          // host decision (launch_wgrad_tr): one source per operand tile, chunks inside one image, < 2 GiB
+  const unsigned gguard = (unsigned)((2 * a.Wgin + 2) * gC * 2);                      // |dh| <= 2 rows, |dw| <= 2 pixels in front
+  __amdgpu_buffer_rsrc_t rsG = make_rsrc((const char*)(gsecond ? a.g.ptr[1] : a.g.ptr[0]) - gguard,
+                                         (unsigned)((size_t)a.N * a.Hgin * a.Wgin * gC * 2) + gguard);
+  __amdgpu_buffer_rsrc_t rsD = make_rsrc(dsecond ? a.d.ptr[1] : a.d.ptr[0], (unsigned)((size_t)a.N * a.Hb * a.Wb * dC * 2));
+  int fq[JA], fB[JA], fr[JA], fD[JA];      // lane constants of the gathered tasks: pq, pq*s + dh, pr, pr*s + dw
+  unsigned fvo[JA];
+  bool fok[JA];
+  int bq[JB], br[JB];
+  unsigned bvo[JB];
+  bool bok[JB];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const TrTask& t = ta[j];
+    const int pq = W2 <= 32 ? t.p >> a.lw : 0, pr = W2 <= 32 ? t.p & (W2 - 1) : t.p;
+    fq[j] = pq; fB[j] = pq * t.s + t.dh; fr[j] = pr; fD[j] = pr * t.s + t.dw;
+    const int chl = (int)(t.base - reinterpret_cast<const bf16*>(gsecond ? a.g.ptr[1] : a.g.ptr[0]));   // channel offset inside the source
+    fvo[j] = gguard + (unsigned)(((fB[j] * a.Wgin + fD[j]) * gC + chl) * 2);
+    fok[j] = t.ok;
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const TrTask& t = tb[j];
+    bq[j] = W2 <= 32 ? t.p >> a.lw : 0; br[j] = W2 <= 32 ? t.p & (W2 - 1) : t.p;
+    const int chl = (int)(t.base - reinterpret_cast<const bf16*>(dsecond ? a.d.ptr[1] : a.d.ptr[0]));
+    bvo[j] = (unsigned)(((bq[j] * a.Wb + br[j]) * dC + chl) * 2);
+    bok[j] = t.ok;
+  }
+  auto issue_fast = [&](int it, int stage) {
+    uint4* la = lds + stage * STG;
+    uint4* lb = la + ASTG;
+    const int u = it * 32;
+    const int ru = u & (W2 - 1), qu = (u >> a.lw) & ((1 << a.lh) - 1), nu = u >> (a.lw + a.lh);
+    const bool nok = nu < a.N;
+    const unsigned gso = (unsigned)((((nu * a.Hgin + qu * a.s) * a.Wgin + ru * a.s) * gC) * 2);
+    const unsigned dso = (unsigned)((((nu * a.Hb + qu) * a.Wb + ru) * dC) * 2);
+    const int qs = qu * a.s, rs = ru * a.s;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      const bool ok = fok[j] && nok && qu + fq[j] < a.Hb && ru + fr[j] < a.Wb &&
+                      (unsigned)(qs + fB[j]) < (unsigned)a.Hgin && (unsigned)(rs + fD[j]) < (unsigned)a.Wgin;
+      dma16_buf(rsG, ok ? fvo[j] : DMA_OOB, gso, la + (wave + NW * j) * 64);
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const bool ok = bok[j] && nok && qu + bq[j] < a.Hb && ru + br[j] < a.Wb;
+      dma16_buf(rsD, ok ? bvo[j] : DMA_OOB, dso, lb + (wave + NW * j) * 64);
+    }
+  };
   auto issue = [&](int it, int stage) {
+    if constexpr (fast) { issue_fast(it, stage); return; }
     uint4* la = lds + stage * STG;
     uint4* lb = la + ASTG;
 #pragma unroll
@@ -197,9 +258,17 @@ hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st) {
   constexpr int BM = 256, BN = 128;
   const size_t smem = (size_t)NST * 32 * (BM / 8 + BN / 8) * 16;
   dim3 grid(a.Mpad / BM, a.Dpad / BN, a.splitk);
-  auto kern = wgrad_tr_kernel<4, 2, 4, 4, NST>;
+  WgradArgs b = a;
+  static const bool fast_on = !getenv("VP_NO_FAST_TR");
+  const size_t gbytes = (size_t)a.N * a.Hgin * a.Wgin * (a.g.C[0] > a.g.C[1] ? a.g.C[0] : a.g.C[1]) * 2;
+  const size_t dbytes = (size_t)a.N * a.Hb * a.Wb * (a.d.C[0] > a.d.C[1] ? a.d.C[0] : a.d.C[1]) * 2;
+  bool fast = fast_on && gbytes < 0x60000000ull && dbytes < 0x60000000ull && a.lw + a.lh >= 5;     // a 32-slot chunk stays inside one image
+  if (a.g.C[1] > 0) fast = fast && a.Gc >= BM && a.g.C[0] % BM == 0;                                // an operand tile never straddles a virtual concat
+  if (a.d.C[1] > 0) fast = fast && a.d.C[0] % BN == 0;
+  b.fast_tr = fast ? 1 : 0;
+  auto kern = fast ? wgrad_tr_kernel<4, 2, 4, 4, NST, true> : wgrad_tr_kernel<4, 2, 4, 4, NST, false>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, b);
   return hipGetLastError();
 }
 
