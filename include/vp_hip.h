@@ -71,8 +71,11 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
                        float* grads_g, float* grads_d, void* stream, vp_pixrefer_t** out);
 void vp_pixrefer_destroy(vp_pixrefer_t* h);
 
-/* Call after the f32 master parameters changed (optimizer step, checkpoint load). */
+/* Call after the f32 master parameters changed: _params_changed after the host wrote any arena (checkpoint load, initialisation:
+ * all three nets are re-packed), _optimizer_stepped after vp_adam_tf on generator* / discriminator* (the frozen vgg_16 trunk -
+ * restored from a checkpoint, never an optimiser variable: pixrefer.py:325-327, 396-407 - keeps its packed weights). */
 int vp_pixrefer_params_changed(vp_pixrefer_t* h);
+int vp_pixrefer_optimizer_stepped(vp_pixrefer_t* h);
 
 /* inputs [N,H,H,6], fg_inputs [N,H,H,6] (inference: only channels 0:3 are read), targets [N,H,H,3],
  * masks [N,H,H,3] (training only) - float32 in [0,1] exactly as PixReferDataGenerator yields them

@@ -51,6 +51,7 @@ _SIGNATURES = {
                                           ctypes.POINTER(_P)]),
     "vp_pixrefer_destroy": (None, [_P]),
     "vp_pixrefer_params_changed": (ctypes.c_int, [_P]),
+    "vp_pixrefer_optimizer_stepped": (ctypes.c_int, [_P]),
     "vp_pixrefer_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "vp_pixrefer_backward": (ctypes.c_int, [_P, _P]),
     "vp_pixrefer_backward_d": (ctypes.c_int, [_P, _P]),

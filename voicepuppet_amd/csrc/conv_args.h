@@ -63,6 +63,7 @@ struct IgemmArgs {
   // patch kernel (conv_patch.hip; plan-time decision, the packed weights carry PackDesc::kswap): stride-1 taps on a regular grid,
   // tap t = r * p_kw + c  ->  (dh, dw) = (p_dhf + r * p_dhs, p_dwf + c * p_dws)
   int patch, p_kw, p_dhf, p_dhs, p_dwf, p_dws;
+  void* pool_out;           // patch kernel, 16 x 16-pixel tiles: also write the 2x2 max-pooled output [N][Hg/2][Wg/2][ldY] (null: no)
 };
 
 // dW[tap][g][d] = sum_{pixels} G~[pixel (+) tap, g] * D~[pixel, d]

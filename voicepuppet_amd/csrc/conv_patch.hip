@@ -37,6 +37,14 @@ struct PatchTilePix {
     const long long off = (((long long)n * a.Hof + y) * a.Wof + x) * a.ldY;
     return (off << 8) | (long long)(n / a.ref_group_n);
   }
+  // 2x2 max pool of the tile: pooled pixel (row pr, column pc) of this tile -> element offset in the pooled image, -1 outside.
+  // Meaningful for 16-pixel-wide tiles (the staged epilogue walks 8 pooled pixels per pooled row) and even image sizes.
+  static constexpr bool HAS_POOL = (TW == 16);
+  __device__ __forceinline__ long long pool(int pr, int pc) const {
+    const int y = (y0 >> 1) + pr, x = (x0 >> 1) + pc;
+    if (y >= (a.Hg >> 1) || x >= (a.Wg >> 1)) return -1;
+    return (((long long)n * (a.Hg >> 1) + y) * (a.Wg >> 1) + x) * a.ldY;
+  }
 };
 
 // fragment reads behind __restrict__ parameters: keeps hipcc from draining vmcnt in front of LDS reads that may alias a pending

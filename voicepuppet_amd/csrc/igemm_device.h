@@ -52,6 +52,11 @@ constexpr unsigned DMA_OOB = 0xF0000000u;     // lane offset beyond every descri
 // MFMA-layout store writes 8 bytes per lane at a 32-byte granularity and ran at ~0.4 TB/s.)
 // ------------------------------------------------------------------------------------------------
 // default tile-row -> output-pixel map: rows are consecutive pixels of the flattened (n, q, r) grid
+// A tile-row -> output-pixel functor may also know where the 2x2-max-pooled image of its tile goes (2-D tiles only):
+// member `static constexpr bool HAS_POOL` + `long long pool(int pooled_row, int pooled_col) const` (offset in elements, -1 outside).
+template <typename F, typename = void> struct pix_has_pool { static constexpr bool value = false; };
+template <typename F> struct pix_has_pool<F, decltype((void)F::HAS_POOL)> { static constexpr bool value = F::HAS_POOL; };
+
 struct LinearPix {
   const IgemmArgs& a; int cls, p_base, P;
   __device__ __forceinline__ long long operator()(int row) const {
@@ -202,6 +207,47 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
       }
       epi_store8<T>(a, ot, c0, off, v);
+    }
+    // fused 2x2 / stride-2 max pool of the tile (VGG conv1_2 / conv2_2: slim max_pool2d, vgg_simple.py:141,144): the pass holds
+    // whole pairs of 16-pixel tile rows; bias + (monotonic) activation + rounding commute with the max, so this equals pooling the
+    // stored tensor bit for bit (relu / identity outputs only: the host does not ask for it otherwise)
+    if constexpr (pix_has_pool<PixFn>::value) {
+      if (a.pool_out != nullptr) {
+        static_assert(RP % 32 == 0, "a pass must hold whole pairs of tile rows");
+        constexpr int PR = RP / 4;                     // pooled pixels of the pass: RP / 32 rows of 8
+        for (int idx = tid; idx < PR * CG; idx += NT) {
+          const int pp = idx / CG, cgp = idx - pp * CG;
+          const int pyl = pp >> 3, pxl = pp & 7;
+          const int c0 = c_base + cgp * 8;
+          const long long po = pixfn.pool(ps * (RP / 32) + pyl, pxl);
+          if (po < 0 || c0 >= a.Cout) continue;
+          const int r00 = pyl * 32 + pxl * 2;
+          float m[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {               // max of the raw accumulators first: bias, activation and rounding are monotonic
+            const int rr = r00 + (k >> 1) * 16 + (k & 1);
+            const float4 v0 = *reinterpret_cast<const float4*>(smem + rr * PITCH + cgp * 32);
+            const float4 v1 = *reinterpret_cast<const float4*>(smem + rr * PITCH + cgp * 32 + 16);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = k == 0 ? v[e] : fmaxf(m[e], v[e]);
+          }
+          if (a.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + c0), b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
+            m[0] += b0.x; m[1] += b0.y; m[2] += b0.z; m[3] += b0.w; m[4] += b1.x; m[5] += b1.y; m[6] += b1.z; m[7] += b1.w;
+          }
+          if (a.out_act != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = act_apply(a.out_act, m[e]);
+          }
+          if (sizeof(T) == 2) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(a.pool_out) + po + c0) = Elem<bf16>::pack(m);
+          else {
+            float* o = reinterpret_cast<float*>(a.pool_out) + po + c0;
+            reinterpret_cast<float4*>(o)[0] = make_float4(m[0], m[1], m[2], m[3]);
+            reinterpret_cast<float4*>(o)[1] = make_float4(m[4], m[5], m[6], m[7]);
+          }
+        }
+      }
     }
   }
   if constexpr (STATS) {

@@ -124,6 +124,7 @@ struct vp_pixrefer {
   size_t scratch_bytes;
   int n_comp, n_perc;
   bool params_dirty;
+  bool vgg_dirty;             // set by vp_pixrefer_params_changed (a host wrote the arenas), cleared by the next forward; vp_pixrefer_optimizer_stepped leaves it
   const float *in_targets, *in_masks;
 };
 
@@ -437,6 +438,7 @@ static void init_handle(vp_pixrefer* h, const vp_pixrefer_desc* d) {
   }
   h->scratch_bytes = smax + 256;
   h->params_dirty = true;
+  h->vgg_dirty = true;
 }
 
 // The batch-norm partial-sum workspace (bn_partial: 1024 chunk rows x 2 x 512 channels of f64) bounds the widths and the
@@ -495,9 +497,20 @@ static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, int fused_chunks, hipS
   return VP_OK;
 }
 
+// the patch kernel's 16-pixel-wide tiles can write the 2x2 max pool of their output from the epilogue (even image sizes)
+static bool plan_can_pool(const IgemmPlan& p) {
+  if (!p.a.patch || (p.a.Hg & 1) || (p.a.Wg & 1)) return false;
+  int bc, bp;
+  igemm_tile(p.cfg, &bc, &bp);
+  int th, tw;
+  patch_tile_hw(bp, &th, &tw);
+  return tw == 16 && th % 2 == 0;
+}
+
 // forward of one half of the batch of a plain conv layer (VGG: no batch-norm, activation in the epilogue): half 0 / 1
-static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStream_t st) {
+static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStream_t st, void* pool_out = nullptr) {
   IgemmArgs a = L.fwd_half.a;
+  a.pool_out = pool_out;
   const int nb = a.N;
   fill_src(n, L, a.x, nb, half * nb, 0, h->es);
   a.Wp = n.packed + L.pk_fwd_half * h->es;
@@ -513,8 +526,9 @@ static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStr
 }
 
 // forward of one conv layer (+ its batch statistics)
-static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
+static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void* pool_out = nullptr) {
   IgemmArgs a = L.fwd.a;
+  a.pool_out = pool_out;
   fill_src(n, L, a.x, n.batch / n.groups, 0, 0, h->es);
   a.Wp = n.packed + L.pk_fwd * h->es;
   Tens& to = n.t[L.out];
@@ -545,6 +559,8 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st) {
       }
     }
   }
+  static const bool dbg_stats = getenv("VP_DBG_STATS") != nullptr;
+  if (dbg_stats && L.has_bn) fprintf(stderr, "[stats] %s fused=%d splitk=%d cfg=%d nclass=%d groups=%d\n", L.scope.c_str(), (int)fused_stats, a.splitk, L.fwd.cfg, a.nclass, n.groups);
   profile_tag((L.scope + ":fwd").c_str());
   VP_HIP_CHECK(launch_igemm(a, h->bf16, L.fwd.cfg, st));
   if (L.tapgemm) {
@@ -761,6 +777,13 @@ void vp_pixrefer_destroy(vp_pixrefer_t* h) {
 int vp_pixrefer_params_changed(vp_pixrefer_t* h) {
   if (!h) return VP_ERR_ARG;
   h->params_dirty = true;
+  h->vgg_dirty = true;
+  return VP_OK;
+}
+
+int vp_pixrefer_optimizer_stepped(vp_pixrefer_t* h) {
+  if (!h) return VP_ERR_ARG;
+  h->params_dirty = true;       // generator* / discriminator* moved; vgg_16 is not an optimiser variable
   return VP_OK;
 }
 
@@ -776,7 +799,8 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
     if ((rc = run_pack(h, h->G, st))) return rc;
     if (d.training) {
       if ((rc = run_pack(h, h->D, st))) return rc;
-      if ((rc = run_pack(h, h->V, st))) return rc;
+      // the perceptual trunk is frozen (pixrefer.py:325-327 restores it, no optimiser touches it): packed once per load, not per step
+      if (h->vgg_dirty) { if ((rc = run_pack(h, h->V, st))) return rc; h->vgg_dirty = false; }
     }
     h->params_dirty = false;
   }
@@ -796,8 +820,10 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
     Net& Vs = h->V;
     for (size_t i = 0; i < Vs.l.size(); ++i) {
       Layer& L = Vs.l[i];
-      if ((rc = run_layer_fwd_half(h, Vs, L, 0, h->side))) return rc;
-      if (L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2") {
+      const bool pooled = L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2";
+      const bool fuse = pooled && plan_can_pool(L.fwd_half);
+      if ((rc = run_layer_fwd_half(h, Vs, L, 0, h->side, fuse ? Vs.t[L.out + 1].y : nullptr))) return rc;
+      if (pooled && !fuse) {
         const Tens& ti = Vs.t[L.out];
         Tens& tp = Vs.t[L.out + 1];
         VP_HIP_CHECK(launch_maxpool_fwd(ti.y, tp.y, N, ti.H, ti.W, ti.C, bf, h->side));
@@ -831,13 +857,13 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
     for (size_t i = 0; i < V.l.size(); ++i) {
       Layer& L = V.l[i];
       int rc2;
-      if ((rc2 = run_layer_fwd_half(h, V, L, half, s2))) return rc2;
-      if (L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2") {
-        const Tens& ti = V.t[L.out];
-        Tens& tp = V.t[L.out + 1];   // pool tensor follows in creation order
-        const size_t oi = (size_t)half * N * ti.H * ti.W * ti.C * h->es, op = (size_t)half * N * tp.H * tp.W * tp.C * h->es;
-        VP_HIP_CHECK(launch_maxpool_fwd((const char*)ti.y + oi, (char*)tp.y + op, N, ti.H, ti.W, ti.C, bf, s2));
-      }
+      const bool pooled = L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2";
+      const bool fuse = pooled && plan_can_pool(L.fwd_half);
+      const Tens& ti = V.t[L.out];
+      Tens& tp = V.t[pooled ? L.out + 1 : L.out];   // pool tensor follows in creation order
+      const size_t oi = (size_t)half * N * ti.H * ti.W * ti.C * h->es, op = (size_t)half * N * tp.H * tp.W * tp.C * h->es;
+      if ((rc2 = run_layer_fwd_half(h, V, L, half, s2, fuse ? (char*)tp.y + op : nullptr))) return rc2;
+      if (pooled && !fuse) VP_HIP_CHECK(launch_maxpool_fwd((const char*)ti.y + oi, (char*)tp.y + op, N, ti.H, ti.W, ti.C, bf, s2));
     }
     return VP_OK;
   };
@@ -847,8 +873,10 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   } else {
     for (size_t i = 0; i < V.l.size(); ++i) {
       Layer& L = V.l[i];
-      if ((rc = run_layer_fwd(h, V, L, st))) return rc;
-      if (L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2") {
+      const bool pooled = L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2";
+      const bool fuse = pooled && plan_can_pool(L.fwd);
+      if ((rc = run_layer_fwd(h, V, L, st, fuse ? V.t[L.out + 1].y : nullptr))) return rc;
+      if (pooled && !fuse) {
         const Tens& ti = V.t[L.out];
         Tens& tp = V.t[L.out + 1];   // pool tensor follows in creation order
         VP_HIP_CHECK(launch_maxpool_fwd(ti.y, tp.y, ti.N, ti.H, ti.W, ti.C, bf, st));

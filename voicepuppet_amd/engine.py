@@ -211,7 +211,7 @@ class PixReferEngine:
       m, v = self.adam[key]
       _lib.check(self.L.vp_adam_tf(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), t, lr, beta1, beta2, eps, _stream()),
                  "vp_adam_tf")
-    self.params_changed()
+    _lib.check(self.L.vp_pixrefer_optimizer_stepped(self.h))      # generator / discriminator moved; the frozen vgg_16 trunk did not
 
   # ---- named device buffers -----------------------------------------------------------------------
   def tensor(self, name):
