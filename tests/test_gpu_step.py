@@ -377,26 +377,35 @@ def test_bucketed_train_step_through_rccl_single_rank():
 
 
 @pytest.mark.gpu
-def test_overlapped_backward_equals_sequential_passes():
-  """vp_pixrefer_backward runs the discriminator-loss pass on the executor's side stream, concurrently with the generator-loss
-  pass (own gradient / scratch buffers for each): bit-identical to the two passes run one after the other on one stream, over
-  repeated steps (the buffers of one pass must never leak into the other)."""
+def test_overlapped_step_equals_single_stream_step():
+  """The executor spreads independent parts of the step over HIP streams of its own (the real half of the perceptual trunk and the
+  generator's foreground encoder branch under the generator forward; the discriminator-loss pass and the foreground branch's
+  backward under the generator-loss pass; each with its own gradient / scratch buffers): bit-identical to the whole step on one
+  stream, over repeated steps (no buffer of one stream may leak into another)."""
+  from voicepuppet_amd import _lib
+  L = _lib.lib()
   ngf = ndf = 8
   p = make_params(ngf, ndf, 5)
   batch = [torch.tensor(b, device="cuda") for b in synth(2, 256, 13)]
   for dtype in ("f32", "bf16"):
-    a = PixReferEngine(2, 256, ngf, ndf, dtype=dtype, training=True)
-    b = PixReferEngine(2, 256, ngf, ndf, dtype=dtype, training=True)
-    a.load_params(p)
-    b.load_params(p)
-    for _ in range(3):
-      a.forward(*batch)
-      a.backward()
-      b.forward(*batch)
-      b.backward_d()
-      b.backward_g()
-      torch.cuda.synchronize()
-      assert torch.equal(a.grads_d, b.grads_d) and torch.equal(a.grads_g, b.grads_g), dtype
-      a.adam_step(3e-4)
-      b.adam_step(3e-4)
-    assert torch.equal(a.params_g, b.params_g) and torch.equal(a.params_d, b.params_d)
+    runs = []
+    for overlap in (1, 0):
+      L.vp_tune(b"overlap", overlap)
+      try:
+        e = PixReferEngine(2, 256, ngf, ndf, dtype=dtype, training=True)
+        e.load_params(p)
+        trace = []
+        for _ in range(3):
+          e.forward(*batch)
+          e.backward()
+          torch.cuda.synchronize()
+          trace.append((e.grads_d.clone(), e.grads_g.clone(), dict(e.losses())))
+          e.adam_step(3e-4)
+        torch.cuda.synchronize()
+        runs.append((trace, e.params_g.clone(), e.params_d.clone()))
+      finally:
+        L.vp_tune(b"overlap", 1)
+    (ta, ga, da), (tb, gb, db) = runs
+    for (d1, g1, l1), (d2, g2, l2) in zip(ta, tb):
+      assert torch.equal(d1, d2) and torch.equal(g1, g2) and l1 == l2, dtype
+    assert torch.equal(ga, gb) and torch.equal(da, db)

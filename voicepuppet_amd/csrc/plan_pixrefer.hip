@@ -117,8 +117,10 @@ struct vp_pixrefer {
   char* scratch;
   char* scratch2;             // split-K / slab scratch and batch-norm partials of the side stream (backward_d when overlapped)
   double* bn_partial2;
-  hipStream_t side;
-  hipEvent_t ev_fork, ev_join;
+  char* scratch3;             // ... and of the branch stream (the generator's foreground encoder branch, forward and backward)
+  double* bn_partial3;
+  hipStream_t side, branch;
+  hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
   bool overlap, forked;
   void* zeros;
   size_t scratch_bytes;
@@ -417,6 +419,8 @@ static size_t carve_all(vp_pixrefer* h, char* base, size_t cap) {
   if (d.training) {
     h->bn_partial2 = (double*)ar.alloc((size_t)1024 * 2 * 512 * sizeof(double));
     h->scratch2 = (char*)ar.alloc(h->scratch_bytes);
+    h->bn_partial3 = (double*)ar.alloc((size_t)1024 * 2 * 512 * sizeof(double));
+    h->scratch3 = (char*)ar.alloc(h->scratch_bytes);
   }
   return ar.off + 256;
 }
@@ -477,14 +481,18 @@ static int run_pack(vp_pixrefer* h, Net& n, hipStream_t st) {
   return VP_OK;
 }
 
+// scratch set of a stream: 0 = the caller's stream, 1 = side stream, 2 = branch stream
+static char* scratch_of(vp_pixrefer* h, int ss) { return ss == 2 ? h->scratch3 : ss == 1 ? h->scratch2 : h->scratch; }
+static double* bnp_of(vp_pixrefer* h, int ss) { return ss == 2 ? h->bn_partial3 : ss == 1 ? h->bn_partial2 : h->bn_partial; }
+
 // fused_chunks > 0: the conv epilogue already wrote that many partial chunks per group; only the finalize pass runs
-static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, int fused_chunks, hipStream_t st) {
+static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, int fused_chunks, hipStream_t st, int ss = 0) {
   Tens& t = n.t[L.out];
   BnArgs b;
   memset(&b, 0, sizeof(b));
   b.y = t.y; b.C = t.C; b.G = n.groups; b.Pg = (n.batch / n.groups) * t.H * t.W;
   b.nchunk = bn_nchunk(b.Pg, b.C, b.G, h->bf16);
-  b.partial = h->bn_partial;
+  b.partial = bnp_of(h, ss);
   b.gamma = n.params + L.gamma_off; b.beta = n.params + L.beta_off;
   b.aff_a = t.bn.a; b.aff_b = t.bn.b; b.mu = t.bn.mu; b.rstd = t.bn.rstd;
   b.eps = 1e-5f;   // pixrefer.py:100
@@ -526,7 +534,7 @@ static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStr
 }
 
 // forward of one conv layer (+ its batch statistics)
-static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void* pool_out = nullptr) {
+static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void* pool_out = nullptr, int ss = 0) {
   IgemmArgs a = L.fwd.a;
   a.pool_out = pool_out;
   fill_src(n, L, a.x, n.batch / n.groups, 0, 0, h->es);
@@ -536,7 +544,7 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
   if (to.is_f32) { a.y_f32 = 1; a.ldY = L.g.Cout; }
   a.bias = L.has_bn ? nullptr : n.params + L.b_off;   // a bias in front of batch-norm cancels exactly
   a.out_act = L.out_act;
-  a.partial = (float*)h->scratch;
+  a.partial = (float*)scratch_of(h, ss);
   a.zeros = h->zeros;
   if (L.tapgemm) { a.Y = L.tap_S; a.y_f32 = 1; a.ldY = 16; a.bias = nullptr; }
   // batch statistics from the conv epilogue (no re-read of the output) when every pixel tile lies inside one BN group
@@ -554,7 +562,7 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
       const int tpg = a.patch ? (n.batch / n.groups) * ((a.Hg + pth - 1) / pth) * ((a.Wg + ptw - 1) / ptw) : (pg + bp - 1) / bp;
       stat_chunks = a.nclass * tpg;
       if ((size_t)n.groups * stat_chunks * 2 * to.C <= (size_t)1024 * 2 * 512) {
-        a.bn_part = h->bn_partial; a.bn_tpg = tpg; a.bn_nchunk = stat_chunks;
+        a.bn_part = bnp_of(h, ss); a.bn_tpg = tpg; a.bn_nchunk = stat_chunks;
         fused_stats = true;
       }
     }
@@ -572,7 +580,7 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
   }
   bool acts_done = false;
   if (L.has_bn) {
-    const int rc = run_bn_stats(h, n, L, fused_stats ? stat_chunks : 0, st);
+    const int rc = run_bn_stats(h, n, L, fused_stats ? stat_chunks : 0, st, ss);
     if (rc < 0) return rc;
     acts_done = rc == 1;
   }
@@ -587,12 +595,14 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
 // backward of one layer given dL/dy in `dy` (dtype T, channel stride g.CoutT):
 //   weight/bias/BN gradients (when grads != null) and dz of every source tensor.
 // sample0/nb/group0/ng select a sub-batch (discriminator G-loss pass: the fake group only).
-// side: the call runs on the side stream (its own scratch); gpass: generator-loss pass through the discriminator (dz2 buffers)
+// ss: scratch set of the stream the call runs on; gpass: generator-loss pass through the discriminator (dz2 buffers)
 static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool want_dw, bool alt,
-                         int sample0, int nb, int group0, hipStream_t st, bool side = false, bool gpass = false) {
+                         int sample0, int nb, int group0, hipStream_t st, int ss = 0, bool gpass = false, int parts = 3) {
+  // parts: bit 0 = weight / bias gradients, bit 1 = data gradients (so a host can put the two on different streams)
   const int es = h->es;
-  char* scratch = side ? h->scratch2 : h->scratch;
-  double* bn_partial = side ? h->bn_partial2 : h->bn_partial;
+  if (!(parts & 1)) want_dw = false;
+  char* scratch = scratch_of(h, ss);
+  double* bn_partial = bnp_of(h, ss);
   const int group_n = n.batch / n.groups;
   if (want_dw) {
     WgradArgs w = L.wg.a;
@@ -628,7 +638,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
     }
   }
-  for (int s = 0; s < L.nsrc; ++s) {
+  for (int s = 0; s < L.nsrc && (parts & 2); ++s) {
     if (!L.need_bwd[s]) continue;
     Tens& ts = n.t[L.src[s]];
     IgemmArgs a = alt ? L.bwd_alt[s].a : L.bwd[s].a;
@@ -658,7 +668,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
 
 // dz -> dy through the training-mode batch norm of tensor t (in place), + dgamma/dbeta
 static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample0, int nb, int group0, int ng, hipStream_t st,
-                      bool side = false, bool gpass = false) {
+                      int ss = 0, bool gpass = false) {
   Tens& t = n.t[L.out];
   BnArgs b;
   memset(&b, 0, sizeof(b));
@@ -666,7 +676,7 @@ static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample
   b.dy = gpass ? t.dz2 : t.dz; b.dz = b.dy;
   b.C = t.C; b.G = ng; b.Pg = (nb / ng) * t.H * t.W;
   b.nchunk = bn_nchunk(b.Pg, b.C, b.G, h->bf16);
-  b.partial = side ? h->bn_partial2 : h->bn_partial;
+  b.partial = bnp_of(h, ss);
   b.gamma = n.params + L.gamma_off;
   b.mu = t.bn.mu + (size_t)group0 * t.C; b.rstd = t.bn.rstd + (size_t)group0 * t.C;
   b.c1 = gpass ? t.bn.c1g : t.bn.c1; b.c2 = gpass ? t.bn.c2g : t.bn.c2;
@@ -757,6 +767,9 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     VP_HIP_CHECK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch, hipStreamNonBlocking));
+    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bfork, hipEventDisableTiming));
+    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bjoin, hipEventDisableTiming));
     h->overlap = true;
   }
   *out = h;
@@ -770,6 +783,10 @@ void vp_pixrefer_destroy(vp_pixrefer_t* h) {
     (void)hipEventDestroy(h->ev_fork);
     (void)hipEventDestroy(h->ev_join);
     (void)hipStreamDestroy(h->side);
+    (void)hipStreamSynchronize(h->branch);
+    (void)hipEventDestroy(h->ev_bfork);
+    (void)hipEventDestroy(h->ev_bjoin);
+    (void)hipStreamDestroy(h->branch);
   }
   delete h;
 }
@@ -832,7 +849,20 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
     VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
   }
 
-  for (Layer& L : h->G.l) if ((rc = run_layer_fwd(h, h->G, L, st))) return rc;
+  // generator: the two encoder branches (encoder_1..4 on `inputs`, encoder_fg_1..4 on `fg_inputs`, pixrefer.py:169-213) are
+  // independent chains of small kernels until merged_encoder_2: the foreground branch runs on the branch stream
+  const bool split_enc = d.training && h->overlap && g_overlap_on;
+  if (split_enc) {
+    VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
+    VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
+    for (Layer& L : h->G.l) if (L.scope.rfind("encoder_fg_", 0) == 0) if ((rc = run_layer_fwd(h, h->G, L, h->branch, nullptr, 2))) return rc;
+    VP_HIP_CHECK(hipEventRecord(h->ev_bjoin, h->branch));
+  }
+  for (Layer& L : h->G.l) {
+    if (split_enc && L.scope.rfind("encoder_fg_", 0) == 0) continue;
+    if (split_enc && L.scope == "merged_encoder_2") VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
+    if ((rc = run_layer_fwd(h, h->G, L, st))) return rc;
+  }
 
   CompositeArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -961,10 +991,10 @@ static int backward_d_on(vp_pixrefer_t* h, hipStream_t st, bool side) {
   for (int i = (int)D.l.size() - 1; i >= 0; --i) {
     Layer& L = D.l[i];
     Tens& to = D.t[L.out];
-    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, true, 0, 3 * N, 0, 3, st, side))) return rc;
+    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, true, 0, 3 * N, 0, 3, st, side ? 1 : 0))) return rc;
     const bool save = L.need_bwd[0];
     if (i == 0) L.need_bwd[0] = false;          // no gradient w.r.t. the images for the D loss
-    rc = run_layer_bwd(h, D, L, to.dz, true, false, 0, 3 * N, 0, st, side);
+    rc = run_layer_bwd(h, D, L, to.dz, true, false, 0, 3 * N, 0, st, side ? 1 : 0);
     L.need_bwd[0] = save;
     if (rc) return rc;
   }
@@ -1005,9 +1035,9 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   for (int i = (int)D.l.size() - 1; i >= 0; --i) {
     Layer& L = D.l[i];
     Tens& to = D.t[L.out];
-    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, false, 2 * N, N, 2, 1, st, false, true))) return rc;
+    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, false, 2 * N, N, 2, 1, st, 0, true))) return rc;
     const void* dy = (i == (int)D.l.size() - 1) ? h->dl_g : to.dz2;
-    if ((rc = run_layer_bwd(h, D, L, dy, false, true, 2 * N, N, 2, st, false, true))) return rc;
+    if ((rc = run_layer_bwd(h, D, L, dy, false, true, 2 * N, N, 2, st, 0, true))) return rc;
   }
   // (b) perceptual term through the VGG trunk, fake half only (dX only: VGG is frozen)
   for (Tens& t : V.t) t.dz_written = false;
@@ -1049,12 +1079,37 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   VP_HIP_CHECK(launch_composite_bwd(ca, bf, st));
   for (Tens& t : G.t) t.dz_written = false;
   }
-  // (d) generator, last layer first
+  // (d) generator, last layer first.  Below merged_encoder_2 the two encoder branches are independent again: the foreground
+  // branch (encoder_fg_4 .. encoder_fg_1) runs on the branch stream, joined before this call returns control of `st`
+  const bool split_enc = h->overlap && g_overlap_on && l_lo == 0;
+  const bool wsplit = h->overlap && g_overlap_on && !getenv("VP_NO_WSPLIT");
+  bool forked = false, fg_forked = false;
   for (int i = l_hi; i >= l_lo; --i) {
     Layer& L = G.l[i];
     Tens& to = G.t[L.out];
-    if (L.has_bn) if ((rc = run_bn_bwd(h, G, L, true, 0, N, 0, 1, st))) return rc;
-    if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st))) return rc;
+    const bool fg = split_enc && L.scope.rfind("encoder_fg_", 0) == 0;
+    if (fg && !fg_forked) {      // the branch's first layer needs merged_encoder_2's data gradient, enqueued on `st` just before
+      VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
+      VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
+      forked = fg_forked = true;
+    }
+    hipStream_t s2 = fg ? h->branch : st;
+    const int ss = fg ? 2 : 0;
+    if (L.has_bn) if ((rc = run_bn_bwd(h, G, L, true, 0, N, 0, 1, s2, ss))) return rc;
+    if (wsplit && !fg) {
+      // the weight gradient of a layer hangs off the chain (only its data gradient feeds the next layer): branch stream
+      VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
+      VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
+      forked = true;
+      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, h->branch, 2, false, 1))) return rc;
+      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st, 0, false, 2))) return rc;
+    } else {
+      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, s2, ss))) return rc;
+    }
+  }
+  if (forked) {
+    VP_HIP_CHECK(hipEventRecord(h->ev_bjoin, h->branch));
+    VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
   }
   return VP_OK;
 }
