@@ -51,6 +51,7 @@ def parse_args(argv=None):
   ap.add_argument("--no-f32", action="store_true")
   ap.add_argument("--no-other-scaling", action="store_true")
   ap.add_argument("--no-input-pipeline", action="store_true")
+  ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="vp_tune knob for experiments (repeatable)")
   return ap.parse_args(argv)
 
 
@@ -299,6 +300,11 @@ def main():
     group = dist.group.WORLD
     assert dist.get_world_size() == args.gpus
 
+  if args.tune:
+    from voicepuppet_amd import _lib
+    for kv in args.tune:
+      k, v = kv.split("=")
+      _lib.check(_lib.lib().vp_tune(k.encode(), int(v)), "vp_tune " + kv)
   main_res = run_config(per_gpu_batch(args, args.scaling, world), args.height, args.dtype, args.steps, args.warmup,
                         rank, world, device, group, not args.no_profile)
   other = None

@@ -695,6 +695,13 @@ extern "C" {
 
 static bool g_overlap_on = true;     // vp_tune("overlap", 0 / 1): per-kernel timing (bench.py's profile pass) needs one stream
 void vp_overlap_enable(int on) { g_overlap_on = on != 0; }
+// where vp_pixrefer_backward starts the discriminator-loss pass on the side stream: 0 = at once, 1 = behind the generator-loss pass
+// through the discriminator, 2 = behind its pass through the VGG trunk as well (i.e. under the generator's own backward)
+static int g_dfork_point = 2;
+void vp_dfork_point(int p) { g_dfork_point = p < 0 ? 0 : (p > 2 ? 2 : p); }
+static int g_dfork_pending = 0;
+static bool g_dsplit_on = true;      // discriminator fwd / generator-loss bwd through it on the branch stream, beside the VGG passes
+void vp_dsplit_enable(int on) { g_dsplit_on = on != 0; }
 
 int vp_version(void) { return 100; }
 const char* vp_last_error(void) { return g_err; }
@@ -871,14 +878,23 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   VP_HIP_CHECK(launch_composite_fwd(ca, bf, st));
   if (!d.training) return VP_OK;
 
-  // discriminator on [real1 | real2 | fake] (pixrefer.py:295-306)
-  for (Layer& L : h->D.l) if ((rc = run_layer_fwd(h, h->D, L, st))) return rc;
+  // discriminator on [real1 | real2 | fake] (pixrefer.py:295-306).  It and the fake half of the VGG trunk both hang off the
+  // composite only: the discriminator (conv + batch-norm glue, HBM-bound in between) runs on the branch stream under the VGG convs
+  const bool split_d = h->overlap && g_overlap_on && g_dsplit_on;
+  hipStream_t sd = split_d ? h->branch : st;
+  const int ssd = split_d ? 2 : 0;
+  if (split_d) {
+    VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
+    VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
+  }
+  for (Layer& L : h->D.l) if ((rc = run_layer_fwd(h, h->D, L, sd, nullptr, ssd))) return rc;
   const int hd = H / 8 - 2;
   GanLossArgs ga;
   memset(&ga, 0, sizeof(ga));
   ga.logits = h->logits; ga.dl_d = h->dl_d; ga.dl_g = h->dl_g; ga.predict = h->predict; ga.losses = h->losses;
   ga.M = N * hd * hd; ga.gan_weight = d.gan_weight;
-  VP_HIP_CHECK(launch_gan_loss(ga, bf, st));
+  VP_HIP_CHECK(launch_gan_loss(ga, bf, sd));
+  if (split_d) VP_HIP_CHECK(hipEventRecord(h->ev_bjoin, h->branch));
 
   // VGG trunk on [real fg | Outputs_FG] (pixrefer.py:321).  The real half does not depend on the generator: when every layer has
   // a half-batch plan it was started on the side stream right after pack_inputs (below, `vgg_half`) and only the fake half runs here
@@ -919,6 +935,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   pa.f3 = f3.y; pa.df3 = f3.dz; pa.partial = h->perc_partial; pa.half = f3.elems() / 2; pa.l1_weight = d.l1_weight;
   VP_HIP_CHECK(launch_perceptual(pa, bf, st));
 
+  if (split_d) VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
   LossFinalArgs lf;
   memset(&lf, 0, sizeof(lf));
   lf.comp_partial = h->comp_partial; lf.n_comp = h->n_comp; lf.perc_partial = h->perc_partial; lf.n_perc = h->n_perc;
@@ -929,6 +946,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
 }
 
 static int backward_d_on(vp_pixrefer_t* h, hipStream_t st, bool side);
+static int fork_d(vp_pixrefer_t* h, hipStream_t st);
 
 // Both gradient passes.  They are independent of each other (the discriminator-loss pass writes only the discriminator's gradient
 // arena and its own dz / scratch buffers, the generator-loss pass the generator's), so the discriminator-loss pass runs on a second
@@ -942,14 +960,22 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
     if (rc) return rc;
     return vp_pixrefer_backward_g(h, stream);
   }
-  VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
-  VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  int rc = backward_d_on(h, h->side, true);
-  if (rc) return rc;
-  VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+  int rc;
+  g_dfork_pending = g_dfork_point;
+  if (g_dfork_pending == 0 && (rc = fork_d(h, st))) return rc;
   rc = vp_pixrefer_backward_g(h, stream);
   if (rc) return rc;
   VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+  return VP_OK;
+}
+
+static int fork_d(vp_pixrefer_t* h, hipStream_t st) {
+  g_dfork_pending = 0;
+  VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+  VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  const int rc = backward_d_on(h, h->side, true);
+  if (rc) return rc;
+  VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
   return VP_OK;
 }
 
@@ -1031,14 +1057,24 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   if (stage <= 0) {
   // ---- Gen_loss -> generator* (pixrefer.py:402-407) ----
   // (a) GAN term through the fake application of the discriminator (dX only, pre-update weights)
+  // ... on the branch stream: independent of the VGG pass (b) until the composite (c) adds the two image gradients
+  const bool split_d = h->overlap && g_overlap_on && g_dsplit_on;
+  hipStream_t sd = split_d ? h->branch : st;
+  const int ssd = split_d ? 2 : 0;
+  if (split_d) {
+    VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
+    VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
+  }
   for (Tens& t : D.t) t.dz2_written = false;
   for (int i = (int)D.l.size() - 1; i >= 0; --i) {
     Layer& L = D.l[i];
     Tens& to = D.t[L.out];
-    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, false, 2 * N, N, 2, 1, st, 0, true))) return rc;
+    if (L.has_bn) if ((rc = run_bn_bwd(h, D, L, false, 2 * N, N, 2, 1, sd, ssd, true))) return rc;
     const void* dy = (i == (int)D.l.size() - 1) ? h->dl_g : to.dz2;
-    if ((rc = run_layer_bwd(h, D, L, dy, false, true, 2 * N, N, 2, st, 0, true))) return rc;
+    if ((rc = run_layer_bwd(h, D, L, dy, false, true, 2 * N, N, 2, sd, ssd, true))) return rc;
   }
+  if (split_d) VP_HIP_CHECK(hipEventRecord(h->ev_bjoin, h->branch));
+  if (g_dfork_pending == 1 && (rc = fork_d(h, st))) return rc;
   // (b) perceptual term through the VGG trunk, fake half only (dX only: VGG is frozen)
   for (Tens& t : V.t) t.dz_written = false;
   for (int i = (int)V.l.size() - 1; i >= 0; --i) {
@@ -1071,6 +1107,8 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
       VP_HIP_CHECK(launch_maxpool_bwd(xin, ti.dz, tc.dz, N, tc.H, tc.W, tc.C, bf, st));
     }
   }
+  if (split_d) VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
+  if (g_dfork_pending == 2 && (rc = fork_d(h, st))) return rc;
   // (c) composite + L1 / matte terms -> gradient w.r.t. the pre-tanh generator output
   CompositeArgs ca;
   memset(&ca, 0, sizeof(ca));
