@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the bench step (no CPU baseline, no f32, no event profiling), overlap on and off
+# rocprofv3 kernel stats of the bench step (no CPU baseline, no f32, no event profiling), single stream (VP_NO_OVERLAP) unless $1 = on
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 o=gpurun_out/kstats
-mkdir -p $o
-rocprofv3 --kernel-trace --stats -d $o/on -o on --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline > $o/on.log 2>&1
-VP_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d $o/off -o off --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline > $o/off.log 2>&1
-rm -f $o/on/*kernel_trace.csv $o/off/*kernel_trace.csv
-tail -c 300 $o/on.log; ls $o/on $o/off
+rm -rf $o; mkdir -p $o
+if [ "$1" != "on" ]; then export VP_NO_OVERLAP=1; fi
+rocprofv3 --kernel-trace --stats -d $o/r -o r --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline > $o/r.log 2>&1
+rm -f $o/r/*kernel_trace.csv
+python3 scripts/kstats_summary.py $o/r/r_kernel_stats.csv 13

@@ -1,0 +1,283 @@
+// igemm_patch3_kernel: the 3x3 / stride-1 form of the patch kernel (conv_patch.hip) with the whole (chunk pair x tap) schedule
+// unrolled.  PMC counters of the generic kernel on VGG conv1_2 (profiles/r02_pmc_sq_patch.txt): 7.6 vector-ALU and 9 scalar
+// instructions per MFMA - fragment addresses (a swizzle of pixel index + tap offset), tap / ring / chunk cursors, a branch tree for
+// the per-step patch DMA - and a vmcnt that waited for the patch DMA issued one step earlier.  Here
+//   * the patch swizzle depends on the COLUMN of a patch pixel only (slot = piece ^ ((px >> 2) & 3)): a tap's row shift is a
+//     plain byte offset.  With the taps unrolled the row shift, the buffer of the chunk and the ring stage are instruction
+//     immediates; the lane part of a B address is one of 3 (column shifts) x TP precomputed registers, of an A address one
+//     register.  A step issues NO vector ALU and a handful of scalar instructions;
+//   * the counted vmcnt of every step is exact (a compile-time function of the tap): only the weights of the step, never a patch
+//     DMA issued in the last two steps, are waited for;
+//   * patches first in LDS (their read offsets fit the 16-bit DS immediate), the weight ring behind them.
+// Bank behaviour of the fragment reads is that of conv_patch.hip: of the 16 consecutive pixels of a B fragment, the four that share
+// an address class (pp & 3) have four different (px >> 2) & 3, so a 32-lane service group of a ds_read_b64 hits 32 distinct 8-byte
+// slots for every column shift.  Two chunks (K = 2 x 64 bytes per tap) per trip: channel counts are multiples of 64 (bf16) / 32 (f32).
+#include <stdlib.h>
+
+#include <utility>
+
+#include "igemm_device.h"
+#include "launch.h"
+
+namespace vp {
+
+template <int TW>
+struct Patch3TilePix {
+  const IgemmArgs& a; int n, y0, x0;
+  __device__ __forceinline__ long long operator()(int row) const {
+    constexpr int BPR = TW / 16;
+    const int pb = row >> 4, i = row & 15;
+    const int y = y0 + pb / BPR, x = x0 + (pb % BPR) * 16 + i;
+    if (y >= a.Hg || x >= a.Wg) return -1;
+    const long long off = (((long long)n * a.Hof + y) * a.Wof + x) * a.ldY;
+    return (off << 8) | (long long)(n / a.ref_group_n);
+  }
+  static constexpr bool HAS_POOL = (TW == 16);
+  __device__ __forceinline__ long long pool(int pr, int pc) const {
+    const int y = (y0 >> 1) + pr, x = (x0 >> 1) + pc;
+    if (y >= (a.Hg >> 1) || x >= (a.Wg >> 1)) return -1;
+    return (((long long)n * (a.Hg >> 1) + y) * (a.Wg >> 1) + x) * a.ldY;
+  }
+};
+
+// Fragment reads as inline asm.  hipcc drains vmcnt in front of every LDS load it can see while an LDS-DMA is pending (the
+// __restrict__ route of conv_patch.hip loses its alias scopes in this fully unrolled form), which would serialise the DMA stream;
+// the ring discipline of the loop - counted vmcnt + barrier - is what orders these reads.  The destination registers are only
+// valid behind lds_fence() (s_waitcnt lgkmcnt(0) + a dependency on every register, so that no consumer is scheduled above it).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int IMM> __device__ __forceinline__ u32x2 lds_rd64(int addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(IMM));
+  return r;
+}
+template <int IMM> __device__ __forceinline__ u32x4 lds_rd128(int addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(IMM));
+  return r;
+}
+// second half of a B piece: address ^ 8, formed inside the asm so that it never occupies a register across steps
+template <int IMM> __device__ __forceinline__ u32x2 lds_rd64_x8(int addr) {
+  u32x2 r;
+  int t;
+  asm volatile("v_xor_b32 %1, 8, %2\n\tds_read_b64 %0, %1 offset:%3" : "=v"(r), "=&v"(t) : "v"(addr), "n"(IMM));
+  return r;
+}
+// B fragments of the step + the A fragments [A0, A0 + NA) of the wave, valid on return
+template <int NA, int TP, int AIMM, int BIMM, bool WITH_B>
+__device__ __forceinline__ void patch3_frag_read(int aaddr, const int (&b0)[TP], uint4 (&fa)[NA], uint4 (&fb)[TP]) {
+  u32x4 ra[NA];
+  u32x2 rl[TP], rh[TP];
+  if constexpr (WITH_B) {
+#pragma unroll
+    for (int t = 0; t < TP; ++t) { rl[t] = lds_rd64<BIMM>(b0[t]); rh[t] = lds_rd64_x8<BIMM>(b0[t]); }
+  }
+  static_assert(NA == 2 || NA == 4, "weight blocks per read batch");
+  ra[0] = lds_rd128<AIMM>(aaddr); ra[1] = lds_rd128<AIMM + 1024>(aaddr);
+  if constexpr (NA >= 4) { ra[2] = lds_rd128<AIMM + 2048>(aaddr); ra[3] = lds_rd128<AIMM + 3072>(aaddr); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (WITH_B) {
+#pragma unroll
+    for (int t = 0; t < TP; ++t) { asm volatile("" : "+v"(rl[t])); asm volatile("" : "+v"(rh[t])); fb[t] = make_uint4(rl[t].x, rl[t].y, rh[t].x, rh[t].y); }
+  }
+#pragma unroll
+  for (int t = 0; t < NA; ++t) { asm volatile("" : "+v"(ra[t])); fa[t] = make_uint4(ra[t].x, ra[t].y, ra[t].z, ra[t].w); }
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <typename F, int... Is> __device__ __forceinline__ void static_steps(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC>
+__global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs a) {
+  constexpr int E = Elem<T>::E, KC = 4 * E;
+  constexpr int NW = 8, NT = 512, NSTW = 3;
+  static_assert(WC * WP == NW, "eight waves");
+  constexpr int BC = WC * TC * 16, BP = TH * TW;
+  static_assert(BP == WP * TP * 16, "pixel blocks of the tile = pixel blocks of the waves");
+  constexpr int NBA = BC / 16;
+  static_assert(NBA % NW == 0 || NBA == 4, "weight DMAs: whole instructions per wave (64-row tiles: half an instruction per wave)");
+  constexpr int JA = (NBA + NW - 1) / NW;
+  constexpr bool HALFW = NBA < NW;
+  constexpr int PW = TW + 2, PH = TH + 2, NPATCH = PW * PH;
+  constexpr int PPAD = (NPATCH + 127) / 128 * 128;                   // patch pixels, padded to whole DMA rounds of the 8 waves
+  constexpr int JP = PPAD / 128;                                     // patch DMA instructions per wave and chunk
+  static_assert(JP <= 7, "one patch DMA per tap step, none in the last two");
+  constexpr int PBUFB = PPAD * 64;                                   // bytes of one patch buffer
+  constexpr int WSTB = 4 * BC * 16;                                  // bytes of one weight stage
+  constexpr int WBASE = 2 * PBUFB;
+  static_assert(PBUFB + 2 * PW * 64 + 64 < 65536 && 2 * WSTB + 7 * 1024 + 16 < 65536, "read offsets are DS immediates");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c_base = blockIdx.y * BC;
+  const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
+  const int bt = blockIdx.x;
+  const int n = bt / (tiles_x * tiles_y);
+  const int trem = bt - n * (tiles_x * tiles_y);
+  const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+  // tap t = 3r + c reads input pixel (y + p_dhf + r * p_dhs, x + p_dwf + c * p_dws); both steps are +1 (forward) or both -1
+  // (backward-data: the flipped kernel).  The loop walks PATCH positions (pr, pc) in a fixed order; the weight chunk that belongs
+  // to patch position u is tap u (forward) or tap 8 - u (flipped)
+  const bool flip = a.p_dhs < 0;
+  const int dh0 = flip ? a.p_dhf - 2 : a.p_dhf, dw0 = flip ? a.p_dwf - 2 : a.p_dwf;
+  const unsigned es = sizeof(T);
+  const int C0 = a.x.C[0];
+  const int nchunkc = C0 / KC;                  // channel chunks (even)
+
+  __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp), 0xFFFFFFFFu);
+  __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * es));
+
+  // patch DMA lanes: instruction j of this wave covers patch pixels (wave + 8j) * 16 .. + 15, lane -> (pixel, slot)
+  unsigned pvo[JP];
+#pragma unroll
+  for (int j = 0; j < JP; ++j) {
+    const int pp = (wave + NW * j) * 16 + (lane >> 2);
+    const int py = pp / PW, px = pp - py * PW;
+    const int ih = y0 + dh0 + py, iw = x0 + dw0 + px;
+    const bool ok = pp < NPATCH && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+    const int piece = (lane & 3) ^ ((px >> 2) & 3);
+    pvo[j] = ok ? (unsigned)((((n * a.Hin + ih) * a.Win + iw) * C0 + piece * E) * es) : DMA_OOB;
+  }
+  // weight DMA lanes (rb_swz image); 64-row tiles: every wave moves half a 16-row block (lanes 0-31)
+  unsigned wvo[JA];
+  {
+    const int r = HALFW ? (wave & 1) * 8 + (lane >> 2) : lane >> 2;
+    const int g = (lane & 3) ^ rb_swz(r & 15);
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      const int blk = HALFW ? (wave >> 1) : wave + NW * j;
+      wvo[j] = (unsigned)(((c_base + blk * 16 + r) * KC + g * E) * es);
+    }
+  }
+  const unsigned wstep = (unsigned)(a.wp_rows * KC * es);
+  // weights of patch position u (tap u or 8 - u) and channel chunk c -> ring stage `stage`
+  auto issue_w = [&](int u, int chunk, int stage) {
+    const int tap = flip ? 8 - u : u;
+    const unsigned wso = (unsigned)(tap * nchunkc + chunk) * wstep;
+    uint4* la = reinterpret_cast<uint4*>(smem + WBASE + stage * WSTB);
+    if constexpr (HALFW) {
+      if (lane < 32) dma16_buf(rsW, wvo[0], wso, la + (wave >> 1) * 64 + (wave & 1) * 32);
+    } else {
+#pragma unroll
+      for (int j = 0; j < JA; ++j) dma16_buf(rsW, wvo[j], wso, la + (wave + NW * j) * 64);
+    }
+  };
+  auto issue_p = [&](int chunk, int buf, int j) {
+    uint4* lb = reinterpret_cast<uint4*>(smem + buf * PBUFB);
+    dma16_buf(rsX, pvo[j], (unsigned)(chunk * KC) * es, lb + (wave + NW * j) * 64);
+  };
+
+  const int wc = wave / WP, wpi = wave - wc * WP;
+  const int blkA0 = wc * TC, blkB0 = wpi * TP;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int aaddr = WBASE + (blkA0 * 64 + fi * 4 + (fg ^ rb_swz(fi))) * 16;     // (ring base folded in: stage and block offsets fit the immediate)
+  // B fragment lane offsets per column shift c: patch pixel (row of the pixel block, its first column + lane + c)
+  int tb0[3][TP];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int q = 0; q < TP; ++q) {
+      constexpr int BPR = TW / 16;
+      const int pb = blkB0 + q;
+      const int px = (pb % BPR) * 16 + fi + c;
+      const int pp = (pb / BPR) * PW + px;
+      tb0[c][q] = (pp << 6) + (((fg ^ (px >> 2)) & 3) << 4) + ((fg & 1) << 3);
+    }
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: the whole first patch, then the weights of the first two steps
+#pragma unroll
+  for (int j = 0; j < JP; ++j) issue_p(0, 0, j);
+  issue_w(0, 0, 0);
+  issue_w(1, 0, 1);
+
+  // One trip = 2 chunks x 9 patch positions.  Step U = 9 * cc + u (cc: chunk of the pair = patch buffer, u: patch position);
+  // ring stage U % 3.  In DMA order behind the weights of step U: [patch piece issued at U-2], weights of U+1, [patch piece of U-1]
+  // - a piece is issued at the steps with u < JP, always (behind the last chunk it fetches bytes nobody reads, into the idle buffer)
+  for (int c = 0; c < nchunkc; c += 2) {
+    const bool last_pair = c + 2 >= nchunkc;
+    auto step = [&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      constexpr int cc = U / 9, u = U % 9, pr = u / 3, pc = u % 3, stage = U % 3;
+      constexpr int um1 = (U + 17) % 18 % 9, um2 = (U + 16) % 18 % 9;            // patch positions of the two previous steps
+      constexpr int NV = JA + (um1 < JP ? 1 : 0) + (um2 < JP ? 1 : 0);
+      if (U == 17 && last_pair) wait_vm<NV - JA>();                            // (no weights of a next step behind the last one)
+      else wait_vm<NV>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // weights two steps ahead (ring stage (U + 2) % 3, last read in step U - 1)
+      {
+        constexpr int U2 = (U + 2) % 18;
+        if (U < 16) issue_w(U2 % 9, c + U2 / 9, (U + 2) % 3);
+        else if (!last_pair) issue_w(U2 % 9, c + 2, (U + 2) % 3);
+      }
+      if constexpr (u < JP) issue_p(c + cc + 1, 1 - cc, u);
+      // eight weight blocks per wave: two read batches of four (16 fragment registers instead of 32); the 64-accumulator tile at
+      // two blocks per CU (128 registers per lane): batches of two
+      constexpr int NA = TC == 8 ? 4 : ((TC == 4 && OCC == 4) ? 2 : TC);
+      uint4 fb[TP];
+#pragma unroll
+      for (int h = 0; h < TC / NA; ++h) {
+        uint4 fa[NA];
+        if (h == 0) patch3_frag_read<NA, TP, stage * WSTB, cc * PBUFB + pr * PW * 64, true>(aaddr, tb0[pc], fa, fb);
+        else patch3_frag_read<NA, TP, stage * WSTB + NA * 1024, cc * PBUFB + pr * PW * 64, false>(aaddr, tb0[pc], fa, fb);
+#pragma unroll
+        for (int tc = 0; tc < NA; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < TP; ++tp) acc[h * NA + tc][tp] = mma16<T>(fa[tc], fb[tp], acc[h * NA + tc][tp]);
+      }
+    };
+    static_steps(step, std::make_integer_sequence<int, 18>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing patch pieces: the epilogue reuses the LDS
+
+  constexpr int RINGB = NSTW * WSTB + 2 * PBUFB;
+  constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
+  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, Patch3TilePix<TW>{a, n, y0, x0}, c_base, blkA0, blkB0, acc, smem, bt, 0);
+}
+
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int OCC>
+static hipError_t launch_patch3_t(const IgemmArgs& b, hipStream_t st) {
+  constexpr int BC = WC * TC * 16, BP = TH * TW;
+  constexpr int PPAD = ((TH + 2) * (TW + 2) + 127) / 128 * 128;
+  constexpr int RINGB = 3 * 4 * BC * 16 + 2 * PPAD * 64;
+  constexpr int NPE = epi_passes(BC, BP, WP, RINGB);
+  size_t sm = RINGB;
+  const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
+  if (se > sm) sm = se;
+  const int tiles = b.N * ((b.Hg + TH - 1) / TH) * ((b.Wg + TW - 1) / TW);
+  dim3 grid(tiles, b.CoutPad / BC, 1);
+  auto kern = b.bn_part ? igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC> : igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(kern, grid, dim3(512), sm, st, b);
+  return hipGetLastError();
+}
+
+// 3x3 taps on a +1 / +1 or -1 / -1 grid, an even number of 64-byte channel chunks: what the unrolled kernel handles
+bool patch3_eligible(const IgemmArgs& a, int is_bf16) {
+  const int kc = is_bf16 ? 32 : 16;
+  return a.patch && a.ntaps == 9 && a.p_kw == 3 && a.p_dhs == a.p_dws && (a.p_dhs == 1 || a.p_dhs == -1) && a.x.C[0] % (2 * kc) == 0 &&
+         a.x.C[1] == 0;
+}
+
+// same tile menu as launch_igemm_patch (conv_patch.hip)
+hipError_t launch_igemm_patch3(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st) {
+  IgemmArgs b = a;
+  b.vec_epi = 1;
+#define VP_PATCH3_GO(WC, WP, TC, TP, TH, TW, OCC) \
+  (is_bf16 ? launch_patch3_t<bf16, WC, WP, TC, TP, TH, TW, OCC>(b, st) : launch_patch3_t<float, WC, WP, TC, TP, TH, TW, OCC>(b, st))
+  if (bc == 256) return bp == 128 ? VP_PATCH3_GO(2, 4, 8, 2, 8, 16, 4) : VP_PATCH3_GO(2, 4, 8, 4, 16, 16, 2);
+  if (bc == 128) return bp == 512 ? VP_PATCH3_GO(1, 8, 8, 4, 16, 32, 2) : VP_PATCH3_GO(2, 4, 4, 4, 16, 16, 4);
+  return bp == 512 ? VP_PATCH3_GO(1, 8, 4, 4, 16, 32, 2) : VP_PATCH3_GO(2, 4, 2, 4, 16, 16, 4);
+#undef VP_PATCH3_GO
+}
+
+}  // namespace vp

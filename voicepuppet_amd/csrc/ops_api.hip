@@ -69,6 +69,7 @@ int vp_tune(const char* key, int value) {
   if (k == "d_backward_fork") { vp_dfork_point(value); return VP_OK; }
   if (k == "d_beside_vgg") { vp_dsplit_enable(value); return VP_OK; }
   if (k == "wgrad_tr") { wgrad_tr_knob() = value; return VP_OK; }
+  if (k == "patch3") { patch3_knob() = value; return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
   return VP_ERR_ARG;
 }

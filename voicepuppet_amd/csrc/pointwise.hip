@@ -121,17 +121,32 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs a) {
   }
   const T* y = reinterpret_cast<const T*>(a.y) + (size_t)grp * a.Pg * a.C + cgi * E;
   const T* dz = reinterpret_cast<const T*>(a.dz) + (size_t)grp * a.Pg * a.C + cgi * E;
-  for (int p = p0 + prow; p < p1; p += nprow) {
-    float fy[E];
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + (size_t)p * a.C), fy);
-    if (MODE == 0) {
+  // four pixel rows per trip, all their loads issued before the first use (the pass is latency-bound otherwise); the sums still
+  // run over p in ascending order, i.e. the result is the same bit for bit as a one-row-per-trip loop
+  constexpr int U = 4;
+  for (int p = p0 + prow; p < p1; p += U * nprow) {
+    uint4 ry[U], rd[U];
 #pragma unroll
-      for (int e = 0; e < E; ++e) { s0[e] += fy[e]; s1[e] += (double)fy[e] * fy[e]; }
-    } else {
-      float fd[E];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(dz + (size_t)p * a.C), fd);
+    for (int u = 0; u < U; ++u) {
+      const int pu = p + u * nprow;
+      const bool ok = pu < p1;
+      ry[u] = ok ? *reinterpret_cast<const uint4*>(y + (size_t)pu * a.C) : make_uint4(0, 0, 0, 0);
+      if (MODE == 1) rd[u] = ok ? *reinterpret_cast<const uint4*>(dz + (size_t)pu * a.C) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
-      for (int e = 0; e < E; ++e) { s0[e] += fd[e]; s1[e] += (double)fd[e] * ((fy[e] - mu[e]) * rs[e]); }
+    for (int u = 0; u < U; ++u) {
+      if (p + u * nprow >= p1) break;
+      float fy[E];
+      Elem<T>::unpack(ry[u], fy);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { s0[e] += fy[e]; s1[e] += (double)fy[e] * fy[e]; }
+      } else {
+        float fd[E];
+        Elem<T>::unpack(rd[u], fd);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { s0[e] += fd[e]; s1[e] += (double)fd[e] * ((fy[e] - mu[e]) * rs[e]); }
+      }
     }
   }
   // reduce over the pixel lanes that share a channel group
@@ -211,20 +226,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
   const T* y = reinterpret_cast<const T*>(a.y);
   const T* dz = reinterpret_cast<const T*>(a.dz);
   T* dy = reinterpret_cast<T*>(a.dy);
+  // ncg divides 256: a thread stays on one channel group; its five per-channel coefficients change only with the BN group
+  // (any other channel count: reloaded per item)
+  const bool fixed = 256 % ncg == 0;
+  int cur = -1;
+  float frs[E], fmu[E], fgm[E], fc1[E], fc2[E];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cgi = (int)(i % ncg);
+    const int c0 = (int)(i % ncg) * E;
     const size_t pix = i / ncg;
     const int grp = (int)(pix / a.Pg);
-    const int c0 = cgi * E;
+    if (grp != cur || !fixed) {
+      cur = grp;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int gi = grp * a.C + c0 + e;
+        frs[e] = a.rstd[gi]; fmu[e] = a.mu[gi]; fc1[e] = a.c1[gi]; fc2[e] = a.c2[gi]; fgm[e] = a.gamma[c0 + e];
+      }
+    }
     float fy[E], fd[E];
     Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + pix * a.C + c0), fy);
     Elem<T>::unpack(*reinterpret_cast<const uint4*>(dz + pix * a.C + c0), fd);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int gi = grp * a.C + c0 + e;
-      const float rs = a.rstd[gi];
-      const float zh = (fy[e] - a.mu[gi]) * rs;
-      fd[e] = a.gamma[c0 + e] * rs * (fd[e] - a.c1[gi] - zh * a.c2[gi]);
+      const float zh = (fy[e] - fmu[e]) * frs[e];
+      fd[e] = fgm[e] * frs[e] * (fd[e] - fc1[e] - zh * fc2[e]);
     }
     *reinterpret_cast<uint4*>(dy + pix * a.C + c0) = Elem<T>::pack(fd);
   }
@@ -377,15 +402,25 @@ __global__ __launch_bounds__(256) void act_apply_kernel(const T* __restrict__ y,
   constexpr int E = Elem<T>::E;
   const int ncg = C / E;
   const size_t total = npix * ncg;
+  // ncg divides 256: a thread stays on one channel group for all its items, its scale / shift change only with the BN group
+  // (any other channel count: reloaded per item)
+  const bool fixed = 256 % ncg == 0;
+  int cur = -1;
+  float fsc[E], fsh[E];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int cg = (int)(i % ncg);
     const size_t pix = i / ncg;
     float f[E], o[E];
     Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + pix * C + cg * E), f);
     if (sc) {
-      const int go = (int)(pix / Pg) * C + cg * E;
+      const int grp = (int)(pix / Pg);
+      if (grp != cur || !fixed) {
+        cur = grp;
 #pragma unroll
-      for (int e = 0; e < E; ++e) f[e] = fmaf(sc[go + e], f[e], sh[go + e]);
+        for (int e = 0; e < E; ++e) { fsc[e] = sc[grp * C + cg * E + e]; fsh[e] = sh[grp * C + cg * E + e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) f[e] = fmaf(fsc[e], f[e], fsh[e]);
     }
     if (out_lrelu) {
 #pragma unroll
@@ -794,7 +829,7 @@ int bn_nchunk(int Pg, int C, int G, int is_bf16) {
   const int E = is_bf16 ? 8 : 4;
   const int nprow = 256 / (C / E);
   int n = (Pg + nprow * 8 - 1) / (nprow * 8);       // >= 8 pixel rows per thread
-  const int cap = 1024 / G;
+  const int cap = 1024 / G;                         // (bn_partial holds 1024 chunk rows)
   if (n > cap) n = cap;
   return n < 1 ? 1 : n;
 }
