@@ -69,7 +69,9 @@ __device__ __forceinline__ const void* tr_src(const WgradArgs& a, const TrTask& 
   return ok ? (const void*)(t.base + ((size_t)(n * t.Hs + ih) * t.Ws + iw) * t.C) : a.zeros;
 }
 
-template <int WM, int WN, int TC, int TP, int NST, bool FAST>
+// EXACT (fast path only): the padded K grid IS the dY image (Hb = 2^lh, Wb = 2^lw): no slot of a chunk lies outside it, the dY
+// lanes need no per-chunk work at all and the gathered lanes only their two tap range checks
+template <int WM, int WN, int TC, int TP, int NST, bool FAST, bool EXACT = false>
 __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradArgs a) {
   constexpr int NW = WM * WN;
   static_assert(NW == 8, "eight waves");
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradAr
     const int chl = (int)(t.base - reinterpret_cast<const bf16*>(gsecond ? a.g.ptr[1] : a.g.ptr[0]));   // channel offset inside the source
     fvo[j] = gguard + (unsigned)(((fB[j] * a.Wgin + fD[j]) * gC + chl) * 2);
     fok[j] = t.ok;
+    if (EXACT && !t.ok) fvo[j] = DMA_OOB;
   }
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradAr
     const int chl = (int)(t.base - reinterpret_cast<const bf16*>(dsecond ? a.d.ptr[1] : a.d.ptr[0]));
     bvo[j] = (unsigned)(((bq[j] * a.Wb + br[j]) * dC + chl) * 2);
     bok[j] = t.ok;
+    if (EXACT && !t.ok) bvo[j] = DMA_OOB;
   }
   auto issue_fast = [&](int it, int stage) {
     uint4* la = lds + stage * STG;
@@ -157,16 +161,27 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradAr
     const unsigned gso = (unsigned)((((nu * a.Hgin + qu * a.s) * a.Wgin + ru * a.s) * gC) * 2);
     const unsigned dso = (unsigned)((((nu * a.Hb + qu) * a.Wb + ru) * dC) * 2);
     const int qs = qu * a.s, rs = ru * a.s;
+    if constexpr (EXACT) {
+      // (it < niter = N * 2^(lh+lw) / 32: nu < N; fok / bok are folded into fvo / bvo)
 #pragma unroll
-    for (int j = 0; j < JA; ++j) {
-      const bool ok = fok[j] && nok && qu + fq[j] < a.Hb && ru + fr[j] < a.Wb &&
-                      (unsigned)(qs + fB[j]) < (unsigned)a.Hgin && (unsigned)(rs + fD[j]) < (unsigned)a.Wgin;
-      dma16_buf(rsG, ok ? fvo[j] : DMA_OOB, gso, la + (wave + NW * j) * 64);
-    }
+      for (int j = 0; j < JA; ++j) {
+        const bool ok = (unsigned)(qs + fB[j]) < (unsigned)a.Hgin && (unsigned)(rs + fD[j]) < (unsigned)a.Wgin;
+        dma16_buf(rsG, ok ? fvo[j] : DMA_OOB, gso, la + (wave + NW * j) * 64);
+      }
 #pragma unroll
-    for (int j = 0; j < JB; ++j) {
-      const bool ok = bok[j] && nok && qu + bq[j] < a.Hb && ru + br[j] < a.Wb;
-      dma16_buf(rsD, ok ? bvo[j] : DMA_OOB, dso, lb + (wave + NW * j) * 64);
+      for (int j = 0; j < JB; ++j) dma16_buf(rsD, bvo[j], dso, lb + (wave + NW * j) * 64);
+    } else {
+#pragma unroll
+      for (int j = 0; j < JA; ++j) {
+        const bool ok = fok[j] && nok && qu + fq[j] < a.Hb && ru + fr[j] < a.Wb &&
+                        (unsigned)(qs + fB[j]) < (unsigned)a.Hgin && (unsigned)(rs + fD[j]) < (unsigned)a.Wgin;
+        dma16_buf(rsG, ok ? fvo[j] : DMA_OOB, gso, la + (wave + NW * j) * 64);
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const bool ok = bok[j] && nok && qu + bq[j] < a.Hb && ru + br[j] < a.Wb;
+        dma16_buf(rsD, ok ? bvo[j] : DMA_OOB, dso, lb + (wave + NW * j) * 64);
+      }
     }
   };
   auto issue = [&](int it, int stage) {
@@ -266,7 +281,8 @@ hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st) {
   if (a.g.C[1] > 0) fast = fast && a.Gc >= BM && a.g.C[0] % BM == 0;                                // an operand tile never straddles a virtual concat
   if (a.d.C[1] > 0) fast = fast && a.d.C[0] % BN == 0;
   b.fast_tr = fast ? 1 : 0;
-  auto kern = fast ? wgrad_tr_kernel<4, 2, 4, 4, NST, true> : wgrad_tr_kernel<4, 2, 4, 4, NST, false>;
+  const bool exact = fast && a.Hb == (1 << a.lh) && a.Wb == (1 << a.lw);
+  auto kern = exact ? wgrad_tr_kernel<4, 2, 4, 4, NST, true, true> : fast ? wgrad_tr_kernel<4, 2, 4, 4, NST, true> : wgrad_tr_kernel<4, 2, 4, 4, NST, false>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, b);
   return hipGetLastError();
