@@ -245,8 +245,9 @@ def run_with_input_pipeline(per_gpu, height, dtype, steps, warmup, device):
   eng.load_params(eng.random_params(seed=0))
   rng = np.random.default_rng(0)
   S = height
-  pool = [(rng.integers(0, 256, (per_gpu, S, 3 * S, 3)).astype(np.uint8), rng.integers(0, 256, (per_gpu, S, 3 * S, 3)).astype(np.uint8),
-           np.tile(np.array([[[3, 5, S - 8], [0, 2, S - 4]]], np.int32), (per_gpu, 1, 1))) for _ in range(3)]
+  pin = lambda a: torch.from_numpy(a).pin_memory()       # decoded frames wait in pinned host memory, as a decoder thread would leave them
+  pool = [(pin(rng.integers(0, 256, (per_gpu, S, 3 * S, 3)).astype(np.uint8)), pin(rng.integers(0, 256, (per_gpu, S, 3 * S, 3)).astype(np.uint8)),
+           pin(np.tile(np.array([[[3, 5, S - 8], [0, 2, S - 4]]], np.int32), (per_gpu, 1, 1)))) for _ in range(4)]
 
   def source():
     k = 0

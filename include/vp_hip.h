@@ -63,6 +63,11 @@ int vp_pixrefer_param_info(const vp_pixrefer_desc* d, int which, int index, char
                            size_t* offset, int* ndim, int64_t shape[4]);
 
 size_t vp_pixrefer_workspace_bytes(const vp_pixrefer_desc* d);
+/* Host-only self-check of the plan a descriptor produces (no GPU needed): every buffer the kernels would be handed is a carved
+ * region of sufficient size inside the workspace, regions do not overlap, parameter / packed-weight ranges lie inside their
+ * arenas, split-K slabs fit the scratch.  VP_OK, VP_ERR_ARG (bad descriptor) or VP_ERR_STATE (vp_last_error names the breach).
+ * Run under AddressSanitizer / UBSan by the `make host-asan` build of the host layer (tests/test_host_logic.py). */
+int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d);
 
 /* params_* / grads_*: flat f32 device arenas laid out as the manifest says (grads may be NULL when
  * training == 0; params_d / params_vgg likewise). */

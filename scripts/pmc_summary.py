@@ -23,6 +23,26 @@ def classify(name):
   garbled: bf16 'DF16b' confuses its demangler and swallows the first int) demangled one; None for other kernels."""
   if "conv_cin8_kernel" in name:
     return "cin8_bf16_64x16"
+  if "wgrad_tr_kernel" in name:
+    return "wgrad_bf16_256x128"
+  for fam in ("igemm_patch3_kernel", "igemm_patch_kernel"):
+    if fam not in name:
+      continue
+    m = re.search(fam + r"I(DF16b|f)((?:Li\d+E)+)", name)
+    if m:
+      dt = "bf16" if m.group(1) == "DF16b" else "f32"
+      ints = [int(x) for x in re.findall(r"Li(\d+)E", m.group(2))]
+    else:
+      m = re.search(fam + r"<(.*?)>\(", name)
+      if not m:
+        return None
+      args = [a.strip() for a in m.group(1).split(",")]
+      dt = "f32" if args[0] == "float" else "bf16"
+      ints = [int(a) for a in args if a.isdigit()]
+    if len(ints) < 6:
+      return None
+    wc, wp, tc, tp, th, tw = ints[:6]
+    return "patch_%s_%dx%d" % (dt, wc * tc * 16, th * tw)
   for fam, tiles in (("igemm_dma_kernel", IGEMM_TILES), ("igemm_ws_kernel", IGEMM_TILES), ("igemm_regb_kernel", IGEMM_TILES), ("wgrad_kernel", WGRAD_TILES)):
     if fam not in name:
       continue

@@ -245,3 +245,57 @@ def test_clip_sharding_and_the_config5_launcher(tmp_path, monkeypatch):
   for r, (argv, env) in enumerate(cmds):
     assert env["RANK"] == env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "8"
     assert argv[1:3] == ["-m", "voicepuppet_amd.pixrefer.infer_clips"] and argv[-1] == "clips.txt" and "--gpus" in argv
+
+
+_VALIDATE_SNIPPET = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+from voicepuppet_amd import _lib
+L = _lib.lib()
+bad = 0
+# (batch, height, ngf, ndf, dtype, training, per_sample_bn): BASELINE.json configs 1, 2, 4 (per GPU), 5 and two corner cases
+for cfg in [(1, 256, 64, 64, 0, 0, 0), (32, 256, 64, 64, 1, 1, 0), (8, 512, 64, 64, 1, 1, 0), (25, 256, 64, 64, 1, 0, 1), (2, 256, 8, 8, 0, 1, 0), (3, 512, 16, 32, 1, 1, 0)]:
+  d = _lib.PixReferDesc(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], 500.0, 1.0, cfg[6])
+  rc = L.vp_pixrefer_validate_plan(ctypes.byref(d))
+  ws = L.vp_pixrefer_workspace_bytes(ctypes.byref(d))
+  n = sum(L.vp_pixrefer_param_count(ctypes.byref(d), w) for w in range(3))
+  print(cfg, rc, ws, n, L.vp_last_error().decode() if rc else "")
+  bad += rc != 0 or ws == 0 or n == 0
+# descriptors the planner must refuse (no out-of-bounds plan is ever built for them)
+for cfg in [(0, 256, 64, 64, 1, 1, 0), (4, 200, 64, 64, 1, 1, 0), (4, 256, 128, 64, 1, 1, 0), (4, 256, 64, 48, 1, 1, 0), (2000, 256, 64, 64, 1, 0, 1)]:
+  d = _lib.PixReferDesc(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], 500.0, 1.0, cfg[6])
+  rc = L.vp_pixrefer_validate_plan(ctypes.byref(d))
+  print("refused", cfg, rc)
+  bad += rc != -1
+sys.exit(1 if bad else 0)
+"""
+
+
+def _run_validate(env_extra):
+  import subprocess
+  env = dict(os.environ)
+  env.update(env_extra)
+  return subprocess.run([sys.executable, "-c", _VALIDATE_SNIPPET % ROOT], env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_plan_validation_every_baseline_config():
+  """vp_pixrefer_validate_plan (host-only: no GPU call) on the descriptors of every BASELINE.json config."""
+  r = _run_validate({})
+  assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_host_layer_under_sanitizers():
+  """The `make host-asan` build of the host / C-ABI layer (AddressSanitizer + UBSan, kernels reduced to launch stubs) plans and
+  validates the same descriptors: a heap overrun or UB in the planner fails here, on the CPU (GPU sanitizers do not exist on this pool)."""
+  import shutil, subprocess
+  csrc = os.path.join(ROOT, "voicepuppet_amd", "csrc")
+  if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+    pytest.skip("no hipcc: the sanitizer build needs the HIP host compiler")
+  b = subprocess.run(["make", "-C", csrc, "-j4", "host-asan"], capture_output=True, text=True, timeout=900)
+  assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
+  so = os.path.join(ROOT, "voicepuppet_amd", "libvp_host_asan.so")
+  rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+  assert os.path.exists(rt), rt
+  r = _run_validate({"VP_LIB": so, "LD_PRELOAD": rt, "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0:exitcode=99", "UBSAN_OPTIONS": "halt_on_error=1:exitcode=98"})
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+  assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]

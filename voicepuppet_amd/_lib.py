@@ -47,6 +47,7 @@ _SIGNATURES = {
                                               ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int),
                                               ctypes.POINTER(ctypes.c_int64)]),
     "vp_pixrefer_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(PixReferDesc)]),
+    "vp_pixrefer_validate_plan": (ctypes.c_int, [ctypes.POINTER(PixReferDesc)]),
     "vp_pixrefer_create": (ctypes.c_int, [ctypes.POINTER(PixReferDesc), _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P,
                                           ctypes.POINTER(_P)]),
     "vp_pixrefer_destroy": (None, [_P]),

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "conv_ops.h"
@@ -34,9 +35,11 @@ void set_err(const char* fmt, ...) {
 struct Arena {
   char* base;
   size_t off, cap;
+  std::vector<std::pair<size_t, size_t>>* track = nullptr;   // (offset, bytes) of every carve: vp_pixrefer_validate_plan
   void* alloc(size_t bytes) {
     off = (off + 255) & ~(size_t)255;
     void* p = base ? base + off : nullptr;
+    if (track) track->push_back({off, bytes});
     off += bytes;
     return p;
   }
@@ -374,8 +377,9 @@ static void carve_net(Net& n, Arena& ar, int es, bool training) {
   (void)training;
 }
 
-static size_t carve_all(vp_pixrefer* h, char* base, size_t cap) {
+static size_t carve_all(vp_pixrefer* h, char* base, size_t cap, std::vector<std::pair<size_t, size_t>>* track = nullptr) {
   Arena ar{base, 0, cap};
+  ar.track = track;
   const vp_pixrefer_desc& d = h->d;
   const int N = d.batch, H = d.height, es = h->es;
   const size_t px = (size_t)N * H * H;
@@ -741,6 +745,99 @@ size_t vp_pixrefer_workspace_bytes(const vp_pixrefer_desc* d) {
   const size_t n = carve_all(h, nullptr, 0);
   delete h;
   return n;
+}
+
+// Host-only self-check of a plan (no GPU call; the sanitizer build of the host layer runs it on the CPU, tests/test_host_logic.py):
+// carves the workspace at a fake base and verifies that every buffer the kernels will be handed is a carved region of sufficient
+// size, that regions are disjoint and inside the workspace, that every parameter / packed-weight range lies inside its arena and
+// that every plan's split-K slab fits the scratch and its statistics the batch-norm partial buffer.
+int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d) {
+  if (!valid_desc(d)) return VP_ERR_ARG;
+  vp_pixrefer* h = new vp_pixrefer{};
+  init_handle(h, d);
+  const size_t need = carve_all(h, nullptr, 0);
+  std::vector<std::pair<size_t, size_t>> regs;
+  char* const base = reinterpret_cast<char*>((uintptr_t)1 << 40);        // never dereferenced
+  carve_all(h, base, need, &regs);
+  int rc = VP_OK;
+  auto fail = [&](const char* fmt, auto... args) { if (rc == VP_OK) { set_err(fmt, args...); rc = VP_ERR_STATE; } };
+  size_t prev_end = 0;
+  for (size_t i = 0; i < regs.size(); ++i) {
+    if (regs[i].first % 256) fail("region %zu at %zu: not 256-byte aligned", i, regs[i].first);
+    if (regs[i].first < prev_end) fail("region %zu at %zu overlaps the previous one (ends %zu)", i, regs[i].first, prev_end);
+    prev_end = regs[i].first + regs[i].second;
+  }
+  if (prev_end + 256 > need + 256 || prev_end > need) fail("carved %zu bytes of a %zu-byte workspace", prev_end, need);
+  auto region_of = [&](const void* p, size_t bytes, const char* what) {
+    if (!p) { fail("%s: null", what); return; }
+    const size_t off = (size_t)((const char*)p - base);
+    for (const auto& r : regs)
+      if (off >= r.first && off + bytes <= r.first + r.second) return;
+    fail("%s: [%zu, +%zu) is not inside a carved region", what, off, bytes);
+  };
+  const int es = h->es;
+  for (Net* n : {&h->G, &h->D, &h->V}) {
+    if (n->t.empty()) continue;
+    for (const Tens& t : n->t) {
+      const std::string nm = t.name;
+      if (t.name == "decoder_1" || t.name == "layer_5") continue;       // thin f32 outputs live in handle-level buffers (checked below)
+      region_of(t.y, t.elems() * es, (nm + ".y").c_str());
+      for (int k = 1; k < 3; ++k) if (t.need_act[k]) region_of(t.xa[k], t.elems() * es, (nm + ".xa").c_str());
+      if (t.has_bn) {
+        const size_t gc = (size_t)n->groups * t.C * sizeof(float);
+        for (const float* p : {t.bn.a, t.bn.b, t.bn.mu, t.bn.rstd, t.bn.c1, t.bn.c2, t.bn.c1g, t.bn.c2g}) region_of(p, gc, (nm + ".bn").c_str());
+        if ((size_t)n->groups * t.C > (size_t)1024 * 512) fail("%s: %d groups x %d channels exceed the batch-norm partial rows", nm.c_str(), n->groups, t.C);
+      }
+      if (d->training && !t.is_input) {
+        const size_t div = n == &h->V ? 2 : 1;
+        region_of(t.dz, t.elems() / div * es, (nm + ".dz").c_str());
+        if (n == &h->D) region_of(t.dz2, t.elems() / 3 * es, (nm + ".dz2").c_str());
+      }
+    }
+    region_of(n->packed, n->packed_elems * es, "packed weights");
+    region_of(n->d_descs, n->descs.size() * sizeof(PackDesc), "pack descriptors");
+    for (const PackDesc& p : n->descs) {
+      const size_t pe = (size_t)p.nclass * p.Kpad * p.rows_pad;
+      if (p.dst_off + pe > n->packed_elems) fail("pack block [%zu, +%zu) outside the %zu-element packed arena", p.dst_off, pe, n->packed_elems);
+      if (p.src_off >= n->nparams) fail("pack source %zu outside the %zu-float parameter arena", p.src_off, n->nparams);
+    }
+    size_t pend = 0;
+    for (const ParamInfo& p : n->manifest) {
+      size_t cnt = 1;
+      for (int i = 0; i < 4; ++i) cnt *= (size_t)p.shape[i];
+      if (p.off != pend) fail("parameter %s at %zu: arena not contiguous (expected %zu)", p.name.c_str(), p.off, pend);
+      pend = p.off + cnt;
+    }
+    if (pend != n->nparams) fail("parameter manifest covers %zu of %zu floats", pend, n->nparams);
+    for (const Layer& L : n->l) {
+      auto plan_ok = [&](const IgemmPlan& p, const char* what) {
+        if (p.partial_bytes > h->scratch_bytes) fail("%s %s: split-K slab %zu > scratch %zu", L.scope.c_str(), what, p.partial_bytes, h->scratch_bytes);
+        if (p.a.splitk < 1 || p.a.CoutPad < p.a.Cout) fail("%s %s: splitk %d CoutPad %d", L.scope.c_str(), what, p.a.splitk, p.a.CoutPad);
+      };
+      plan_ok(L.fwd, "fwd");
+      if (d->training)
+        for (int s2 = 0; s2 < L.nsrc; ++s2) if (L.need_bwd[s2]) { plan_ok(L.bwd[s2], "bwd"); if (n == &h->D || n == &h->V) plan_ok(L.bwd_alt[s2], "bwd_alt"); }
+      if (d->training && n != &h->V && L.wg.partial_bytes > h->scratch_bytes) fail("%s wgrad: slab %zu > scratch %zu", L.scope.c_str(), L.wg.partial_bytes, h->scratch_bytes);
+      if (L.tapgemm) { region_of(L.tap_S, (size_t)L.g.N * L.g.Hin * L.g.Win * 16 * 4, "tap_S"); region_of(L.tap_dyS, (size_t)L.g.N * L.g.Hin * L.g.Win * 16 * es, "tap_dyS"); }
+    }
+  }
+  const size_t px = (size_t)d->batch * d->height * d->height;
+  region_of(h->gin, px * 8 * es, "gin"); region_of(h->gfg, px * 8 * es, "gfg");
+  region_of(h->y4, px * 4 * 4, "y4"); region_of(h->o4, px * 4 * 4, "o4");
+  region_of(h->outputs, px * 3 * 4, "outputs"); region_of(h->outputs_fg, px * 3 * 4, "outputs_fg");
+  region_of(h->scratch, h->scratch_bytes, "scratch"); region_of(h->bn_partial, (size_t)1024 * 2 * 512 * 8, "bn_partial");
+  if (d->training) {
+    const int hd = d->height / 8 - 2;
+    const size_t M = (size_t)d->batch * hd * hd;
+    region_of(h->din, 3 * px * 8 * es, "din"); region_of(h->vin, 2 * px * 8 * es, "vin");
+    region_of(h->logits, 3 * M * 4, "logits"); region_of(h->predict, 2 * M * 4, "predict");
+    region_of(h->dl_d, 3 * M * 8 * es, "dl_d"); region_of(h->dl_g, M * 8 * es, "dl_g");
+    region_of(h->d_din, px * 8 * es, "d_din"); region_of(h->d_vin, px * 8 * es, "d_vin"); region_of(h->dy4, px * 8 * es, "dy4");
+    region_of(h->scratch2, h->scratch_bytes, "scratch2"); region_of(h->scratch3, h->scratch_bytes, "scratch3");
+    region_of(h->bn_partial2, (size_t)1024 * 2 * 512 * 8, "bn_partial2"); region_of(h->bn_partial3, (size_t)1024 * 2 * 512 * 8, "bn_partial3");
+  }
+  delete h;
+  return rc;
 }
 
 int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t workspace_bytes,

@@ -52,7 +52,8 @@ class DeviceFramePacker:
 class FramePrefetcher:
   """Double-buffered host -> device hand-over of uint8 frame batches on a side stream.
 
-  `source` yields (ex [N,S,3S,3] uint8, cur [N,S,3S,3] uint8, crops [N,2,3] int32) numpy arrays.  next() returns the four packed
+  `source` yields (ex [N,S,3S,3] uint8, cur [N,S,3S,3] uint8, crops [N,2,3] int32) as numpy arrays or torch tensors; pinned
+  torch tensors cross PCIe straight from where they are (they must stay unchanged until two batches later).  next() returns the four packed
   float32 tensors of the oldest batch in flight (valid until the next call) and starts the copies of a following one; the
   copies and the pack kernel of batch k+1 overlap the training step of batch k.
   """
@@ -79,14 +80,24 @@ class FramePrefetcher:
       ex, cur, crops = next(self.source)
     except StopIteration:
       return False
-    if slot["busy"]:
-      slot["ready"].synchronize()                     # the previous copies out of this slot's pinned buffers have completed
+    # a source that already decodes into PINNED torch tensors (what a decoder thread should do) is copied from directly; anything
+    # else is staged through this slot's pinned buffers first (a host memcpy of 18 * S * S bytes per sample on the calling thread)
+    srcs = []
+    staged = False
     for h, a in zip(slot["host"], (ex, cur, crops)):
-      h.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+      if isinstance(a, torch.Tensor) and a.is_pinned() and a.dtype == h.dtype and a.shape == h.shape and a.is_contiguous():
+        srcs.append(a)
+        continue
+      if not staged and slot["busy"]:
+        slot["ready"].synchronize()                   # the previous copies out of this slot's pinned buffers have completed
+      staged = True
+      h.copy_(a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a)))
+      srcs.append(h)
+    slot["src"] = srcs                                # keeps a caller's pinned tensors alive until the slot is refilled
     with torch.cuda.stream(self.stream):
       if slot["busy"]:
         self.stream.wait_event(slot["free"])          # the consumer of this slot's previous batch has been enqueued past it
-      for d, h in zip(slot["dev"], slot["host"]):
+      for d, h in zip(slot["dev"], srcs):
         d.copy_(h, non_blocking=True)
       slot["packer"](*slot["dev"])
       slot["ready"].record(self.stream)
