@@ -65,34 +65,55 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   }
 }
 
-// depthwise 7x3 stride 1 SAME + folded BN + relu6, 4 channels per thread     (tinynet.py:84-103)
+// depthwise 7x3 stride 1 SAME + folded BN + relu6     (tinynet.py:84-103)
+// A thread owns 4 channels of a column strip of RH = 8 consecutive output rows: the 21 taps live in registers and the (RH + 6) x 3
+// input pixels of the strip are loaded once each (5 loads per output instead of 21 + 21 weight loads: the pass was load-issue
+// bound).  Per output the products are still accumulated bias first, then kh = 0..6, kw = 0..2 (same sums as a per-pixel loop).
 __global__ __launch_bounds__(256) void dwconv7x3_kernel(const float* __restrict__ x, const float* __restrict__ w /*[21][C]*/,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W, int C) {
-  const int cq = C >> 2;
-  const size_t total = (size_t)B * H * W * cq;
+  constexpr int RH = 8;
+  const int cq = C >> 2, hb = (H + RH - 1) / RH;
+  const size_t total = (size_t)B * hb * W * cq;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c4 = (int)(i % cq) * 4;
     size_t t = i / cq;
     const int ow = (int)(t % W); t /= W;
-    const int oh = (int)(t % H);
-    const int b = (int)(t / H);
-    float4 acc = *reinterpret_cast<const float4*>(bias + c4);
+    const int oh0 = (int)(t % hb) * RH;
+    const int b = (int)(t / hb);
+    float4 wv[21];
 #pragma unroll
-    for (int kh = 0; kh < 7; ++kh) {
-      const int ih = oh + kh - 3;
+    for (int k = 0; k < 21; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (size_t)k * C + c4);
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c4);
+    float4 acc[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) acc[r] = bv;
+#pragma unroll
+    for (int j = 0; j < RH + 6; ++j) {
+      const int ih = oh0 + j - 3;
       if ((unsigned)ih >= (unsigned)H) continue;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = ow + kw - 1;
         if ((unsigned)iw >= (unsigned)W) continue;
         const float4 xv = *reinterpret_cast<const float4*>(x + (((size_t)b * H + ih) * W + iw) * C + c4);
-        const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(kh * 3 + kw) * C + c4);
-        acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y); acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+          const int kh = j - r;                    // input row ih = (oh0 + r) + kh - 3
+          if (kh < 0 || kh > 6) continue;
+          const float4 ww = wv[kh * 3 + kw];
+          acc[r].x = fmaf(xv.x, ww.x, acc[r].x); acc[r].y = fmaf(xv.y, ww.y, acc[r].y);
+          acc[r].z = fmaf(xv.z, ww.z, acc[r].z); acc[r].w = fmaf(xv.w, ww.w, acc[r].w);
+        }
       }
     }
-    acc.x = fminf(fmaxf(acc.x, 0.f), 6.f); acc.y = fminf(fmaxf(acc.y, 0.f), 6.f);
-    acc.z = fminf(fmaxf(acc.z, 0.f), 6.f); acc.w = fminf(fmaxf(acc.w, 0.f), 6.f);
-    *reinterpret_cast<float4*>(y + i * 4) = acc;
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      if (oh0 + r >= H) break;
+      float4 a = acc[r];
+      a.x = fminf(fmaxf(a.x, 0.f), 6.f); a.y = fminf(fmaxf(a.y, 0.f), 6.f);
+      a.z = fminf(fmaxf(a.z, 0.f), 6.f); a.w = fminf(fmaxf(a.w, 0.f), 6.f);
+      *reinterpret_cast<float4*>(y + (((size_t)b * H + oh0 + r) * W + ow) * C + c4) = a;
+    }
   }
 }
 
@@ -197,7 +218,7 @@ hipError_t launch_conv_first(const float* x, const float* w, const float* bias, 
   return hipGetLastError();
 }
 hipError_t launch_dwconv7x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(dwconv7x3_kernel, dim3(nblk((size_t)B * H * W * (C / 4), 8192)), dim3(256), 0, st, x, w, bias, y, B, H, W, C);
+  hipLaunchKernelGGL(dwconv7x3_kernel, dim3(nblk((size_t)B * ((H + 7) / 8) * W * (C / 4), 8192)), dim3(256), 0, st, x, w, bias, y, B, H, W, C);
   return hipGetLastError();
 }
 hipError_t launch_maxpool_same(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, hipStream_t st) {
