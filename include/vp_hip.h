@@ -92,6 +92,14 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
 /* Both gradient sets from the forward just run: d(Discrim_loss)/d(discriminator*) -> grads_d,
  * d(Gen_loss)/d(generator*) -> grads_g (pixrefer.py:396-407; pre-update weights for both). */
 int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream);
+/* vp_pixrefer_backward + both tf.train.AdamOptimizer updates (vp_adam_tf on generator* and discriminator*) + the weight re-pack
+ * the next forward would do, as ONE call: every range of an arena is updated as soon as its gradients are final, on the side /
+ * branch streams under the rest of the backward pass.  m / v: Adam slot arenas (same layout as the parameter arenas);
+ * step_t: 1-based Adam step of each optimiser.  Parameters after the call are bit-identical to the three separate calls.
+ * Single-GPU steps only: a data-parallel host must all-reduce the gradients first (vp_pixrefer_backward_g_stage). */
+int vp_pixrefer_backward_update(vp_pixrefer_t* h, float* m_g, float* v_g, float* m_d, float* v_d, int step_t_g, int step_t_d,
+                                float lr, float beta1, float beta2, float eps, void* stream);
+
 /* The two halves of vp_pixrefer_backward, so a data-parallel host can start the all-reduce of the
  * discriminator gradients while the generator backward runs. */
 int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream);

@@ -409,3 +409,28 @@ def test_overlapped_step_equals_single_stream_step():
     for (d1, g1, l1), (d2, g2, l2) in zip(ta, tb):
       assert torch.equal(d1, d2) and torch.equal(g1, g2) and l1 == l2, dtype
     assert torch.equal(ga, gb) and torch.equal(da, db)
+
+
+@pytest.mark.gpu
+def test_fused_backward_update_equals_separate_calls():
+  """vp_pixrefer_backward_update (backward + Adam x 2 + weight re-pack, bucket by bucket under the backward pass) leaves exactly the
+  parameters, Adam slots and next-step losses of vp_pixrefer_backward + vp_adam_tf x 2, over repeated steps and both dtypes."""
+  ngf = ndf = 8
+  p = make_params(ngf, ndf, 7)
+  batch = [torch.tensor(b, device="cuda") for b in synth(2, 256, 21)]
+  for dtype in ("f32", "bf16"):
+    runs = []
+    for fused in (True, False):
+      e = PixReferEngine(2, 256, ngf, ndf, dtype=dtype, training=True)
+      e.fused_update = fused
+      e.load_params(p)
+      losses = []
+      for _ in range(4):
+        e.train_step(*batch, lr=3e-4)
+        losses.append(dict(e.losses()))
+      torch.cuda.synchronize()
+      runs.append((losses, e.params_g.clone(), e.params_d.clone(), [t.clone() for t in e.adam["g"] + e.adam["d"]], e.t_g, e.t_d))
+    a, b = runs
+    assert a[0] == b[0], dtype
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), dtype
+    assert all(torch.equal(x, y) for x, y in zip(a[3], b[3])) and a[4:] == b[4:]

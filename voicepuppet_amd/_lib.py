@@ -55,6 +55,8 @@ _SIGNATURES = {
     "vp_pixrefer_optimizer_stepped": (ctypes.c_int, [_P]),
     "vp_pixrefer_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "vp_pixrefer_backward": (ctypes.c_int, [_P, _P]),
+    "vp_pixrefer_backward_update": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                                   ctypes.c_float, ctypes.c_float, _P]),
     "vp_pixrefer_backward_d": (ctypes.c_int, [_P, _P]),
     "vp_pixrefer_backward_g": (ctypes.c_int, [_P, _P]),
     "vp_pixrefer_backward_d_fork": (ctypes.c_int, [_P, _P]),

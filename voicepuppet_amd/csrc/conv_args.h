@@ -86,6 +86,7 @@ struct WgradArgs {
   const void* zeros;        // >= 16 zero bytes: enables the branch-free loader for prologue-free operands
   int lw, lh;               // log2 of Wb, Hb rounded up to powers of two
   int fastw;                // K walks the padded grid [N][2^lh][2^lw] (division-free loader)
+  int xcd_remap;            // wgrad_tr.hip: K splits pinned to XCDs (set by the launcher)
   int fast_tr;              // wgrad_tr.hip: buffer-descriptor DMAs with scalar per-chunk offsets (set by the launcher: tensors below 2 GiB)
 };
 

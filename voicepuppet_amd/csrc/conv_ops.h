@@ -360,6 +360,13 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
       if (cost < best - 1e-9) { best = cost; s = c; }
     }
   }
+  // wgrad_tr pins K splits to XCDs (the blocks of a split share their pixels in one L2): a multiple of 8 splits when there are 8 or more
+  if (tr && s >= 8 && (s & 7)) {
+    const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
+    auto cost = [&](int c) { return ((tiles * c + 511) / 512) * ((double)nchunk / c + 8.0) + 0.15 * c; };
+    const int lo = s & ~7, hi = lo + 8;
+    s = (hi <= smax && cost(hi) <= cost(lo)) ? hi : lo;
+  }
   a.splitk = s;
   p.partial_bytes = (size_t)s * a.Mpad * a.Dpad * sizeof(float);
   return p;

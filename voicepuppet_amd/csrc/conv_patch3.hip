@@ -114,6 +114,8 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c_base = blockIdx.y * BC;
   const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
+  // (an XCD-aware tile order - each XCD a contiguous run of tiles, so that halo pixels meet in one L2 - was measured: no change,
+  // the shared infinity cache already serves the halos)
   const int bt = blockIdx.x;
   const int n = bt / (tiles_x * tiles_y);
   const int trem = bt - n * (tiles_x * tiles_y);

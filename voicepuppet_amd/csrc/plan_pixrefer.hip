@@ -82,6 +82,7 @@ struct Layer {
   bool has_fwd_half = false;
   WgradPlan wg;
   // one-output-channel stride-1 conv (D layer_5) run as a GEMM over taps (TapArgs): x is read once per pass, not 16 times
+  size_t desc0 = 0, desc1 = 0;   // this layer's pack descriptors: Net::descs[desc0, desc1)
   bool tapgemm = false;
   float* tap_S = nullptr;    // [N,Hin,Win,16] f32
   void* tap_dyS = nullptr;   // [N,Hin,Win,16] T
@@ -128,6 +129,8 @@ struct vp_pixrefer {
   void* zeros;
   size_t scratch_bytes;
   int n_comp, n_perc;
+  // vp_pixrefer_backward_update: Adam state of the two optimisers + this step's hyper-parameters; active only inside that call
+  struct { bool active, d_done; float *m_g, *v_g, *m_d, *v_d; float lr_t_g, lr_t_d, beta1, beta2, eps; } upd;
   bool params_dirty;
   bool vgg_dirty;             // set by vp_pixrefer_params_changed (a host wrote the arenas), cleared by the next forward; vp_pixrefer_optimizer_stepped leaves it
   const float *in_targets, *in_masks;
@@ -257,6 +260,7 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
   };
   static const bool tap_on = !getenv("VP_NO_TAPGEMM");
   for (Layer& L : n.l) {
+    L.desc0 = n.descs.size();
     L.tapgemm = tap_on && training && L.g.kind == 0 && L.g.stride == 1 && L.g.ks == 4 && L.g.Cout == 1 && L.nsrc == 1 && !L.has_bn &&
                 L.g.Cin == L.g.Cin_real;
     if (L.tapgemm) {
@@ -348,6 +352,7 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
     }
   }
   n.packed_elems = pk;
+  for (size_t i = 0; i < n.l.size(); ++i) n.l[i].desc1 = i + 1 < n.l.size() ? n.l[i + 1].desc0 : n.descs.size();
 }
 
 // carve device buffers of a net out of the workspace
@@ -1045,6 +1050,24 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
 static int backward_d_on(vp_pixrefer_t* h, hipStream_t st, bool side);
 static int fork_d(vp_pixrefer_t* h, hipStream_t st);
 
+// tf.train.AdamOptimizer on the arena range [off0, off1) of a net (= its layers l0 .. l1) followed by the re-pack of those layers'
+// weights for the next step, both on stream s
+static int update_range(vp_pixrefer_t* h, Net& n, float* m, float* v, float lr_t, size_t off0, size_t off1, int l0, int l1, hipStream_t s) {
+  if (off1 > off0) {
+    AdamArgs a;
+    a.p = n.params + off0; a.g = n.grads + off0; a.m = m + off0; a.v = v + off0; a.n = off1 - off0;
+    a.lr_t = lr_t; a.beta1 = h->upd.beta1; a.beta2 = h->upd.beta2; a.eps = h->upd.eps;
+    VP_HIP_CHECK(launch_adam(a, s));
+  }
+  const size_t d0 = n.l[l0].desc0, d1 = n.l[l1].desc1;
+  if (d1 > d0) VP_HIP_CHECK(launch_pack_weights(n.d_descs + d0, (int)(d1 - d0), n.params, n.packed, h->bf16, s));
+  return VP_OK;
+}
+static int update_d(vp_pixrefer_t* h, hipStream_t s) {
+  h->upd.d_done = true;
+  return update_range(h, h->D, h->upd.m_d, h->upd.v_d, h->upd.lr_t_d, 0, h->D.nparams, 0, (int)h->D.l.size() - 1, s);
+}
+
 // Both gradient passes.  They are independent of each other (the discriminator-loss pass writes only the discriminator's gradient
 // arena and its own dz / scratch buffers, the generator-loss pass the generator's), so the discriminator-loss pass runs on a second
 // HIP stream: its large kernels fill the CUs that the generator's launch-bound bottleneck layers leave idle.  Fork / join by events;
@@ -1070,9 +1093,32 @@ static int fork_d(vp_pixrefer_t* h, hipStream_t st) {
   g_dfork_pending = 0;
   VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
   VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  const int rc = backward_d_on(h, h->side, true);
+  int rc = backward_d_on(h, h->side, true);
   if (rc) return rc;
+  // forked behind the generator-loss pass through the discriminator (point 2): nobody reads the discriminator's weights any more
+  if (h->upd.active && g_dfork_point == 2 && (rc = update_d(h, h->side))) return rc;
   VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+  return VP_OK;
+}
+
+// Backward of both losses AND the two Adam updates + weight re-packs of the step (train_pixrefer.py:134-139 runs them in one
+// sess.run as well).  A range of an arena is updated as soon as its gradients are final - the discriminator behind its loss pass on
+// the side stream, the generator in the three buckets of vp_pixrefer_backward_g_stage on the branch stream - so the (HBM-bound)
+// optimiser runs under the launch-bound tail of the generator backward instead of after it.  Same kernels on the same values as
+// vp_pixrefer_backward + vp_adam_tf x 2 (+ the re-pack the next forward would do): bit-identical parameters.
+int vp_pixrefer_backward_update(vp_pixrefer_t* h, float* m_g, float* v_g, float* m_d, float* v_d, int step_t_g, int step_t_d,
+                                float lr, float beta1, float beta2, float eps, void* stream) {
+  if (!h || !h->d.training) { set_err("vp_pixrefer_backward_update: needs a training plan"); return VP_ERR_STATE; }
+  if (!m_g || !v_g || !m_d || !v_d || step_t_g < 1 || step_t_d < 1) { set_err("vp_pixrefer_backward_update: bad argument"); return VP_ERR_ARG; }
+  auto lr_t = [&](int t) { return (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t))); };
+  h->upd.active = true; h->upd.d_done = false;
+  h->upd.m_g = m_g; h->upd.v_g = v_g; h->upd.m_d = m_d; h->upd.v_d = v_d;
+  h->upd.lr_t_g = lr_t(step_t_g); h->upd.lr_t_d = lr_t(step_t_d); h->upd.beta1 = beta1; h->upd.beta2 = beta2; h->upd.eps = eps;
+  int rc = vp_pixrefer_backward(h, stream);
+  if (!rc && !h->upd.d_done) rc = update_d(h, (hipStream_t)stream);
+  h->upd.active = false;
+  if (rc) return rc;
+  h->params_dirty = false;          // every layer was re-packed from the updated parameters
   return VP_OK;
 }
 
@@ -1240,6 +1286,18 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
       if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st, 0, false, 2))) return rc;
     } else {
       if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, s2, ss))) return rc;
+    }
+    // a bucket of the gradient arena is final (stage boundaries above): its Adam update + re-pack, on the branch stream
+    if (h->upd.active && (i == i_md5 || i == i_me2 || i == 0)) {
+      const int l0 = i, l1 = i == i_md5 ? (int)G.l.size() - 1 : (i == i_me2 ? i_md5 - 1 : i_me2 - 1);
+      const size_t off0 = G.l[l0].w_off, off1 = l1 + 1 < (int)G.l.size() ? G.l[l1 + 1].w_off : G.nparams;
+      hipStream_t su = st;
+      if (h->overlap && g_overlap_on) {
+        VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
+        VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
+        su = h->branch; forked = true;
+      }
+      if ((rc = update_range(h, G, h->upd.m_g, h->upd.v_g, h->upd.lr_t_g, off0, off1, l0, l1, su))) return rc;
     }
   }
   if (forked) {

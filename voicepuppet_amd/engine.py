@@ -4,6 +4,7 @@ torch is used for device memory, the current HIP stream and (optionally) torch.d
 arithmetic happens in the HIP kernels behind the C ABI.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -60,6 +61,7 @@ class PixReferEngine:
     if training:
       self.adam = {"g": [z(counts[0]), z(counts[0])], "d": [z(counts[1]), z(counts[1])]}
     self.t_g = self.t_d = 0
+    self.fused_update = not os.environ.get("VP_NO_FUSED_UPDATE")      # single-GPU train_step: vp_pixrefer_backward_update (backward + Adam x 2 + re-pack in one call)
     ws = self.L.vp_pixrefer_workspace_bytes(d)
     if ws == 0:
       raise ValueError("invalid PixReferNet descriptor: %s" % self.L.vp_last_error().decode())
@@ -186,6 +188,15 @@ class PixReferEngine:
     with the generator backward), Adam(D) then Adam(G)."""
     from .parallel import allreduce_mean
     self.forward(inputs, fg_inputs, targets, masks)
+    if group is None and self.fused_update:
+      # both passes AND both Adam updates + weight re-packs in one executor call: every arena range is updated as soon as its
+      # gradients are final, under the rest of the backward pass (bit-identical to backward() + adam_step())
+      self.t_d += 1
+      self.t_g += 1
+      (m_g, v_g), (m_d, v_d) = self.adam["g"], self.adam["d"]
+      _lib.check(self.L.vp_pixrefer_backward_update(self.h, _ptr(m_g), _ptr(v_g), _ptr(m_d), _ptr(v_d), self.t_g, self.t_d, lr, beta1,
+                                                    0.999, 1e-8, _stream()), "vp_pixrefer_backward_update")
+      return
     if group is None:
       self.backward()          # both passes, the discriminator-loss pass on the executor's side stream
     else:
