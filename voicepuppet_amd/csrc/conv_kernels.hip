@@ -1649,7 +1649,7 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
     case 4: e = launch_wgrad_cfg<T, 2, 4, 8, 2>(a, st); break;   // 256 rows x 128 cols, 8 waves
 #endif
     case 2: e = launch_wgrad_cfg<T, 4, 1, 2, 1>(a, st); break;   // 128 rows x  16 cols
-    case 5: {                                                       // 256 rows x 128 cols, LDS-DMA + transpose reads (wgrad_tr.hip; bf16, plain operands)
+    case 5: case 6: {                                               // 256 / 128 rows x 128 cols, LDS-DMA + transpose reads (wgrad_tr.hip; bf16, plain operands)
       const bool plain = a.zeros && !a.g.aff_a[0] && !a.g.aff_a[1] && a.g.act == ACT_NONE && !a.d.aff_a[0] && !a.d.aff_a[1] && a.d.act == ACT_NONE;
       if (sizeof(T) != 2 || !plain) return hipErrorInvalidValue;
       e = launch_wgrad_tr(a, st);
@@ -1674,7 +1674,7 @@ hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st
 }
 
 void wgrad_tile(int cfg, int* bm, int* bn) {
-  static const int t[6][2] = {{128, 128}, {128, 64}, {128, 16}, {256, 256}, {256, 128}, {256, 128}};   // 5: wgrad_tr.hip
+  static const int t[7][2] = {{128, 128}, {128, 64}, {128, 16}, {256, 256}, {256, 128}, {256, 128}, {128, 128}};   // 5, 6: wgrad_tr.hip
   *bm = t[cfg][0]; *bn = t[cfg][1];
 }
 

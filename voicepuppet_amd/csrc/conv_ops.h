@@ -302,7 +302,7 @@ struct WgradPlan {
   size_t partial_bytes;
 };
 
-inline int& wgrad_tr_knob() { static int v = getenv("VP_WGRAD_TR") ? atoi(getenv("VP_WGRAD_TR")) : 1; return v; }   // LDS-DMA + transpose-read weight gradient (wgrad_tr.hip)
+inline int& wgrad_tr_knob() { static int v = getenv("VP_WGRAD_TR") ? atoi(getenv("VP_WGRAD_TR")) : 3; return v; }   // LDS-DMA + transpose-read weight gradient (wgrad_tr.hip)
 
 // plain_operands: both tensors are read as stored (no deferred affine / activation): required by the LDS-DMA kernel
 inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands = true) {
@@ -334,18 +334,22 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
     }
   }
   a.lw = ilog2(a.Wb); a.lh = ilog2(a.Hb);
-  const bool tr = is_bf16 && plain_operands && wgrad_tr_knob() && (a.ntaps * a.Gc) % 256 == 0 && a.Dc % 128 == 0 &&
+  const bool tr = is_bf16 && plain_operands && (wgrad_tr_knob() & 1) && (a.ntaps * a.Gc) % 256 == 0 && a.Dc % 128 == 0 &&
                   (((long long)a.N << (a.lw + a.lh)) % 32) == 0;
   if (tr) p.cfg = 5;
+  // thin layers (image inputs: 16 taps x 8 padded channels = 128 rows): the 128 x 128 form of the same kernel, single-source operands
+  const bool tr_thin = !tr && is_bf16 && plain_operands && (wgrad_tr_knob() & 2) && (a.ntaps * a.Gc) % 128 == 0 && a.Dc % 8 == 0 && a.Dc <= 128 &&
+                       (((long long)a.N << (a.lw + a.lh)) % 32) == 0 && a.lw + a.lh >= 5;
+  if (tr_thin) p.cfg = 6;
   int bm, bn;
   wgrad_tile(p.cfg, &bm, &bn);
   a.Mpad = round_up(a.ntaps * a.Gc, bm);
   a.Dpad = round_up(a.Dc, bn);
-  const int kiter = tr ? 32 : kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of the kernel
+  const int kiter = (tr || tr_thin) ? 32 : kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of the kernel
   // padded-grid K walk: rows of 2^lw slots, at least one 16-byte pixel group and at most one iteration long
   static const bool fastw_on = !getenv("VP_NO_FASTW");
-  a.fastw = (fastw_on && !tr && (1 << a.lw) >= (is_bf16 ? 8 : 4) && (1 << a.lw) <= kiter) ? 1 : 0;
-  const int P = (a.fastw || tr) ? (a.N << (a.lw + a.lh)) : a.N * a.Hb * a.Wb;
+  a.fastw = (fastw_on && !tr && !tr_thin && (1 << a.lw) >= (is_bf16 ? 8 : 4) && (1 << a.lw) <= kiter) ? 1 : 0;
+  const int P = (a.fastw || tr || tr_thin) ? (a.N << (a.lw + a.lh)) : a.N * a.Hb * a.Wb;
   const int nchunk = (P + kiter - 1) / kiter;
   const int tiles = (a.Mpad / bm) * (a.Dpad / bn);
   // K split: minimise (rounds of the ~512 resident blocks) x (iterations per block + fixed per-block cost),
@@ -361,7 +365,7 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
     }
   }
   // wgrad_tr pins K splits to XCDs (the blocks of a split share their pixels in one L2): a multiple of 8 splits when there are 8 or more
-  if (tr && s >= 8 && (s & 7)) {
+  if ((tr || tr_thin) && s >= 8 && (s & 7)) {
     const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
     auto cost = [&](int c) { return ((tiles * c + 511) / 512) * ((double)nchunk / c + 8.0) + 0.15 * c; };
     const int lo = s & ~7, hi = lo + 8;

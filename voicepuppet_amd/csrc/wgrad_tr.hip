@@ -280,10 +280,10 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradAr
     }
 }
 
-// 256 rows x 128 columns (wgrad cfg 5)
-hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st) {
+template <int WM, int WN, int TC, int TP>
+static hipError_t launch_wgrad_tr_t(const WgradArgs& a, hipStream_t st) {
   constexpr int NST = 3;
-  constexpr int BM = 256, BN = 128;
+  constexpr int BM = WM * TC * 16, BN = WN * TP * 16;
   const size_t smem = (size_t)NST * 32 * (BM / 8 + BN / 8) * 16;
   dim3 grid(a.Mpad / BM, a.Dpad / BN, a.splitk);
   WgradArgs b = a;
@@ -297,10 +297,17 @@ hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st) {
   static const bool xcd_on = !getenv("VP_NO_XCD_REMAP");
   b.xcd_remap = xcd_on ? 1 : 0;
   const bool exact = fast && a.Hb == (1 << a.lh) && a.Wb == (1 << a.lw);
-  auto kern = exact ? wgrad_tr_kernel<4, 2, 4, 4, NST, true, true> : fast ? wgrad_tr_kernel<4, 2, 4, 4, NST, true> : wgrad_tr_kernel<4, 2, 4, 4, NST, false>;
+  auto kern = exact ? wgrad_tr_kernel<WM, WN, TC, TP, NST, true, true> : fast ? wgrad_tr_kernel<WM, WN, TC, TP, NST, true> : wgrad_tr_kernel<WM, WN, TC, TP, NST, false>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, b);
   return hipGetLastError();
+}
+
+// wgrad cfg 5: 256 rows x 128 columns; cfg 6: 128 x 128 (the 6- / 3-channel input layers: 16 taps x 8 padded channels = 128 rows,
+// 64 real columns - HBM-bound, the point is the loader: LDS-DMA instead of register loads + 8x8 transposes)
+hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st) {
+  if (a.Mpad % 256 == 0) return launch_wgrad_tr_t<4, 2, 4, 4>(a, st);
+  return launch_wgrad_tr_t<4, 2, 2, 4>(a, st);
 }
 
 }  // namespace vp
