@@ -262,4 +262,4 @@ class PixReferNet(ModelBuilder):
         t_g = steps([('generator_train/beta1_power', 'generator_train/beta2_power'), ('beta1_power_1', 'beta2_power_1')])
       self.engine.load_adam(d, t_g=t_g, t_d=t_d)
     if 'global_step' in d:
-      self.global_step = int(d['global_step'])
+      self.global_step = int(np.asarray(d['global_step']).reshape(-1)[0])

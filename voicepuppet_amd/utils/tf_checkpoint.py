@@ -540,7 +540,7 @@ def adam_steps_from_beta_powers(beta1_power, beta2_power, beta1, beta2):
   (initial value beta, multiplied once per apply_gradients).  beta2_power is the better-conditioned one (0.999^t stays in
   float32 range for ~100k steps); 0 -> treated as 'very many' (the bias correction is 1 by then)."""
   for p, b in ((beta2_power, beta2), (beta1_power, beta1)):
-    p = float(p)
+    p = float(np.asarray(p).reshape(-1)[0])     # (a 0-d or 1-element array: explicit, NumPy deprecates the implicit form)
     if 0.0 < p < 1.0 and 0.0 < b < 1.0:
       return max(0, int(round(np.log(p) / np.log(b))) - 1)
   return 1000000
