@@ -92,6 +92,45 @@ def test_infer_bfmvid_cli_end_to_end(tmp_path, monkeypatch):
   assert Image.open(os.path.join("output", "0.jpg")).size == (512, 512)
 
 
+def test_infer_bfmvid_cli_through_the_clip_renderer(tmp_path, monkeypatch):
+  """The CLI's ClipRenderer branch end to end (infer_bfmvid.py:79-122,221-243): BFM/BFM_model_front.mat (a synthetic face model
+  written with scipy.io.savemat in the layout utils/bfm_load_data.py:9-21 reads) + the photo's coefficient file -> wav -> log-mel ->
+  BFMNet -> spliced coefficients -> device reconstruction + rasteriser -> resize / paste -> generator -> frames.  The conditioning
+  channels must differ from the fallback run (reference 3-D face panel) and between frames."""
+  from PIL import Image
+  from scipy.io import savemat, wavfile
+  from oracle import bfm_ref as br
+  from voicepuppet_amd.pixrefer import infer_bfmvid
+  monkeypatch.chdir(tmp_path)
+  rng = np.random.default_rng(0)
+  Image.fromarray((rng.uniform(size=(512, 1536, 3)) * 255).astype(np.uint8)).save("face.jpg")
+  t = np.arange(8000) / 16000.0
+  wavfile.write("a.wav", 16000, (0.3 * np.sin(2 * np.pi * 440 * t) * 32767).astype(np.int16))
+  fm = br.synthetic_facemodel(3)
+  os.makedirs("BFM")
+  savemat(os.path.join("BFM", "BFM_model_front.mat"),
+          {"meanshape": fm.meanshape, "idBase": fm.idBase, "exBase": fm.exBase, "meantex": fm.meantex, "texBase": fm.texBase,
+           "point_buf": fm.point_buf, "tri": fm.tri, "keypoints": (fm.keypoints + 1).reshape(1, -1)})
+  coeff, _ = br.synthetic_coeffs(1, 5)
+  np.savez("photo.npz", bfmcoeff=coeff.reshape(1, 257), transform_params=np.array([512, 512, 1.0, 0.0, 0.0], np.float32),
+           center_x=256, center_y=256, ratio=0.9)
+  captured = []
+  real = infer_bfmvid.render_faces
+  monkeypatch.setattr(infer_bfmvid, "render_faces", lambda *a, **k: captured.append(real(*a, **k)) or captured[-1])
+  infer_bfmvid.main(["--config_path", CFG, "--frame_batch", "4", "--bfmcoeff", "photo.npz", "face.jpg", "a.wav"])
+  frames = sorted(os.listdir("output"))
+  nf = int(1 + 8000 / 640)
+  assert len(frames) == nf and Image.open(os.path.join("output", "0.jpg")).size == (512, 512)
+  assert len(captured) == 1 and captured[0].shape == (nf, 512, 512, 3) and captured[0].dtype == np.uint8
+  drawn = captured[0].reshape(nf, -1)
+  assert (drawn.max(axis=1) > 0).all()                                # every frame has a rasterised face pasted in
+  assert any(not np.array_equal(drawn[0], drawn[i]) for i in range(1, nf))   # and the mouth / pose moves over the clip
+  with_render = np.asarray(Image.open(os.path.join("output", "1.jpg"))).astype(np.int32)
+  infer_bfmvid.main(["--config_path", CFG, "--frame_batch", "4", "--output_dir", "out_fallback", "face.jpg", "a.wav"])
+  fallback = np.asarray(Image.open(os.path.join("out_fallback", "1.jpg"))).astype(np.int32)
+  assert np.abs(with_render - fallback).max() > 0                     # the generator really was conditioned on the rendered face
+
+
 def _train_net(batch=1, dtype="f32"):
   from voicepuppet_amd.pixrefer.pixrefer import PixReferNet
   from voicepuppet_amd.runtime import Placeholder, Session
