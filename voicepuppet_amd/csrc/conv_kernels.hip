@@ -959,9 +959,19 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArg
     const int pidx = (int)(t % P);
     const int cls = (int)(t / P);
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < a.splitk; ++s) {
-      const float4 x = *reinterpret_cast<const float4*>(a.partial + (((size_t)(cls * a.splitk + s) * P + pidx) * a.CoutPad + c0));
-      v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+    // the slabs are added in slab order (deterministic, same sums as a one-load-per-trip loop); eight loads are in flight at a
+    // time - a thread's slabs lie P * CoutPad floats apart, the pass is pure load latency otherwise
+    const float* src = a.partial + (((size_t)cls * a.splitk * P + pidx) * a.CoutPad + c0);
+    const size_t sstride = (size_t)P * a.CoutPad;
+    for (int s0 = 0; s0 < a.splitk; s0 += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = s0 + u < a.splitk ? *reinterpret_cast<const float4*>(src + (size_t)(s0 + u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s0 + u >= a.splitk) break;
+        v[0] += x[u].x; v[1] += x[u].y; v[2] += x[u].z; v[3] += x[u].w;
+      }
     }
     igemm_epilogue<T>(a, cls, pidx, c0, v);
   }
