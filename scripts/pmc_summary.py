@@ -60,7 +60,11 @@ def classify(name):
       want = 5 if fam in ("wgrad_kernel", "igemm_ws_kernel") else 4
       ints = tuple(nums[:4]) if len(nums) >= want else tuple([1] + nums[:3])     # garbled form lost WC=1
     t = tiles.get(ints)
-    return "%s_%s_%s" % ("igemm" if fam.startswith("igemm") else "wgrad", dt, t) if t else None
+    if not t:
+      return None
+    if fam.startswith("igemm"):      # one class per kernel template, as bench.py's HIP-event records name them
+      return "igemm_%s_%s_%s" % ({"igemm_dma_kernel": "dma", "igemm_ws_kernel": "ws", "igemm_regb_kernel": "regb"}[fam], dt, t)
+    return "wgrad_%s_%s" % (dt, t)
   return None
 
 

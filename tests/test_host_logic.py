@@ -181,11 +181,13 @@ def test_pmc_kernel_classifier():
   import sys
   sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
   import pmc_summary as p
-  assert p.classify("_ZN2vp16igemm_dma_kernelIDF16bLi2ELi4ELi4ELi4ELb1ELb0EEEvNS_9IgemmArgsE") == "igemm_bf16_128x256"
-  assert p.classify("_ZN2vp15igemm_ws_kernelIDF16bLi2ELi4ELi8ELi4ELi4ELb0EEEvNS_9IgemmArgsE") == "igemm_bf16_256x256"
+  assert p.classify("_ZN2vp16igemm_dma_kernelIDF16bLi2ELi4ELi4ELi4ELb1ELb0EEEvNS_9IgemmArgsE") == "igemm_dma_bf16_128x256"
+  assert p.classify("_ZN2vp15igemm_ws_kernelIDF16bLi2ELi4ELi8ELi4ELi4ELb0EEEvNS_9IgemmArgsE") == "igemm_ws_bf16_256x256"
   assert p.classify("_ZN2vp12wgrad_kernelIDF16bLi2ELi2ELi4ELi4ELi2ELb1EEEvNS_9WgradArgsE") == "wgrad_bf16_128x128"
   assert p.classify("void vp::conv_cin8_kernel<3>(vp::IgemmArgs, int, int)") == "cin8_bf16_64x16"
   assert p.classify("vp::adam_tf_kernel(vp::AdamArgs)") is None
+  assert p.classify("_ZN2vp19igemm_patch3_kernelIDF16bLi2ELi4ELi8ELi2ELi8ELi16ELb0ELi4EEEvNS_9IgemmArgsE") == "patch_bf16_256x128"
+  assert p.classify("void vp::wgrad_tr_kernel<4, 2, 4, 4, 3, true, true>(vp::WgradArgs)") == "wgrad_bf16_256x128"
 
 
 def test_bench_launches_n_ranks_as_a_child_before_touching_the_gpu(monkeypatch):

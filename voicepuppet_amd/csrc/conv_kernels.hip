@@ -1310,22 +1310,31 @@ static bool g_prof_detail = false;
 void profile_enable(int on) { g_prof_on = on != 0; g_prof_detail = on > 1; }
 void profile_tag(const char* tag) { if (g_prof_on && g_prof_detail) g_prof_tag = tag ? tag : ""; }
 
+// which kernel family a launch_igemm_cfg call ended up on ("ws" wave-specialised, "dma", "reg" register loader): part of the
+// class name of the record, so that a class is ONE kernel template (the names rocprofv3 reports are per kernel too)
+static const char* g_prof_family = nullptr;
+
 struct ProfScope {
   bool on;
   ProfRec r;
   hipStream_t st;
-  ProfScope(const char* kind, int is_bf16, int bc, int bp, double flops, double bytes, hipStream_t s) : on(g_prof_on), st(s) {
+  std::string kind;
+  int bf, bc, bp;
+  ProfScope(const char* kind_, int is_bf16, int bc_, int bp_, double flops, double bytes, hipStream_t s) : on(g_prof_on), st(s), kind(kind_), bf(is_bf16), bc(bc_), bp(bp_) {
     if (!on) return;
-    char buf[96];
-    snprintf(buf, sizeof(buf), "%s_%s_%dx%d", kind, is_bf16 ? "bf16" : "f32", bc, bp);
-    r.name = buf; r.flops = flops; r.bytes = bytes;
-    if (g_prof_detail && !g_prof_tag.empty()) r.name = g_prof_tag + " " + r.name;
+    g_prof_family = nullptr;
+    r.flops = flops; r.bytes = bytes;
     r.e0 = prof_event(); r.e1 = prof_event();
     hipEventRecord(r.e0, st);
   }
   ~ProfScope() {
     if (!on) return;
     hipEventRecord(r.e1, st);
+    char buf[96];
+    if (kind == "igemm" && g_prof_family) snprintf(buf, sizeof(buf), "igemm_%s_%s_%dx%d", g_prof_family, bf ? "bf16" : "f32", bc, bp);
+    else snprintf(buf, sizeof(buf), "%s_%s_%dx%d", kind.c_str(), bf ? "bf16" : "f32", bc, bp);
+    r.name = buf;
+    if (g_prof_detail && !g_prof_tag.empty()) r.name = g_prof_tag + " " + r.name;
     g_prof.push_back(r);
   }
 };
@@ -1466,6 +1475,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         size_t sm = RB + 64 + BP * 8;
         const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
         if (se > sm) sm = se;
+        g_prof_family = "ws";
         if (b.bn_part) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, true>), grid, dim3((NW + 4) * 64), sm, st, b);
         else hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, false>), grid, dim3((NW + 4) * 64), sm, st, b);
         return hipGetLastError();
@@ -1484,11 +1494,13 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
       }
     }
 #endif
+    g_prof_family = "dma";
     if (b.vec_epi && b.bn_part) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, true>), grid, dim3(NW * 64), smem, st, b);
     else if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(NW * 64), smem, st, b);
     return hipGetLastError();
   }
+  g_prof_family = "reg";
   if constexpr (NW == 4) hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), 2 * 4 * (BC + BP) * 16 + 64, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
