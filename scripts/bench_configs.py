@@ -17,14 +17,14 @@ def timed(fn, warm, steps):
 for n, h in ((8, 256), (8, 512), (2, 512)):
   eng = PixReferEngine(n, h, 64, 64, dtype="bf16", training=True); eng.load_params(eng.random_params(0))
   b = bench.synth_batch(n, h, 1, torch.device("cuda"))
-  dt = timed(lambda: eng.train_step(*b, lr=3e-4), 3, 10)
+  dt = timed(lambda: eng.train_step(*b, lr=3e-4), 10, 20)
   print(json.dumps({"config": "G+D step bf16 bs=%d %dx%d 1 GPU" % (n, h, h), "ms_per_step": dt * 1e3, "frames_per_s": n / dt,
                     "tflops": 163.02e9 * (h / 256) ** 2 * n / dt / 1e12}))
   del eng; torch.cuda.empty_cache()
 for n, h in ((1, 512), (8, 512), (1, 256)):
   eng = PixReferEngine(n, h, 64, 64, dtype="bf16", training=False, per_sample_bn=True); eng.load_params(eng.random_params(0))
   b = bench.synth_batch(n, h, 1, torch.device("cuda"))
-  dt = timed(lambda: eng.forward(b[0], b[1], b[2]), 5, 30)
+  dt = timed(lambda: eng.forward(b[0], b[1], b[2]), 10, 30)
   print(json.dumps({"config": "generator inference bf16 bs=%d %dx%d" % (n, h, h), "ms": dt * 1e3, "frames_per_s": n / dt}))
   del eng; torch.cuda.empty_cache()
 B, T = 64, 25
