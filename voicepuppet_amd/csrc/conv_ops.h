@@ -206,6 +206,37 @@ inline void plan_make_patch(IgemmPlan& p, int rows, int is_bf16) {
   p.pack.kswap = 1;
 }
 
+// The four parity classes of a 4x4 stride-2 transposed conv (deconv forward, conv backward-data) on the unrolled 2x2-tap patch
+// kernel (conv_patch2.hip).  c0 / c1: channels of the one or two source tensors of the GEMM's pixel operand.
+inline int& patch2_knob() { static int v = getenv("VP_NO_PATCH2") ? 0 : 1; return v; }
+inline bool plan_patch2_eligible(const IgemmPlan& p, int rows, int is_bf16, int c0, int c1) {
+  const IgemmArgs& a = p.a;
+  const int kc = kc_elems(is_bf16);
+  if (!patch2_knob() || a.nclass != 4 || a.ntaps != 4 || a.os != 2 || a.sh != 1 || a.sw != 1) return false;
+  if (c0 + c1 != a.Cin || c0 % (2 * kc) || c1 % (2 * kc) || c0 < 2 * kc) return false;
+  if (rows % 64 || rows > 128 || a.Cout % 8 || a.ldY % 8 || a.Hg < 16 || a.Wg < 16 || a.Hof != 2 * a.Hg || a.Wof != 2 * a.Wg) return false;
+  const long long blocks = (long long)a.N * ((a.Hg + 15) / 16) * ((a.Wg + 15) / 16) * 4;
+  if (blocks < patch_minblk_knob()) return false;
+  const size_t cmax = c0 > c1 ? c0 : c1;
+  if ((size_t)a.N * a.Hin * a.Win * cmax * (is_bf16 ? 2 : 4) >= 0x70000000ull) return false;     // lane offsets of the buffer loads
+  for (int cls = 0; cls < 4; ++cls)
+    for (int t = 0; t < 4; ++t)          // patch origin = tap 3, tap t one step up / left per bit (conv_patch2.hip)
+      if (a.taps[cls].dh[t] != a.taps[cls].dh[3] + 1 - (t >> 1) || a.taps[cls].dw[t] != a.taps[cls].dw[3] + 1 - (t & 1)) return false;
+  return true;
+}
+inline void plan_make_patch2(IgemmPlan& p, int rows, int is_bf16) {
+  IgemmArgs& a = p.a;
+  const int bc = rows % 128 == 0 ? 128 : 64;
+  a.patch = 2; a.p_kw = 2;
+  p.cfg = bc == 128 ? 13 : 14;
+  a.CoutPad = round_up(rows, bc);
+  a.splitk = 1;
+  p.partial_bytes = 0;
+  a.rowperm = 1;
+  p.pack.perm = 1;
+  p.pack.kswap = 1;
+}
+
 // x (PixSrc, total channels g.Cin) -> y [N,Hout,Wout,ldY]
 inline IgemmPlan plan_fwd(const ConvGeomX& g, size_t w_off, int is_bf16) {
   IgemmPlan p;
@@ -355,19 +386,21 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
   // K split: minimise (rounds of the ~512 resident blocks) x (iterations per block + fixed per-block cost),
   // plus a small penalty per slab for the reduce pass
   int s = 1;
+  static const double wg_fixed = getenv("VP_WG_FIXED") ? atof(getenv("VP_WG_FIXED")) : 8.0;
+  static const double wg_slab = getenv("VP_WG_SLAB") ? atof(getenv("VP_WG_SLAB")) : 0.15;
   {
     const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
     double best = 1e30;
     for (int c = 1; c <= smax; ++c) {
       const int rounds = (tiles * c + 511) / 512;
-      const double cost = rounds * ((double)nchunk / c + 8.0) + 0.15 * c;
+      const double cost = rounds * ((double)nchunk / c + wg_fixed) + wg_slab * c;
       if (cost < best - 1e-9) { best = cost; s = c; }
     }
   }
   // wgrad_tr pins K splits to XCDs (the blocks of a split share their pixels in one L2): a multiple of 8 splits when there are 8 or more
   if ((tr || tr_thin) && s >= 8 && (s & 7)) {
     const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
-    auto cost = [&](int c) { return ((tiles * c + 511) / 512) * ((double)nchunk / c + 8.0) + 0.15 * c; };
+    auto cost = [&](int c) { return ((tiles * c + 511) / 512) * ((double)nchunk / c + wg_fixed) + wg_slab * c; };
     const int lo = s & ~7, hi = lo + 8;
     s = (hi <= smax && cost(hi) <= cost(lo)) ? hi : lo;
   }

@@ -230,6 +230,7 @@ static hipError_t launch_patch_t(const IgemmArgs& b, hipStream_t st) {
 // variants run TWO blocks per CU (64 / 32 accumulator registers, 72 / 60 KB of LDS): the blocks are not in lockstep with each
 // other, so one block's barrier / DMA-issue / ds_read phase overlaps the other's MFMAs.
 hipError_t launch_igemm_patch(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st) {
+  if (a.patch == 2) return launch_igemm_patch2(a, is_bf16, bc, bp, st);                                  // 2x2-tap parity classes (conv_patch2.hip)
   if (patch3_knob() && patch3_eligible(a, is_bf16)) return launch_igemm_patch3(a, is_bf16, bc, bp, st);   // 3x3: the unrolled schedule
   IgemmArgs b = a;
   b.vec_epi = 1;

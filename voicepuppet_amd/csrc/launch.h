@@ -12,6 +12,7 @@ void igemm_tile(int cfg, int* bc, int* bp);
 hipError_t launch_igemm_patch(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                    // conv_patch.hip
 bool patch3_eligible(const IgemmArgs& a, int is_bf16);                                                               // conv_patch3.hip
 hipError_t launch_igemm_patch3(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                   // conv_patch3.hip
+hipError_t launch_igemm_patch2(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                   // conv_patch2.hip
 hipError_t launch_igemm_db(const IgemmArgs& b, int is_bf16, int bc, dim3 grid, hipStream_t st);   // conv_db.hip
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
 hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st);                                          // wgrad_tr.hip

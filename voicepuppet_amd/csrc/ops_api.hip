@@ -70,6 +70,7 @@ int vp_tune(const char* key, int value) {
   if (k == "d_beside_vgg") { vp_dsplit_enable(value); return VP_OK; }
   if (k == "wgrad_tr") { wgrad_tr_knob() = value; return VP_OK; }
   if (k == "patch3") { patch3_knob() = value; return VP_OK; }
+  if (k == "patch2") { patch2_knob() = value; return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
   return VP_ERR_ARG;
 }
@@ -104,6 +105,7 @@ int vp_conv_fwd(const vp_conv_desc* d, const void* x, const float* in_scale, con
   IgemmPlan p = plan_fwd(g, 0, bf);
   // the patch kernel moves plain bytes (LDS-DMA): only inputs that need no deferred affine / activation
   if (d->in_act == ACT_NONE && !in_scale && plan_patch_eligible(p, g.Cout, bf, true)) plan_make_patch(p, g.Cout, bf);
+  else if (d->in_act == ACT_NONE && !in_scale && plan_patch2_eligible(p, g.Cout, bf, d->cin, 0)) plan_make_patch2(p, g.Cout, bf);
   char* ws = (char*)workspace;
   VP_HIP_CHECK(launch_pack_weights_one(p.pack, w, ws, bf, st));
   IgemmArgs a = p.a;
@@ -124,6 +126,7 @@ int vp_conv_bwd_data(const vp_conv_desc* d, const void* dy, const float* w, void
   const ConvGeomX g = geom_of(d);
   IgemmPlan p = plan_bwd_data(g, 0, 0, d->cin, d->cin, d->cin, bf);
   if (plan_patch_eligible(p, d->cin, bf, true)) plan_make_patch(p, d->cin, bf);
+  else if (plan_patch2_eligible(p, d->cin, bf, d->cout, 0)) plan_make_patch2(p, d->cin, bf);
   char* ws = (char*)workspace;
   VP_HIP_CHECK(launch_pack_weights_one(p.pack, w, ws, bf, st));
   IgemmArgs a = p.a;

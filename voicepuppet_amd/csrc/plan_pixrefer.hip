@@ -274,6 +274,7 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       for (int s = 0; s < L.nsrc; ++s) srcs_ok = srcs_ok && n.t[L.src[s]].C % (2 * kc_elems(bf16)) == 0;
       if (plan_wide_eligible(L.fwd, bf16, srcs_ok, true) && !(L.g.Cout < 8)) plan_make_wide(L.fwd, bf16);
       else if (plan_patch_eligible(L.fwd, L.g.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == L.g.Cin)) plan_make_patch(L.fwd, L.g.Cout, bf16);
+      else if (plan_patch2_eligible(L.fwd, L.g.Cout, bf16, n.t[L.src[0]].C, L.nsrc > 1 ? n.t[L.src[1]].C : 0)) plan_make_patch2(L.fwd, L.g.Cout, bf16);
     }
     take(L.fwd);
     L.pk_fwd = L.fwd.pack.dst_off;
@@ -322,7 +323,9 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
           else {
             // backward-data of a stride-1 conv is a stride-1 conv over dY (one tensor of CoutT channels): patch kernel, per batch size
             if (plan_patch_eligible(L.bwd[s], rows, bf16, true)) plan_make_patch(L.bwd[s], rows, bf16);
+            else if (plan_patch2_eligible(L.bwd[s], rows, bf16, L.g.CoutT, 0)) plan_make_patch2(L.bwd[s], rows, bf16);
             if (alt_batch > 0 && plan_patch_eligible(L.bwd_alt[s], rows, bf16, true)) plan_make_patch(L.bwd_alt[s], rows, bf16);
+            else if (alt_batch > 0 && plan_patch2_eligible(L.bwd_alt[s], rows, bf16, L.g.CoutT, 0)) plan_make_patch2(L.bwd_alt[s], rows, bf16);
           }
         }
         take(L.bwd[s]);
@@ -516,7 +519,7 @@ static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, int fused_chunks, hipS
 
 // the patch kernel's 16-pixel-wide tiles can write the 2x2 max pool of their output from the epilogue (even image sizes)
 static bool plan_can_pool(const IgemmPlan& p) {
-  if (!p.a.patch || (p.a.Hg & 1) || (p.a.Wg & 1)) return false;
+  if (p.a.patch != 1 || (p.a.Hg & 1) || (p.a.Wg & 1)) return false;
   int bc, bp;
   igemm_tile(p.cfg, &bc, &bp);
   int th, tw;
