@@ -33,7 +33,8 @@ struct Patch2TilePix {
   }
 };
 
-template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC>
+// TWOSRC: the pixel operand is a virtual concat of two tensors (decoder layers); single-source launches carry one set of lane offsets
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC, bool TWOSRC>
 __global__ __launch_bounds__(512, OCC) void igemm_patch2_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NW = 8, NT = 512, NSTW = 4, NSTEP = 8;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch2_kernel(const IgemmArgs 
   const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
   const int dh0 = a.taps[cls].dh[3], dw0 = a.taps[cls].dw[3];        // patch origin = tap 3 (ta = tb = 1)
   const unsigned es = sizeof(T);
-  const int C0 = a.x.C[0], C1 = a.x.C[1];
+  const int C0 = a.x.C[0], C1 = TWOSRC ? a.x.C[1] : 0;
   const int n0 = C0 / KC, nchunkc = (C0 + C1) / KC;                  // chunks of source 0 / of both (even each)
 
   __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const T*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad, 0xFFFFFFFFu);
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch2_kernel(const IgemmArgs 
 
   // patch DMA lanes: instruction j of this wave covers patch pixels (wave + 8j) * 16 .. + 15, lane -> (pixel, slot); one lane offset
   // per source (the pixel stride differs)
-  unsigned pvo0[JP], pvo1[JP];
+  unsigned pvo0[JP], pvo1[TWOSRC ? JP : 1];
 #pragma unroll
   for (int j = 0; j < JP; ++j) {
     const int pp = (wave + NW * j) * 16 + (lane >> 2);
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch2_kernel(const IgemmArgs 
     const int piece = (lane & 3) ^ ((px >> 2) & 3);
     const int pix = (n * a.Hin + ih) * a.Win + iw;
     pvo0[j] = ok ? (unsigned)((pix * C0 + piece * E) * es) : DMA_OOB;
-    pvo1[j] = (ok && C1 > 0) ? (unsigned)((pix * C1 + piece * E) * es) : DMA_OOB;
+    if (TWOSRC) pvo1[TWOSRC ? j : 0] = ok ? (unsigned)((pix * C1 + piece * E) * es) : DMA_OOB;
   }
   unsigned wvo[JA];
   {
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch2_kernel(const IgemmArgs 
   };
   auto issue_p = [&](int chunk, int buf, int j) {
     uint4* lb = reinterpret_cast<uint4*>(smem + buf * PBUFB) + (wave + NW * j) * 64;
-    if (chunk < n0) dma16_buf(rsX0, pvo0[j], (unsigned)(chunk * KC) * es, lb);
-    else dma16_buf(rsX1, pvo1[j], (unsigned)((chunk - n0) * KC) * es, lb);     // (behind the last chunk: bytes nobody reads)
+    if (!TWOSRC || chunk < n0) dma16_buf(rsX0, pvo0[j], (unsigned)(chunk * KC) * es, lb);    // (behind the last chunk: bytes nobody reads)
+    else dma16_buf(rsX1, pvo1[TWOSRC ? j : 0], (unsigned)((chunk - n0) * KC) * es, lb);
   };
 
   const int wc = wave / WP, wpi = wave - wc * WP;
@@ -205,7 +206,9 @@ static hipError_t launch_patch2_t(const IgemmArgs& b, hipStream_t st) {
   if (se > sm) sm = se;
   const int tiles = b.N * ((b.Hg + TH - 1) / TH) * ((b.Wg + TW - 1) / TW);
   dim3 grid(tiles, b.CoutPad / BC, b.nclass);
-  auto kern = b.bn_part ? igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC> : igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC>;
+  const bool two = b.x.C[1] > 0;
+  auto kern = b.bn_part ? (two ? igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC, true> : igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC, false>)
+                        : (two ? igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC, true> : igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC, false>);
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(kern, grid, dim3(512), sm, st, b);
   return hipGetLastError();
