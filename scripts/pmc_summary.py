@@ -25,7 +25,7 @@ def classify(name):
     return "cin8_bf16_64x16"
   if "wgrad_tr_kernel" in name:
     return "wgrad_bf16_256x128"
-  for fam in ("igemm_patch3_kernel", "igemm_patch_kernel"):
+  for fam in ("igemm_patch3_kernel", "igemm_patch2_kernel", "igemm_patch_kernel"):
     if fam not in name:
       continue
     m = re.search(fam + r"I(DF16b|f)((?:Li\d+E)+)", name)
@@ -42,7 +42,7 @@ def classify(name):
     if len(ints) < 6:
       return None
     wc, wp, tc, tp, th, tw = ints[:6]
-    return "patch_%s_%dx%d" % (dt, wc * tc * 16, th * tw)
+    return "%s_%s_%dx%d" % ({"igemm_patch3_kernel": "patch3", "igemm_patch2_kernel": "patch2", "igemm_patch_kernel": "patch"}[fam], dt, wc * tc * 16, th * tw)
   for fam, tiles in (("igemm_dma_kernel", IGEMM_TILES), ("igemm_ws_kernel", IGEMM_TILES), ("igemm_regb_kernel", IGEMM_TILES), ("wgrad_kernel", WGRAD_TILES)):
     if fam not in name:
       continue

@@ -186,7 +186,8 @@ def test_pmc_kernel_classifier():
   assert p.classify("_ZN2vp12wgrad_kernelIDF16bLi2ELi2ELi4ELi4ELi2ELb1EEEvNS_9WgradArgsE") == "wgrad_bf16_128x128"
   assert p.classify("void vp::conv_cin8_kernel<3>(vp::IgemmArgs, int, int)") == "cin8_bf16_64x16"
   assert p.classify("vp::adam_tf_kernel(vp::AdamArgs)") is None
-  assert p.classify("_ZN2vp19igemm_patch3_kernelIDF16bLi2ELi4ELi8ELi2ELi8ELi16ELb0ELi4EEEvNS_9IgemmArgsE") == "patch_bf16_256x128"
+  assert p.classify("_ZN2vp19igemm_patch3_kernelIDF16bLi2ELi4ELi8ELi2ELi8ELi16ELb0ELi4EEEvNS_9IgemmArgsE") == "patch3_bf16_256x128"
+  assert p.classify("_ZN2vp19igemm_patch2_kernelIDF16bLi2ELi4ELi2ELi4ELi16ELi16ELb0ELi4ELb0EEEvNS_9IgemmArgsE") == "patch2_bf16_64x256"
   assert p.classify("void vp::wgrad_tr_kernel<4, 2, 4, 4, 3, true, true>(vp::WgradArgs)") == "wgrad_bf16_256x128"
 
 

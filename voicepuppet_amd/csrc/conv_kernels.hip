@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "conv_args.h"
+#include "conv_ops.h"
 #include "igemm_device.h"
 #include "launch.h"
 #include "vp_common.h"
@@ -1585,7 +1586,9 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     }
   }
   if (a.patch) {   // stride-1 convs with the input patch staged once per channel chunk (conv_patch.hip)
-    ProfScope prof("patch", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
+    // class name per kernel template: patch2 (parity classes, conv_patch2.hip), patch3 (unrolled 3x3, conv_patch3.hip), patch (generic)
+    const char* pk = a.patch == 2 ? "patch2" : (patch3_knob() && patch3_eligible(a, sizeof(T) == 2) ? "patch3" : "patch");
+    ProfScope prof(pk, sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
                    es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
     return launch_igemm_patch(a, sizeof(T) == 2, pbc, pbp, st);
   }
