@@ -1233,9 +1233,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
       const int tap = (int)(t / a.Greal);
       const size_t m = (size_t)tap * a.Gc + gc;
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int k = 0; k < a.splitk; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(a.partial + ((size_t)k * a.Mpad + m) * a.Dpad + d);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      // slabs added in slab order, eight loads in flight (the slabs of one element lie Mpad * Dpad floats apart: load latency)
+      const float* src = a.partial + m * a.Dpad + d;
+      const size_t sstride = (size_t)a.Mpad * a.Dpad;
+      for (int k0 = 0; k0 < a.splitk; k0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k0 + u < a.splitk ? *reinterpret_cast<const float4*>(src + (size_t)(k0 + u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (k0 + u >= a.splitk) break;
+          s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+        }
       }
       float4* o = reinterpret_cast<float4*>(a.dW + (t * a.Dreal + d));
       if (a.accumulate) { const float4 e = *o; s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w; }
@@ -1272,9 +1281,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const WgradArgs 
   const int d4 = threadIdx.x % dqp, kg = threadIdx.x / dqp;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (d4 < dq) {
-    for (int k = kg; k < a.splitk; k += KG) {
-      const float4 v = *reinterpret_cast<const float4*>(a.partial + ((size_t)k * a.Mpad + m) * a.Dpad + d4 * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    // this thread's slabs kg, kg + KG, ... in that order, four loads in flight
+    const float* src = a.partial + m * a.Dpad + d4 * 4;
+    const size_t sstride = (size_t)a.Mpad * a.Dpad;
+    for (int k0 = kg; k0 < a.splitk; k0 += 4 * KG) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = k0 + u * KG < a.splitk ? *reinterpret_cast<const float4*>(src + (size_t)(k0 + u * KG) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + u * KG >= a.splitk) break;
+        s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+      }
     }
   }
   sm[threadIdx.x] = s;
