@@ -209,6 +209,9 @@ typedef struct vp_bfmnet_desc {
   int batch;          /* clips */
   int frames;         /* T video frames per clip; the mel input has 5*T frames (frame_mfcc_scale, generator.py:46-52) */
   int num_mel_bins;   /* 80 */
+  int trunk_dtype;    /* VP_F32 (parity path: coefficients 1e-5 vs the float64 oracle) or VP_BF16 (opt-in, 2x the rate): the 6x-expanded
+                         tensors and the 1x1-conv operands of MfccNet in bf16, f32 accumulation / residual stream / depthwise /
+                         pooling / head; trunk features within 4e-2 rel-L2 of the oracle (tests/test_gpu_audio.py) */
 } vp_bfmnet_desc;
 typedef struct vp_bfmnet vp_bfmnet_t;
 size_t vp_bfmnet_param_count(void);

@@ -7,6 +7,7 @@ from oracle import audio_ref as ar   # pcm length helper + BFMNet initialiser on
 from voicepuppet_amd.audio import LogMel, BFMNetEngine
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+trunk = sys.argv[2] if len(sys.argv) > 2 else "f32"      # "bf16": MfccNet activations / 1x1-conv operands in bf16
 
 def timed(fn, warm, n):
   for _ in range(warm): fn()
@@ -16,11 +17,11 @@ def timed(fn, warm, n):
 
 B, T = 64, 25
 pcm = torch.tensor(np.random.default_rng(0).normal(0, 0.1, (B, ar.pcm_length_for(T))).astype(np.float32), device="cuda")
-lm = LogMel(B, pcm.shape[1]); net = BFMNetEngine(B, T); net.load_params(ar.init_bfmnet_params(0, dtype=np.float32))
+lm = LogMel(B, pcm.shape[1]); net = BFMNetEngine(B, T, dtype=trunk); net.load_params(ar.init_bfmnet_params(0, dtype=np.float32))
 ears = torch.full((B, T, 1), 0.3, device="cuda"); seq = [T] * B
 dt_lm = timed(lambda: lm(pcm), 3, steps)
 mf = lm(pcm)
 dt_net = timed(lambda: net.forward(ears, mf, seq), 3, steps)
-print(json.dumps({"config": "log-mel -> BFMNet f32 bs=64 x 1 s", "logmel_ms": dt_lm * 1e3, "bfmnet_ms": dt_net * 1e3,
+print(json.dumps({"config": "log-mel -> BFMNet %s bs=64 x 1 s" % trunk, "logmel_ms": dt_lm * 1e3, "bfmnet_ms": dt_net * 1e3,
                   "audio_seconds_per_s": B / (dt_lm + dt_net), "logmel_GBps": 4 * (pcm.numel() + mf.numel()) / dt_lm / 1e9,
                   "bfmnet_tflops": 10.64e9 * B / dt_net / 1e12}))

@@ -60,3 +60,29 @@ def test_bfmnet_parity(b, t, lens):
   assert gu.rel_l2(out, ref["BFMCoeffDecoder"]) < 1e-3
   for i, n in enumerate(lens):       # dynamic_rnn: outputs past sequence_length are zero
     assert np.all(rnn[i, n:] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t,lens", [(2, 6, [6, 4]), (3, 25, [25, 25, 17])])
+def test_bfmnet_bf16_trunk(b, t, lens):
+  """trunk_dtype = bf16 (opt-in throughput mode, 2x the f32 path): the 6x-expanded tensors and every 1x1-conv operand of MfccNet
+  in bf16 (f32 accumulation, f32 residual stream, f32 depthwise / pooling arithmetic, f32 head).  Stated tolerance: 4e-2 rel-L2 on
+  the trunk's output features (about 50 bf16-operand GEMMs in sequence: sqrt(50) * 2^-8); the recurrent head of a RANDOMLY
+  initialised net amplifies that to about 1e-1 on the coefficients (bounded at 2e-1 here) - the parity path stays f32 (1e-3 above).
+  Sequence-length masking is exact in both."""
+  p = ar.init_bfmnet_params(3, dtype=np.float32)
+  rng = np.random.default_rng(4)
+  pcm = synth_pcm(b, ar.pcm_length_for(t), seed=5)
+  mfcc = ar.extract_mfcc(pcm.astype(np.float64)).astype(np.float32)
+  ears = (rng.uniform(size=(b, t, 1)) / 100).astype(np.float32)
+  eng = BFMNetEngine(b, t, dtype="bf16")
+  eng.load_params(p)
+  out = eng.forward(torch.tensor(ears, device="cuda"), torch.tensor(mfcc, device="cuda"), lens).cpu().numpy()
+  ref = ar.bfmnet_fwd({k: v.astype(np.float64) for k, v in p.items()}, ears.astype(np.float64), mfcc.astype(np.float64), lens)
+  enc = eng.tensor("MfccEncoder").cpu().numpy()
+  rnn = eng.tensor("RNNModule").cpu().numpy()
+  e = (gu.rel_l2(enc, ref["MfccEncoder"]), gu.rel_l2(rnn, ref["RNNModule"]), gu.rel_l2(out, ref["BFMCoeffDecoder"]))
+  print("\nbf16 trunk: MfccEncoder %.2e RNN %.2e coeff %.2e" % e)
+  assert e[0] < 4e-2 and e[1] < 2e-1 and e[2] < 2e-1, e
+  for i, n in enumerate(lens):
+    assert np.all(rnn[i, n:] == 0)

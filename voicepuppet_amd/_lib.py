@@ -28,7 +28,7 @@ class LogMelDesc(ctypes.Structure):
 
 
 class BfmNetDesc(ctypes.Structure):
-  _fields_ = [("batch", ctypes.c_int), ("frames", ctypes.c_int), ("num_mel_bins", ctypes.c_int)]
+  _fields_ = [("batch", ctypes.c_int), ("frames", ctypes.c_int), ("num_mel_bins", ctypes.c_int), ("trunk_dtype", ctypes.c_int)]
 
 
 class BfmModel(ctypes.Structure):

@@ -68,11 +68,12 @@ def bfmnet_manifest():
 class BFMNetEngine:
   """BFMNet.build_inference_op (bfmnet.py:325-333) for a fixed [batch, frames] shape."""
 
-  def __init__(self, batch, frames, num_mel_bins=80):
+  def __init__(self, batch, frames, num_mel_bins=80, dtype="f32"):
+    """dtype "f32": the parity path; "bf16": MfccNet activations / 1x1-conv operands in bf16 (f32 accumulation, f32 head)."""
     if not torch.cuda.is_available():
       raise RuntimeError("BFMNetEngine needs an MI355X (no CPU fallback)")
     self.L = _lib.lib()
-    self.desc = BfmNetDesc(batch, frames, num_mel_bins)
+    self.desc = BfmNetDesc(batch, frames, num_mel_bins, {"f32": _lib.VP_F32, "bf16": _lib.VP_BF16}[dtype])
     d = ctypes.byref(self.desc)
     self.manifest = bfmnet_manifest()
     self.params = torch.zeros(self.L.vp_bfmnet_param_count(), dtype=torch.float32, device="cuda")

@@ -37,9 +37,26 @@ __global__ __launch_bounds__(128) void mag_mel_log_kernel(const float* __restric
   }
 }
 
+// four consecutive channels of an activation tensor stored as float or bf16 (the bf16 trunk of vp_bfmnet: f32 arithmetic, bf16 storage)
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16>(const bf16* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16>(bf16* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(Elem<bf16>::pack2(v.x, v.y), Elem<bf16>::pack2(v.z, v.w));
+}
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16>(bf16* p, float v) { *reinterpret_cast<unsigned short*>(p) = (unsigned short)f32_to_bf16_bits(v); }
+
 // y = relu(conv9x5 stride (1,2) SAME (x[B,H,W,1]) * folded_scale + folded_bias)   (tinynet.py:168)
+template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w /*[45][Cout]*/,
-                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const float* __restrict__ bias, T* __restrict__ y,
                                                          int B, int H, int W, int Wo, int Cout, int pt, int pl) {
   extern __shared__ float sw[];
   for (int i = threadIdx.x; i < 45 * Cout; i += 256) sw[i] = w[i];
@@ -61,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         acc = fmaf(x[((size_t)b * H + ih) * W + iw], sw[(kh * 5 + kw) * Cout + co], acc);
       }
     }
-    y[i] = fmaxf(acc, 0.f);
+    st1<T>(y + i, fmaxf(acc, 0.f));
   }
 }
 
@@ -69,8 +86,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 // A thread owns 4 channels of a column strip of RH = 8 consecutive output rows: the 21 taps live in registers and the (RH + 6) x 3
 // input pixels of the strip are loaded once each (5 loads per output instead of 21 + 21 weight loads: the pass was load-issue
 // bound).  Per output the products are still accumulated bias first, then kh = 0..6, kw = 0..2 (same sums as a per-pixel loop).
-__global__ __launch_bounds__(256) void dwconv7x3_kernel(const float* __restrict__ x, const float* __restrict__ w /*[21][C]*/,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7x3_kernel(const T* __restrict__ x, const float* __restrict__ w /*[21][C]*/,
+                                                        const float* __restrict__ bias, T* __restrict__ y, int B, int H, int W, int C) {
   constexpr int RH = 8;
   const int cq = C >> 2, hb = (H + RH - 1) / RH;
   const size_t total = (size_t)B * hb * W * cq;
@@ -95,7 +113,7 @@ __global__ __launch_bounds__(256) void dwconv7x3_kernel(const float* __restrict_
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = ow + kw - 1;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const float4 xv = *reinterpret_cast<const float4*>(x + (((size_t)b * H + ih) * W + iw) * C + c4);
+        const float4 xv = ld4<T>(x + (((size_t)b * H + ih) * W + iw) * C + c4);
 #pragma unroll
         for (int r = 0; r < RH; ++r) {
           const int kh = j - r;                    // input row ih = (oh0 + r) + kh - 3
@@ -112,13 +130,14 @@ __global__ __launch_bounds__(256) void dwconv7x3_kernel(const float* __restrict_
       float4 a = acc[r];
       a.x = fminf(fmaxf(a.x, 0.f), 6.f); a.y = fminf(fmaxf(a.y, 0.f), 6.f);
       a.z = fminf(fmaxf(a.z, 0.f), 6.f); a.w = fminf(fmaxf(a.w, 0.f), 6.f);
-      *reinterpret_cast<float4*>(y + (((size_t)b * H + oh0 + r) * W + ow) * C + c4) = a;
+      st4<T>(y + (((size_t)b * H + oh0 + r) * W + ow) * C + c4, a);
     }
   }
 }
 
 // max-pool kxk, stride s, TF 'SAME' (padding never wins), 4 channels per thread
-__global__ __launch_bounds__(256) void maxpool_same_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void maxpool_same_kernel(const TI* __restrict__ x, TO* __restrict__ y, int B, int H, int W, int C,
                                                            int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo) {
   const int cq = C >> 2;
   const size_t total = (size_t)B * Ho * Wo * cq;
@@ -135,12 +154,17 @@ __global__ __launch_bounds__(256) void maxpool_same_kernel(const float* __restri
       for (int j2 = 0; j2 < kw; ++j2) {
         const int iw = ow * sw + j2 - pl;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + ih) * W + iw) * C + c4);
+        const float4 v = ld4<TI>(x + (((size_t)b * H + ih) * W + iw) * C + c4);
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    *reinterpret_cast<float4*>(y + i * 4) = m;
+    st4<TO>(y + i * 4, m);
   }
+}
+
+// f32 -> bf16 copy of a narrow trunk tensor (the operand of the next expansion conv; the residual stream itself stays f32)
+__global__ __launch_bounds__(256) void cvt_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) st4<bf16>(y + i * 4, ld4<float>(x + i * 4));
 }
 
 // inference batch-norm folding (contrib batch_norm: no gamma, eps 1e-3):
@@ -213,16 +237,28 @@ hipError_t launch_mag_mel_log(const float* spec, int ld, int nb, const float* me
   hipLaunchKernelGGL(mag_mel_log_kernel, dim3(nframes), dim3(128), nb * sizeof(float), st, spec, ld, nb, mel, nmel, out);
   return hipGetLastError();
 }
-hipError_t launch_conv_first(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Wo, int Cout, int pt, int pl, hipStream_t st) {
-  hipLaunchKernelGGL(conv_first_kernel, dim3(nblk((size_t)B * H * Wo * Cout)), dim3(256), 45 * Cout * sizeof(float), st, x, w, bias, y, B, H, W, Wo, Cout, pt, pl);
+// out_bf16 / in_bf16: storage type of the activation tensors (bf16 trunk of vp_bfmnet); arithmetic is f32 either way
+hipError_t launch_conv_first(const float* x, const float* w, const float* bias, void* y, int out_bf16, int B, int H, int W, int Wo, int Cout, int pt, int pl, hipStream_t st) {
+  const dim3 grid(nblk((size_t)B * H * Wo * Cout));
+  if (out_bf16) hipLaunchKernelGGL((conv_first_kernel<bf16>), grid, dim3(256), 45 * Cout * sizeof(float), st, x, w, bias, (bf16*)y, B, H, W, Wo, Cout, pt, pl);
+  else hipLaunchKernelGGL((conv_first_kernel<float>), grid, dim3(256), 45 * Cout * sizeof(float), st, x, w, bias, (float*)y, B, H, W, Wo, Cout, pt, pl);
   return hipGetLastError();
 }
-hipError_t launch_dwconv7x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, hipStream_t st) {
-  hipLaunchKernelGGL(dwconv7x3_kernel, dim3(nblk((size_t)B * ((H + 7) / 8) * W * (C / 4), 8192)), dim3(256), 0, st, x, w, bias, y, B, H, W, C);
+hipError_t launch_dwconv7x3(const void* x, const float* w, const float* bias, void* y, int is_bf16, int B, int H, int W, int C, hipStream_t st) {
+  const dim3 grid(nblk((size_t)B * ((H + 7) / 8) * W * (C / 4), 8192));
+  if (is_bf16) hipLaunchKernelGGL((dwconv7x3_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C);
+  else hipLaunchKernelGGL((dwconv7x3_kernel<float>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C);
   return hipGetLastError();
 }
-hipError_t launch_maxpool_same(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, hipStream_t st) {
-  hipLaunchKernelGGL(maxpool_same_kernel, dim3(nblk((size_t)B * Ho * Wo * (C / 4))), dim3(256), 0, st, x, y, B, H, W, C, kh, kw, sh, sw, pt, pl, Ho, Wo);
+hipError_t launch_maxpool_same(const void* x, void* y, int in_bf16, int out_bf16, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, hipStream_t st) {
+  const dim3 grid(nblk((size_t)B * Ho * Wo * (C / 4)));
+  if (in_bf16 && out_bf16) hipLaunchKernelGGL((maxpool_same_kernel<bf16, bf16>), grid, dim3(256), 0, st, (const bf16*)x, (bf16*)y, B, H, W, C, kh, kw, sh, sw, pt, pl, Ho, Wo);
+  else if (in_bf16) hipLaunchKernelGGL((maxpool_same_kernel<bf16, float>), grid, dim3(256), 0, st, (const bf16*)x, (float*)y, B, H, W, C, kh, kw, sh, sw, pt, pl, Ho, Wo);
+  else hipLaunchKernelGGL((maxpool_same_kernel<float, float>), grid, dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, kh, kw, sh, sw, pt, pl, Ho, Wo);
+  return hipGetLastError();
+}
+hipError_t launch_cvt_f32_bf16(const float* x, void* y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(nblk(n / 4)), dim3(256), 0, st, x, (bf16*)y, n / 4);
   return hipGetLastError();
 }
 hipError_t launch_fold_bn(const float* w, const float* beta, const float* mean, const float* var, float eps, size_t n, int C, float* wf, float* bf, hipStream_t st) {

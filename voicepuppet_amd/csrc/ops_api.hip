@@ -243,7 +243,7 @@ int vp_gan_loss(const float* logits, void* seed_d, void* seed_g, float* predict,
 
 int vp_dwconv7x3_bn_act(const float* x, const float* w, const float* bias, float* y, int b, int h, int wd, int c, void* stream) {
   if (!x || !w || !bias || !y || b < 1 || h < 1 || wd < 1 || c < 4 || (c & 3)) { set_err("vp_dwconv7x3_bn_act: bad argument"); return VP_ERR_ARG; }
-  VP_HIP_CHECK(launch_dwconv7x3(x, w, bias, y, b, h, wd, c, (hipStream_t)stream));
+  VP_HIP_CHECK(launch_dwconv7x3(x, w, bias, y, 0, b, h, wd, c, (hipStream_t)stream));
   return VP_OK;
 }
 
@@ -253,7 +253,7 @@ int vp_maxpool_hw(const float* x, float* y, int b, int h, int w, int c, int kh, 
   const int ho = (h + sh - 1) / sh, wo = (w + sw - 1) / sw;
   const int ph = (ho - 1) * sh + kh - h, pw = (wo - 1) * sw + kw - w;
   const int pt = ph > 0 ? ph / 2 : 0, pl = pw > 0 ? pw / 2 : 0;
-  VP_HIP_CHECK(launch_maxpool_same(x, y, b, h, w, c, kh, kw, sh, sw, pt, pl, ho, wo, (hipStream_t)stream));
+  VP_HIP_CHECK(launch_maxpool_same(x, y, 0, 0, b, h, w, c, kh, kw, sh, sw, pt, pl, ho, wo, (hipStream_t)stream));
   return VP_OK;
 }
 

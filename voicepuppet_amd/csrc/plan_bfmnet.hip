@@ -42,7 +42,8 @@ struct Gemm {
   int src_ld = 0;        // row stride (cout of the full TF kernel; GRU kernels are read partially)
   int which = 0;         // 0: folded arena, 1: raw parameter arena
   size_t bias = 0;       // float offset of the bias (folded arena or raw arena, same `which`)
-  size_t pk = 0;         // element offset in the packed arena
+  size_t pk = 0;         // BYTE offset in the packed arena
+  int bf = 0;            // bf16 operands / output (the MfccNet trunk in bf16-storage mode), f32 accumulation
   IgemmPlan plan;
 };
 
@@ -257,6 +258,7 @@ struct vp_bfmnet {
   float* folded;
   char* packed;
   size_t packed_elems;
+  void* nb16;            // bf16 copy of the current narrow trunk tensor (bf16-trunk mode: operand of the expansion / shortcut convs)
   float *mf, *n0, *n1, *ex, *dwb, *pooled, *enc, *c1, *xg, *xc, *rnn, *dd0, *dd1;
   char* scratch;
   size_t scratch_bytes;
@@ -267,14 +269,14 @@ struct vp_bfmnet {
 
 namespace {
 
-void plan_gemm(vp_bfmnet* h, Gemm& g, int pixels, int cin, int cout, int which, size_t w_src, int src_ld, size_t bias) {
-  g.cin = cin; g.cout = cout; g.which = which; g.w_src = w_src; g.src_ld = src_ld; g.bias = bias;
+void plan_gemm(vp_bfmnet* h, Gemm& g, int pixels, int cin, int cout, int which, size_t w_src, int src_ld, size_t bias, int bf = 0) {
+  g.cin = cin; g.cout = cout; g.which = which; g.w_src = w_src; g.src_ld = src_ld; g.bias = bias; g.bf = bf;
   ConvGeomX geo = make_geom(0, 1, 1, 0, 1, pixels, 1, cin, cin, cout);
-  g.plan = plan_fwd(geo, w_src, 0);
+  g.plan = plan_fwd(geo, w_src, bf);
   g.plan.pack.s_ch = src_ld;      // row stride of the [cin, cout] source matrix (HWIO with H = W = 1)
-  g.pk = h->packed_elems;
-  g.plan.pack.dst_off = g.pk;
-  h->packed_elems += (g.plan.pack_elems + 63) & ~(size_t)63;
+  g.pk = h->packed_elems;         // (bytes: the arena mixes bf16 and f32 blocks; every block is packed relative to its own base)
+  g.plan.pack.dst_off = 0;
+  h->packed_elems += (g.plan.pack_elems * (bf ? 2 : 4) + 255) & ~(size_t)255;
   if (g.plan.partial_bytes > h->scratch_bytes) h->scratch_bytes = g.plan.partial_bytes;
 }
 
@@ -287,16 +289,18 @@ size_t bfm_carve(vp_bfmnet* h, char* base) {
   // mel widths: 80 -> 40 (stem stride 2) -> 20 -> 10 -> 5 -> 3 (SAME pools after block2_0, 3_0, 4_0, 6_0)
   int W = (h->d.num_mel_bins + 1) / 2;
   size_t max_net = 0, max_exp = 0;
+  const int tb = h->d.trunk_dtype == VP_BF16 ? 1 : 0;      // MfccNet activations / 1x1-conv operands in bf16 (f32 accumulation)
+  const size_t tes = tb ? 2 : 4;
   for (Block& b : m.blocks) {
     const int P = B * h->T5 * W;
-    plan_gemm(h, b.g_expand, P, b.cin, b.cexp, 0, b.expand.wf, b.cexp, b.expand.bf);
-    plan_gemm(h, b.g_project, P, b.cexp, b.cout, 0, b.project.wf, b.cout, b.project.bf);
-    if (b.shortcut) plan_gemm(h, b.g_sc, P, b.cin, b.cout, 0, b.sc.wf, b.cout, b.sc.bf);
+    plan_gemm(h, b.g_expand, P, b.cin, b.cexp, 0, b.expand.wf, b.cexp, b.expand.bf, tb);
+    plan_gemm(h, b.g_project, P, b.cexp, b.cout, 0, b.project.wf, b.cout, b.project.bf, tb);
+    if (b.shortcut) plan_gemm(h, b.g_sc, P, b.cin, b.cout, 0, b.sc.wf, b.cout, b.sc.bf, tb);
     if ((size_t)P * b.cexp > max_exp) max_exp = (size_t)P * b.cexp;
     if ((size_t)P * (b.cin > b.cout ? b.cin : b.cout) > max_net) max_net = (size_t)P * (b.cin > b.cout ? b.cin : b.cout);
     if (b.pool) W = (W + 1) / 2;
   }
-  plan_gemm(h, m.g_last, B * h->T5 * W, 256, 256, 0, m.last.wf, 256, m.last.bf);
+  plan_gemm(h, m.g_last, B * h->T5 * W, 256, 256, 0, m.last.wf, 256, m.last.bf, tb);
   const int BT = B * T;
   plan_gemm(h, m.g_enc, BT, 256, 256, 1, m.enc_w, 256, m.enc_b);
   plan_gemm(h, m.g_rnn, BT, 256, 256, 1, m.rnn_w, 256, m.rnn_b);
@@ -306,11 +310,12 @@ size_t bfm_carve(vp_bfmnet* h, char* base) {
   plan_gemm(h, m.g_d1, BT, 128, 64, 1, m.d1w, 64, m.d1b);
   plan_gemm(h, m.g_d2, BT, 64, 64, 1, m.d2w, 64, m.d2b);
   h->folded = (float*)ar.alloc(m.nfolded * sizeof(float));
-  h->packed = (char*)ar.alloc(h->packed_elems * sizeof(float));
-  h->n0 = (float*)ar.alloc(max_net * sizeof(float));
+  h->packed = (char*)ar.alloc(h->packed_elems);
+  h->n0 = (float*)ar.alloc(max_net * sizeof(float));      // the residual stream stays f32 in both modes
   h->n1 = (float*)ar.alloc(max_net * sizeof(float));
-  h->ex = (float*)ar.alloc(max_exp * sizeof(float));
-  h->dwb = (float*)ar.alloc(max_exp * sizeof(float));
+  h->nb16 = ar.alloc(max_net * 2);
+  h->ex = (float*)ar.alloc(max_exp * tes);
+  h->dwb = (float*)ar.alloc(max_exp * tes);
   h->pooled = (float*)ar.alloc((size_t)BT * 256 * 4);
   h->enc = (float*)ar.alloc((size_t)BT * 256 * 4);
   h->c1 = (float*)ar.alloc((size_t)BT * 256 * 4);
@@ -324,17 +329,20 @@ size_t bfm_carve(vp_bfmnet* h, char* base) {
   return ar.off + 256;
 }
 
-bool bfm_ok(const vp_bfmnet_desc* d) { return d && d->batch >= 1 && d->frames >= 1 && d->num_mel_bins == 80; }
+bool bfm_ok(const vp_bfmnet_desc* d) {
+  return d && d->batch >= 1 && d->frames >= 1 && d->num_mel_bins == 80 && (d->trunk_dtype == VP_F32 || d->trunk_dtype == VP_BF16);
+}
 
-int run_gemm(vp_bfmnet* h, Gemm& g, const float* x, float* y, int act, int accumulate, hipStream_t st) {
+int run_gemm(vp_bfmnet* h, Gemm& g, const void* x, void* y, int act, int accumulate, hipStream_t st, int y_f32 = 0) {
   IgemmArgs a = g.plan.a;
+  a.y_f32 = (g.bf && y_f32) ? 1 : 0;           // bf16 operands, f32 result (residual stream / head inputs)
   set_single_src(a.x, x, g.cin, nullptr, nullptr, ACT_NONE, 0);
-  a.Wp = h->packed + g.pk * sizeof(float);
+  a.Wp = h->packed + g.pk;
   a.Y = y; a.ldY = g.cout;
   a.bias = (g.which == 0 ? h->folded : h->params) + g.bias;
   a.out_act = act; a.accumulate = accumulate;
   a.partial = (float*)h->scratch; a.zeros = h->zeros;
-  VP_HIP_CHECK(launch_igemm(a, 0, g.plan.cfg, st));
+  VP_HIP_CHECK(launch_igemm(a, g.bf, g.plan.cfg, st));
   return VP_OK;
 }
 
@@ -351,7 +359,7 @@ int prepare_weights(vp_bfmnet* h, hipStream_t st) {
   }
   VP_HIP_CHECK(fold(m.last));
   auto pack = [&](Gemm& g) -> hipError_t {
-    return launch_pack_weights_one(g.plan.pack, g.which == 0 ? h->folded : h->params, h->packed, 0, st);
+    return launch_pack_weights_one(g.plan.pack, g.which == 0 ? h->folded : h->params, h->packed + g.pk, g.bf, st);
   };
   for (Block& b : m.blocks) {
     VP_HIP_CHECK(pack(b.g_expand)); VP_HIP_CHECK(pack(b.g_project));
@@ -418,35 +426,45 @@ int vp_bfmnet_forward(vp_bfmnet_t* h, const float* ears, const float* mfccs, con
   int W = h->d.num_mel_bins, pl, Wo;
   // stem: conv [9,5] stride [1,2] SAME on [B, 5T, 80, 1]
   same_pad(W, 5, 2, &pl, &Wo);
-  VP_HIP_CHECK(launch_conv_first(mfccs, h->folded + m.stem.wf, h->folded + m.stem.bf, h->n0, B, H, W, Wo, 32, 4, pl, st));
+  // bf16-trunk mode: the 6x-expanded tensors (ex, dwb: the bytes of this network) and every 1x1-conv operand are bf16; the narrow
+  // residual stream (block inputs / outputs) stays f32 so that rounding does not compound over the 17 blocks - an expansion conv
+  // reads a bf16 COPY of it (nb16), the projection conv adds its f32 result into it
+  const int tb = h->d.trunk_dtype == VP_BF16 ? 1 : 0;
+  VP_HIP_CHECK(launch_conv_first(mfccs, h->folded + m.stem.wf, h->folded + m.stem.bf, h->n0, 0, B, H, W, Wo, 32, 4, pl, st));
   W = Wo;
   float* cur = h->n0;
   float* alt = h->n1;
+  auto operand = [&](const float* t, int c) -> const void* {      // what a trunk GEMM reads for the narrow tensor t
+    if (!tb) return t;
+    (void)launch_cvt_f32_bf16(t, h->nb16, (size_t)B * H * W * c, st);
+    return h->nb16;
+  };
   for (Block& b : m.blocks) {
-    if ((rc = run_gemm(h, b.g_expand, cur, h->ex, ACT_RELU6, 0, st))) return rc;
-    VP_HIP_CHECK(launch_dwconv7x3(h->ex, h->folded + b.dw.wf, h->folded + b.dw.bf, h->dwb, B, H, W, b.cexp, st));
+    const void* xin = operand(cur, b.cin);
+    if ((rc = run_gemm(h, b.g_expand, xin, h->ex, ACT_RELU6, 0, st))) return rc;
+    VP_HIP_CHECK(launch_dwconv7x3(h->ex, h->folded + b.dw.wf, h->folded + b.dw.bf, h->dwb, tb, B, H, W, b.cexp, st));
     if (b.shortcut) {
-      if ((rc = run_gemm(h, b.g_sc, cur, alt, ACT_NONE, 0, st))) return rc;
-      if ((rc = run_gemm(h, b.g_project, h->dwb, alt, ACT_NONE, 1, st))) return rc;
+      if ((rc = run_gemm(h, b.g_sc, xin, alt, ACT_NONE, 0, st, 1))) return rc;
+      if ((rc = run_gemm(h, b.g_project, h->dwb, alt, ACT_NONE, 1, st, 1))) return rc;
       float* t = cur; cur = alt; alt = t;
     } else {
-      if ((rc = run_gemm(h, b.g_project, h->dwb, cur, ACT_NONE, 1, st))) return rc;   // residual add in place
+      if ((rc = run_gemm(h, b.g_project, h->dwb, cur, ACT_NONE, 1, st, 1))) return rc;   // residual add in place
     }
     if (b.pool) {   // max_pooling2d([2,2], strides [1,2], 'same'): time pad (0,1), mel pad (0, W odd)
       const int Wn = (W + 1) / 2;
-      VP_HIP_CHECK(launch_maxpool_same(cur, alt, B, H, W, b.cout, 2, 2, 1, 2, 0, 0, H, Wn, st));
+      VP_HIP_CHECK(launch_maxpool_same(cur, alt, 0, 0, B, H, W, b.cout, 2, 2, 1, 2, 0, 0, H, Wn, st));
       float* t = cur; cur = alt; alt = t;
       W = Wn;
     }
   }
-  if ((rc = run_gemm(h, m.g_last, cur, alt, ACT_RELU, 0, st))) return rc;
+  if ((rc = run_gemm(h, m.g_last, operand(cur, 256), alt, ACT_RELU, 0, st, 1))) return rc;
   // MfccEncoder pool [5,3] stride [5,3] SAME -> [B, T, 1, 256]  (bfmnet.py:35)
   {
     int pt, ph, pw2, wo2;
     same_pad(H, 5, 5, &pt, &ph);
     same_pad(W, 3, 3, &pw2, &wo2);
     if (ph != T || wo2 != 1) { set_err("vp_bfmnet_forward: unexpected pooled size %dx%d", ph, wo2); return VP_ERR_STATE; }
-    VP_HIP_CHECK(launch_maxpool_same(alt, h->pooled, B, H, W, 256, 5, 3, 5, 3, pt, pw2, ph, wo2, st));
+    VP_HIP_CHECK(launch_maxpool_same(alt, h->pooled, 0, 0, B, H, W, 256, 5, 3, 5, 3, pt, pw2, ph, wo2, st));
   }
   if ((rc = run_gemm(h, m.g_enc, h->pooled, h->enc, ACT_LEAKY, 0, st))) return rc;
   if ((rc = run_gemm(h, m.g_rnn, h->enc, h->c1, ACT_LEAKY, 0, st))) return rc;
