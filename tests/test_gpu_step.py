@@ -211,7 +211,9 @@ def test_step_parity_bf16_against_rounding_aware_oracle(oracle_step):
   print("\n[bf16 vs rounding-aware oracle] intermediates %s\n worst gradient rel-L2: %s" % (mid, top))
   # residual: f32 accumulation order differs from the oracle's, which flips the bf16 rounding (1 ulp = 0.4 %) of a few
   # per cent of the elements at each of the ~8 backward stages
-  assert max(mid.values()) < 2e-2, mid
+  # (d_din of this 8-channel mini net moves between 1.5e-2 and 2.4e-2 with the split-K setting of the discriminator's first layer -
+  # the order of the f32 partial sums decides a few more bf16 roundings; bound 3e-2, the gradient bound below is unchanged)
+  assert max(mid.values()) < 3e-2, mid
   bad = {k: v for k, v in worst.items() if v > 5e-2}   # measured worst: 3.0e-2 (a bias gradient), typical 1e-2
   assert not bad, bad
 

@@ -57,6 +57,7 @@ struct IgemmArgs {
   int direct_epi;           // store straight from the accumulators (needs rowperm; set by the launcher, opt-in)
   int rowperm;              // packed weight rows are permuted inside every 64-row block (PackDesc::perm): MFMA tile t, row 4q+e of a
                             // block holds channel 32*(t>>1) + 8q + 4*(t&1) + e, so a lane ends with 2 x 8 consecutive channels per pixel
+  int xcd_remap;            // conv_patch3.hip: pixel tiles dealt to the XCDs in contiguous runs (set by the launcher)
   double* bn_part;          // staged epilogue also writes batch-norm partials [group][bn_nchunk][2][Cout] (null: no)
   int bn_tpg, bn_nchunk;    // pixel tiles per BN group (per class), partial chunks per group = nclass * bn_tpg
   const void* zeros;        // >= 16 bytes of zeros (padding source of the LDS-DMA loader); null: register loader

@@ -60,9 +60,11 @@ inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
 }
 
 inline int pick_igemm_splitk(int blocks, int nchunk) {
-  static const int target = getenv("VP_SPLITK_TARGET") ? atoi(getenv("VP_SPLITK_TARGET")) : 512;   // resident blocks aimed at.  (128 / 16 / 16 measured 11.77 vs 11.87 ms/step,
-  static const int cap = getenv("VP_SPLITK_MAX") ? atoi(getenv("VP_SPLITK_MAX")) : 32;         //  scripts/splitk_sweep.sh, but moves the mini-net bf16 d_din check from 1e-2 to 4e-2: not adopted)
-  static const int minchunk = getenv("VP_SPLITK_MINCHUNK") ? atoi(getenv("VP_SPLITK_MINCHUNK")) : 2;   // K chunks per split at least
+  // round-2 sweep (scripts/exp_sk.sh): target 128 / cap 8 / at least 4 chunks per split: 8.79 vs 8.97 ms at batch 32, 2.84 vs 3.00 ms at
+  // batch 4 against the round-1 setting 512 / 32 / 2 - the slab reduce and the short blocks cost more than the idle CUs
+  static const int target = getenv("VP_SPLITK_TARGET") ? atoi(getenv("VP_SPLITK_TARGET")) : 128;   // resident blocks aimed at
+  static const int cap = getenv("VP_SPLITK_MAX") ? atoi(getenv("VP_SPLITK_MAX")) : 8;
+  static const int minchunk = getenv("VP_SPLITK_MINCHUNK") ? atoi(getenv("VP_SPLITK_MINCHUNK")) : 4;   // K chunks per split at least
   if (blocks >= 256) return 1;
   int s = (target + blocks - 1) / blocks;
   if (s > nchunk / minchunk) s = nchunk / minchunk;
@@ -208,6 +210,7 @@ inline void plan_make_patch(IgemmPlan& p, int rows, int is_bf16) {
 
 // The four parity classes of a 4x4 stride-2 transposed conv (deconv forward, conv backward-data) on the unrolled 2x2-tap patch
 // kernel (conv_patch2.hip).  c0 / c1: channels of the one or two source tensors of the GEMM's pixel operand.
+inline int& patch_xcd_knob() { static int v = getenv("VP_PATCH_XCD") ? atoi(getenv("VP_PATCH_XCD")) : 0; return v; }
 inline int& patch2_knob() { static int v = getenv("VP_NO_PATCH2") ? 0 : 1; return v; }
 inline bool plan_patch2_eligible(const IgemmPlan& p, int rows, int is_bf16, int c0, int c1) {
   const IgemmArgs& a = p.a;

@@ -16,6 +16,7 @@
 
 #include <utility>
 
+#include "conv_ops.h"
 #include "igemm_device.h"
 #include "launch.h"
 #include "patch_device.h"
@@ -66,9 +67,11 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c_base = blockIdx.y * BC;
   const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
-  // (an XCD-aware tile order - each XCD a contiguous run of tiles, so that halo pixels meet in one L2 - was measured: no change,
-  // the shared infinity cache already serves the halos)
-  const int bt = blockIdx.x;
+  // XCD-aware tile order (a.xcd_remap): each XCD a contiguous run of tiles, so that halo pixels meet in one L2.  No change for the
+  // kernel alone (the shared infinity cache already serves the halos); it takes L2-miss traffic off the fabric the co-running
+  // streams share
+  int bt = blockIdx.x;
+  if (a.xcd_remap && (gridDim.x & 7) == 0) bt = (bt & 7) * (gridDim.x >> 3) + (bt >> 3);
   const int n = bt / (tiles_x * tiles_y);
   const int trem = bt - n * (tiles_x * tiles_y);
   const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
@@ -226,6 +229,7 @@ bool patch3_eligible(const IgemmArgs& a, int is_bf16) {
 hipError_t launch_igemm_patch3(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st) {
   IgemmArgs b = a;
   b.vec_epi = 1;
+  b.xcd_remap = patch_xcd_knob();
 #define VP_PATCH3_GO(WC, WP, TC, TP, TH, TW, OCC) \
   (is_bf16 ? launch_patch3_t<bf16, WC, WP, TC, TP, TH, TW, OCC>(b, st) : launch_patch3_t<float, WC, WP, TC, TP, TH, TW, OCC>(b, st))
   if (bc == 256) return bp == 128 ? VP_PATCH3_GO(2, 4, 8, 2, 8, 16, 4) : VP_PATCH3_GO(2, 4, 8, 4, 16, 16, 2);
