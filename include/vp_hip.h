@@ -296,6 +296,42 @@ int vp_bfm_reconstruct(const vp_bfm_model* m, const float* coeff, const double* 
                        double* face_shape, double* face_texture, double* face_color, double* face_projection, double* z_buffer,
                        float* vertices, float* colors, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * BFMNet TRAINING step (voicepuppet/bfmnet/bfmnet.py:215-323, tinynet.py:7-212): the non-GEMM kernels, float32 NHWC,
+ * any channel count that is a multiple of 4.  voicepuppet_amd/bfmnet/train_engine.py chains them with plain GEMMs (rocBLAS).
+ *   vp_bn_train_fwd / _bwd   tf.contrib.layers.batch_norm(is_training=True, scale=False, eps 1e-3): batch statistics + the affine that
+ *                            normalises (y = x * scale + shift), and its backward (dx, dbeta)
+ *   vp_affine_act_fwd        y = act(scale[c] * x + shift[c]) * mask (affine and mask optional: relu / relu6 / leaky-relu, dropout)
+ *   vp_act_bwd               dx = dy * mask * act'(y)
+ *   vp_dwconv7x3_raw         depthwise [7,3] SAME without bias / activation (forward; backward-data with reversed taps);
+ *   vp_dwconv7x3_wgrad       its weight gradient [21][c]
+ *   vp_maxpool_hw_bwd        backward of vp_maxpool_hw (first maximum of a window, as TF's MaxPoolGrad)
+ *   vp_stem_im2col           the 9x5 stride-(1,2) stem as a [pixels, 48] matrix (GEMM operand for forward and weight gradient)
+ *   vp_gru_train_fwd / _bwd  GRUCell recurrence with saved gates, and backward through time to the gate / candidate pre-activations
+ *   vp_bfm_vertex_loss       add_cost_function on D = face_shape(true) - face_shape(pred): loss partials (f64) and dLoss/dD
+ *   vp_sumsq                 sum of squares partials (f64): regulariser value, global-norm clipping
+ * ---------------------------------------------------------------------------------------------- */
+size_t vp_bn_train_workspace_bytes(size_t pixels, int c);
+int vp_bn_train_fwd(const float* x, size_t pixels, int c, const float* beta, float eps, float* mean, float* var, float* rstd, float* scale,
+                    float* shift, void* workspace, void* stream);
+int vp_bn_train_bwd(const float* x, const float* dz, size_t pixels, int c, const float* mean, const float* rstd, float* dx, float* dbeta,
+                    void* workspace, void* stream);
+int vp_affine_act_fwd(const float* x, const float* scale, const float* shift, const float* mask, size_t pixels, int c, int act, float* y, void* stream);
+int vp_act_bwd(const float* dy, const float* ya, const float* mask, size_t n, int act, float* dx, void* stream);
+int vp_dwconv7x3_raw(const float* x, const float* w, float* y, int b, int h, int wd, int c, void* stream);
+size_t vp_dwconv7x3_wgrad_workspace_bytes(int b, int wd, int c);
+int vp_dwconv7x3_wgrad(const float* x, const float* dy, float* dw, int b, int h, int wd, int c, void* workspace, void* stream);
+int vp_maxpool_hw_bwd(const float* x, const float* dy, float* dx, int b, int h, int w, int c, int kh, int kw, int sh, int sw, void* stream);
+int vp_stem_im2col(const float* x, float* col, int b, int h, int w, void* stream);
+int vp_gru_train_fwd(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, float* r, float* u, float* c,
+                     float* hprev, int b, int t, void* stream);
+int vp_gru_train_bwd(const float* dout, const float* whg, const float* whc, const int* seq_len, const float* r, const float* u, const float* c,
+                     const float* hprev, float* dag, float* dac, int b, int t, void* stream);
+int vp_vertex_loss_partials(int b, int j);
+int vp_bfm_vertex_loss(const float* d, const float* vmask, const int* seq_len, int b, int t, int j, float* gd, double* partial, void* stream);
+int vp_sumsq_partials(size_t n);
+int vp_sumsq(const float* x, size_t n, double* partial, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

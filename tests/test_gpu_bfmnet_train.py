@@ -1,0 +1,103 @@
+"""BFMNet training step on the device vs the float64 torch-CPU restatement of build_train_op
+(oracle/bfmnet_train_torch.py; parity unpinned by the reference - TF 1.x cannot run here).  Tolerances: float32 device arithmetic
+against float64, through 52 batch-normalised layers at a tiny batch: loss 1e-4, coefficients 1e-3, gradient tensors 3e-2 rel-L2.  The
+gradient bound is what float32 buys on this graph: the SAME torch restatement run in float32 differs from its float64 run by up to
+2.2e-2 on the same tensors (relu / relu6 / |.| kinks and 20-pixel batch statistics; measured); the device
+lands at 1.5e-2."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_ref as ar
+from oracle import bfmnet_train_torch as bt
+from voicepuppet_amd.bfmnet.train_engine import BFMNetTrainEngine, trainable
+
+import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, T, seq, nver, seed, with_masks):
+  rng = np.random.default_rng(seed)
+  p = ar.init_bfmnet_params(seed + 1, dtype=np.float32)
+  mf = rng.normal(0, 1, (B, 5 * T, 80)).astype(np.float32)
+  ears = (rng.uniform(size=(B, T, 1)) / 100).astype(np.float32)
+  coeff = rng.normal(0, 0.5, (B, T, 257)).astype(np.float32)
+  model = bt.synthetic_model(nver, seed + 2)
+  masks = {}
+  if with_masks:
+    for k, c in (("enc", 256), ("rnn", 256), ("d0", 128), ("d1", 64)):
+      masks[k] = ((rng.uniform(size=(B, T, c)) < 0.75) / 0.75).astype(np.float32)
+  return p, mf, ears, coeff, model, masks
+
+
+@pytest.mark.parametrize("B,T,seq,with_masks", [(2, 4, [4, 3], False), (3, 5, [5, 2, 4], True)])
+def test_train_step_matches_oracle(B, T, seq, with_masks):
+  p, mf, ears, coeff, model, masks = _case(B, T, seq, 120, 5, with_masks)
+  ref = bt.train_step({k: v.astype(np.float64) for k, v in p.items()}, None, ears, mf, coeff, seq, masks, model)
+  eng = BFMNetTrainEngine(B, T, model)
+  eng.load_params(p)
+  dev = lambda a: torch.tensor(a, device="cuda")
+  got = eng.train_step(dev(ears), dev(mf), dev(coeff), seq, {k: dev(v) for k, v in masks.items()})
+  out = eng.last_out.cpu().numpy()
+  print("\nloss %.6f vs %.6f, global norm %.4f vs %.4f, coefficients %.2e" % (got["loss"], ref["loss"], got["global_norm"], ref["global_norm"],
+                                                                            gu.rel_l2(out, ref["out"])))
+  assert got["loss"] == pytest.approx(ref["loss"], rel=1e-4)
+  assert got["loss_data"] == pytest.approx(ref["loss_data"], rel=1e-4)
+  assert got["global_norm"] == pytest.approx(ref["global_norm"], rel=1e-3)
+  assert gu.rel_l2(out, ref["out"]) < 1e-3
+  grads = eng.get_grads()
+  # (the beta of a batch-norm whose output only reaches the next batch-norm through linear ops - every projection / shortcut BN - has
+  # an analytically zero gradient: float64 gives 1e-17, float32 1e-9; such tensors are bounded absolutely against the global norm)
+  gnorm = ref["global_norm"] * min(1.0, 50.0 / ref["global_norm"])
+  live = [k for k in ref["grads"] if np.linalg.norm(ref["grads"][k]) > 1e-6 * gnorm]
+  dead = [k for k in ref["grads"] if k not in live]
+  worst = sorted(((gu.rel_l2(grads[k], ref["grads"][k]), k) for k in live), reverse=True)
+  print("worst gradient tensors:", [(round(e, 5), k.split("MfccNet/")[-1]) for e, k in worst[:4]], "analytically-zero tensors:", len(dead))
+  assert worst[0][0] < 3e-2, worst[:6]
+  assert all(np.linalg.norm(grads[k]) < 1e-4 * gnorm for k in dead)
+  # the first Adam step moves every element by lr * sign(gradient) (m / sqrt(v) = +-1 at t = 1): parameters agree to rounding wherever the
+  # sign of the gradient is not decided by float32 noise (|g| > 0.2 of the tensor's largest); moving statistics compare directly
+  new = eng.get_params()
+  for k in ref["params"]:
+    diff = np.abs(new[k] - ref["params"][k])
+    if trainable(k):
+      gr = np.abs(ref["grads"][k])
+      solid = gr > 0.2 * gr.max() if k in live else np.zeros_like(gr, bool)
+      assert diff[solid].max(initial=0.0) < 2e-6, (k, diff[solid].max())
+      assert diff.max() <= 2.0001e-4 + 1e-6, (k, diff.max())                      # a flipped sign: 2 * lr
+    else:
+      assert diff.max() <= 1e-4 * np.abs(ref["params"][k]).max() + 1e-7, (k, diff.max())
+
+
+def test_single_kernels_against_numpy():
+  """depthwise weight gradient, SAME max-pool backward, GRU backward through time and the vertex loss on their own."""
+  from voicepuppet_amd import _lib
+  import ctypes
+  L = _lib.lib()
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  rng = np.random.default_rng(0)
+  b, h, w, c = 2, 9, 5, 8
+  x = rng.normal(size=(b, h, w, c)).astype(np.float32)
+  dy = rng.normal(size=(b, h, w, c)).astype(np.float32)
+  xt, dyt = torch.tensor(x, device="cuda"), torch.tensor(dy, device="cuda")
+  dw = torch.empty(21, c, device="cuda")
+  ws = torch.empty(L.vp_dwconv7x3_wgrad_workspace_bytes(b, w, c), dtype=torch.uint8, device="cuda")
+  _lib.check(L.vp_dwconv7x3_wgrad(P(xt), P(dyt), P(dw), b, h, w, c, P(ws), st))
+  xp = np.pad(x.astype(np.float64), ((0, 0), (3, 3), (1, 1), (0, 0)))
+  ref = np.stack([(xp[:, kh:kh + h, kw:kw + w, :] * dy).sum((0, 1, 2)) for kh in range(7) for kw in range(3)])
+  assert gu.rel_l2(dw.cpu().numpy(), ref) < 1e-5
+  # max-pool backward: overlapping 2x2 stride (1,2) windows with SAME padding, and the 5x3 / (5,3) pool
+  for (hh, ww, k, s) in ((7, 5, (2, 2), (1, 2)), (10, 3, (5, 3), (5, 3))):
+    xx = rng.normal(size=(b, hh, ww, c)).astype(np.float32)
+    xg = torch.tensor(xx, dtype=torch.float64, requires_grad=True)
+    from oracle.bfmnet_train_torch import _pool
+    yy = _pool(xg.permute(0, 3, 1, 2), k, s)
+    gy = rng.normal(size=tuple(yy.shape)).astype(np.float32)
+    yy.backward(torch.tensor(gy, dtype=torch.float64))
+    dx = torch.empty(b, hh, ww, c, device="cuda")
+    xd, gd = torch.tensor(xx, device="cuda"), torch.tensor(np.ascontiguousarray(gy.transpose(0, 2, 3, 1)), device="cuda")
+    _lib.check(L.vp_maxpool_hw_bwd(P(xd), P(gd), P(dx), b, hh, ww, c, k[0], k[1], s[0], s[1], st))
+    torch.cuda.synchronize()
+    assert np.allclose(dx.cpu().numpy(), xg.grad.numpy(), atol=1e-6)

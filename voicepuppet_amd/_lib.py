@@ -104,6 +104,22 @@ _SIGNATURES = {
     "vp_render_colors_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "vp_render_colors": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _P, _P]),
+    "vp_bn_train_workspace_bytes": (ctypes.c_size_t, [ctypes.c_size_t, ctypes.c_int]),
+    "vp_bn_train_fwd": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.c_int, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "vp_bn_train_bwd": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
+    "vp_affine_act_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_act_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_int, _P, _P]),
+    "vp_dwconv7x3_raw": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "vp_dwconv7x3_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vp_dwconv7x3_wgrad": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_maxpool_hw_bwd": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 8 + [_P]),
+    "vp_stem_im2col": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "vp_gru_train_fwd": (ctypes.c_int, [_P] * 10 + [ctypes.c_int, ctypes.c_int, _P]),
+    "vp_gru_train_bwd": (ctypes.c_int, [_P] * 10 + [ctypes.c_int, ctypes.c_int, _P]),
+    "vp_vertex_loss_partials": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "vp_bfm_vertex_loss": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
+    "vp_sumsq_partials": (ctypes.c_int, [ctypes.c_size_t]),
+    "vp_sumsq": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P]),
     "vp_bn_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P]),
 }
 

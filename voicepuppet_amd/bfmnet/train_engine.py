@@ -1,0 +1,364 @@
+"""BFMNet.build_train_op on the device (reference: voicepuppet/bfmnet/bfmnet.py:215-323 over tinynet.py:7-212).
+
+One `train_step` = training-mode forward (batch-statistics batch_norm, dropout masks), the vertex-space loss of add_cost_function
+plus the l2 regulariser, the full backward pass, clip_by_global_norm and one tf.train.AdamOptimizer update, plus the moving-average
+update of every batch_norm.  Division of labour: everything that is a plain matrix product (1x1 convolutions and dense layers on
+[pixels, channels] matrices, the GRU's input / recurrent weight gradients, the [B*T, 64] x [64, 3n] face-shape products) is a
+rocBLAS GEMM through torch.mm; everything else - batch-norm statistics and backward, activations and dropout, the depthwise 7x3
+convolution with its two gradients, SAME max-pools, the im2col of the stem, the GRU recurrence forward and backward through time, the
+loss with its gradient, the sums of squares, Adam - is a hand-written HIP kernel of libvp_hip.so (csrc/bfm_train.hip,
+audio_kernels.hip, pointwise.hip).  No CPU fallback: the constructor raises without a GPU.
+
+Layouts: activations NHWC float32 viewed as [pixels, channels]; parameters live in ONE flat float32 arena (trainable variables first,
+moving statistics behind them) in the order of oracle/audio_ref.bfmnet_manifest() = the TF variable order, so the Adam slots and the
+gradient arena are flat too."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..audio import bfmnet_manifest
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_RELU6 = 0, 1, 2, 5
+BN_EPS, BN_DECAY, L2_SCALE = 1e-3, 0.999, 1e-4
+_P = ctypes.c_void_p
+
+# (scope, out_channels, expansion, pool_after)   tinynet.py:172-203
+BLOCKS = [("block1_0", 64, 1, False), ("block2_0", 64, 6, True), ("block2_1", 64, 6, False), ("block3_0", 128, 6, True),
+          ("block3_1", 128, 6, False), ("block3_2", 128, 6, False), ("block4_0", 192, 6, True), ("block4_1", 192, 6, False),
+          ("block4_2", 192, 6, False), ("block4_3", 192, 6, False), ("block5_0", 256, 6, False), ("block5_1", 256, 6, False),
+          ("block5_2", 256, 6, False), ("block6_0", 256, 6, True), ("block6_1", 256, 6, False), ("block6_2", 256, 6, False),
+          ("block7_0", 256, 6, False)]
+PREFIX = "mfcc_encoder/MfccNet/"
+GRU = "rnn_module/rnn/multi_rnn_cell/cell_0/gru_cell/"
+
+
+def _ptr(t):
+  return _P(t.data_ptr()) if t is not None else _P(0)
+
+
+def _stream():
+  return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def trainable(name):
+  return not (name.endswith("moving_mean") or name.endswith("moving_variance"))
+
+
+def regularised(name):
+  return "MfccNet" in name and (name.endswith("/kernel") or name.endswith("depthwise_weights"))
+
+
+class BFMNetTrainEngine:
+  def __init__(self, batch, frames, model, lr=1e-4, max_grad_norm=50.0, num_mel_bins=80):
+    """model: dict with exBase [3n,64] and vmask [3n] (the mouth-weighted vertex mask of bfmnet.py:131-134); idBase / meanshape cancel in
+    every term of the loss (both face shapes share the identity coefficients) and are not needed on the device."""
+    if not torch.cuda.is_available():
+      raise RuntimeError("BFMNetTrainEngine needs an MI355X (no CPU fallback)")
+    self.L = _lib.lib()
+    self.B, self.T, self.W0 = batch, frames, num_mel_bins
+    self.lr, self.clip = lr, max_grad_norm
+    dev = torch.device("cuda", torch.cuda.current_device())
+    self.dev = dev
+    man = [(n, s) for n, _, s in bfmnet_manifest()]
+    order = [(n, s) for n, s in man if trainable(n)] + [(n, s) for n, s in man if not trainable(n)]
+    self.ntrain = sum(int(np.prod(s)) for n, s in order if trainable(n))
+    total = sum(int(np.prod(s)) for n, s in order)
+    self.arena = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.grads = torch.zeros(self.ntrain, dtype=torch.float32, device=dev)
+    self.m = torch.zeros(self.ntrain, dtype=torch.float32, device=dev)
+    self.v = torch.zeros(self.ntrain, dtype=torch.float32, device=dev)
+    self.p, self.g, self.shapes = {}, {}, {}
+    off = 0
+    for n, s in order:
+      k = int(np.prod(s))
+      self.p[n] = self.arena[off:off + k].view(s)
+      if trainable(n):
+        self.g[n] = self.grads[off:off + k].view(s)
+      self.shapes[n] = s
+      off += k
+    self.step_t = 0
+    self.exbase = torch.tensor(np.asarray(model["exBase"], dtype=np.float32), device=dev).contiguous()       # [3n, 64]
+    self.vmask = torch.tensor(np.asarray(model["vmask"], dtype=np.float32).reshape(-1), device=dev).contiguous()
+    self.J = self.exbase.shape[0]
+    self.ears_scale = torch.tensor([-2.0, -2.0, -2.0, -4.0], device=dev)
+    self._ws = {}
+
+  # ---- parameters -----------------------------------------------------------------------------------------------------------
+  def load_params(self, params):
+    for n, t in self.p.items():
+      if n in params:
+        t.copy_(torch.tensor(np.asarray(params[n], dtype=np.float32).reshape(self.shapes[n]), device=self.dev))
+
+  def get_params(self):
+    return {n: t.detach().cpu().numpy().copy() for n, t in self.p.items()}
+
+  def get_grads(self):
+    return {n: t.detach().cpu().numpy().copy() for n, t in self.g.items()}
+
+  # ---- kernel wrappers ------------------------------------------------------------------------------------------------------
+  def _work(self, key, nbytes):
+    w = self._ws.get(key)
+    if w is None or w.numel() < nbytes:
+      w = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
+      self._ws[key] = w
+    return w
+
+  def _bn_fwd(self, y, beta):
+    P, C = y.shape
+    mean, var, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=self.dev) for _ in range(5))
+    ws = self._work("bn", self.L.vp_bn_train_workspace_bytes(P, C))
+    _lib.check(self.L.vp_bn_train_fwd(_ptr(y), P, C, _ptr(beta), BN_EPS, _ptr(mean), _ptr(var), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(ws),
+                                      _stream()), "vp_bn_train_fwd")
+    return mean, var, rstd, scale, shift
+
+  def _bn_bwd(self, y, dz, mean, rstd, dbeta):
+    P, C = y.shape
+    dx = torch.empty_like(y)
+    ws = self._work("bn", self.L.vp_bn_train_workspace_bytes(P, C))
+    _lib.check(self.L.vp_bn_train_bwd(_ptr(y), _ptr(dz), P, C, _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dbeta), _ptr(ws), _stream()), "vp_bn_train_bwd")
+    return dx
+
+  def _act(self, x, scale, shift, act, mask=None):
+    P, C = x.shape
+    y = torch.empty_like(x)
+    _lib.check(self.L.vp_affine_act_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(mask), P, C, act, _ptr(y), _stream()), "vp_affine_act_fwd")
+    return y
+
+  def _act_bwd(self, dy, ya, act, mask=None):
+    dx = torch.empty_like(dy)
+    _lib.check(self.L.vp_act_bwd(_ptr(dy), _ptr(ya), _ptr(mask), dy.numel(), act, _ptr(dx), _stream()), "vp_act_bwd")
+    return dx
+
+  def _dw(self, x2d, w21, H, W):
+    C = x2d.shape[1]
+    y = torch.empty_like(x2d)
+    _lib.check(self.L.vp_dwconv7x3_raw(_ptr(x2d), _ptr(w21), _ptr(y), self.B, H, W, C, _stream()), "vp_dwconv7x3_raw")
+    return y
+
+  def _dw_wgrad(self, x2d, dy2d, H, W):
+    C = x2d.shape[1]
+    dw = torch.empty(21, C, dtype=torch.float32, device=self.dev)
+    ws = self._work("dw", self.L.vp_dwconv7x3_wgrad_workspace_bytes(self.B, W, C))
+    _lib.check(self.L.vp_dwconv7x3_wgrad(_ptr(x2d), _ptr(dy2d), _ptr(dw), self.B, H, W, C, _ptr(ws), _stream()), "vp_dwconv7x3_wgrad")
+    return dw
+
+  def _pool(self, x2d, H, W, k, s):
+    C = x2d.shape[1]
+    Ho, Wo = -(-H // s[0]), -(-W // s[1])
+    y = torch.empty(self.B * Ho * Wo, C, dtype=torch.float32, device=self.dev)
+    _lib.check(self.L.vp_maxpool_hw(_ptr(x2d), _ptr(y), self.B, H, W, C, k[0], k[1], s[0], s[1], _stream()), "vp_maxpool_hw")
+    return y, Ho, Wo
+
+  def _pool_bwd(self, x2d, dy2d, H, W, k, s):
+    C = x2d.shape[1]
+    dx = torch.empty_like(x2d)
+    _lib.check(self.L.vp_maxpool_hw_bwd(_ptr(x2d), _ptr(dy2d), _ptr(dx), self.B, H, W, C, k[0], k[1], s[0], s[1], _stream()), "vp_maxpool_hw_bwd")
+    return dx
+
+  def _sumsq(self, x):
+    n = self.L.vp_sumsq_partials(x.numel())
+    part = torch.empty(n, dtype=torch.float64, device=self.dev)
+    _lib.check(self.L.vp_sumsq(_ptr(x), x.numel(), _ptr(part), _stream()), "vp_sumsq")
+    return part.sum()
+
+  # ---- conv + batch-norm + activation, forward / backward -----------------------------------------------------------------------
+  def _cba_fwd(self, x, kernel, bn_scope, act, tape):
+    """x [P, cin] @ kernel [cin, cout] -> batch_norm -> act.  tape gets what the backward needs."""
+    y = torch.mm(x, kernel)
+    mean, var, rstd, scale, shift = self._bn_fwd(y, self.p[bn_scope + "/BatchNorm/beta"])
+    a = self._act(y, scale, shift, act)
+    tape.append(("cba", x, kernel, y, mean, var, rstd, a, act, bn_scope))
+    return a
+
+  def _bn_act_bwd(self, da, y, mean, rstd, a, act, bn_scope):
+    dz = da if act == ACT_NONE else self._act_bwd(da, a, act)
+    return self._bn_bwd(y, dz, mean, rstd, self.g[bn_scope + "/BatchNorm/beta"])
+
+  def _moving(self, bn_scope, mean, var, n):
+    self.p[bn_scope + "/BatchNorm/moving_mean"].mul_(BN_DECAY).add_(mean, alpha=1 - BN_DECAY)
+    self.p[bn_scope + "/BatchNorm/moving_variance"].mul_(BN_DECAY).add_(var, alpha=(1 - BN_DECAY) * n / max(n - 1, 1))   # fused kernel: unbiased
+
+  # ---- the step -------------------------------------------------------------------------------------------------------------
+  def train_step(self, ears, mfccs, bfm_coeffs, seq_len, masks=None, apply=True):
+    """ears [B,T,1], mfccs [B,5T,80], bfm_coeffs [B,T,>=144] (device float32 tensors); seq_len: list / int32 tensor [B];
+    masks: optional dict 'enc' [B,T,256], 'rnn' [B,T,256], 'd0' [B,T,128], 'd1' [B,T,64] with entries 0 or 1/keep_prob (dropout draws).
+    Returns dict(loss, loss_data, global_norm) of python floats.  apply=False: gradients only (self.g), no update."""
+    B, T, L, p, g = self.B, self.T, self.L, self.p, self.g
+    masks = masks or {}
+    H, W = 5 * T, self.W0
+    seq = torch.as_tensor(seq_len, dtype=torch.int32, device=self.dev).contiguous()
+    mk = lambda k, c: (masks[k].reshape(B * T, c).contiguous() if masks.get(k) is not None else None)
+    tape = []
+    # stem: 9x5 stride (1,2) as im2col + GEMM
+    Wo = (W + 1) // 2
+    col = torch.empty(B * H * Wo, 48, dtype=torch.float32, device=self.dev)
+    _lib.check(L.vp_stem_im2col(_ptr(mfccs.contiguous()), _ptr(col), B, H, W, _stream()), "vp_stem_im2col")
+    s0 = PREFIX + "block0_0/conv2d"
+    k0 = torch.zeros(48, 32, dtype=torch.float32, device=self.dev)
+    k0[:45] = p[s0 + "/conv2d/kernel"].reshape(45, 32)
+    net = self._cba_fwd(col, k0, s0, ACT_RELU, tape)
+    W = Wo
+    for scope, cout, exp, pool in BLOCKS:
+      b = PREFIX + scope
+      cin = net.shape[1]
+      inp = net
+      a = self._cba_fwd(inp, p[b + "/expansion_1x1_conv2d/conv2d/kernel"].reshape(cin, cin * exp), b + "/expansion_1x1_conv2d", ACT_RELU6, tape)
+      wd = p[b + "/depthwise_conv2d/SeparableConv2d/depthwise_weights"].reshape(21, cin * exp)
+      yd = self._dw(a, wd, H, W)
+      mean, var, rstd, scale, shift = self._bn_fwd(yd, p[b + "/depthwise_conv2d/BatchNorm/beta"])
+      ad = self._act(yd, scale, shift, ACT_RELU6)
+      tape.append(("dw", a, wd, yd, mean, var, rstd, ad, b, H, W))
+      out = self._cba_fwd(ad, p[b + "/projection_1x1_conv2d/conv2d/kernel"].reshape(cin * exp, cout), b + "/projection_1x1_conv2d", ACT_NONE, tape)
+      if cout != cin:
+        sc = self._cba_fwd(inp, p[b + "/1x1_conv2d/conv2d/kernel"].reshape(cin, cout), b + "/1x1_conv2d", ACT_NONE, tape)
+        tape.append(("add_sc",))
+        net = out + sc
+      else:
+        tape.append(("add_id",))
+        net = out + inp
+      if pool:
+        pooled, Ho, Wn = self._pool(net, H, W, (2, 2), (1, 2))
+        tape.append(("pool", net, H, W, (2, 2), (1, 2)))
+        net, W = pooled, Wn
+    s8 = PREFIX + "block8_0/conv2d"
+    feat = self._cba_fwd(net, p[s8 + "/conv2d/kernel"].reshape(256, 256), s8, ACT_RELU, tape)
+    enc_in, Ho, Wn = self._pool(feat, H, W, (5, 3), (5, 3))
+    assert Ho == T and Wn == 1, (Ho, Wn)
+    tape.append(("pool", feat, H, W, (5, 3), (5, 3)))
+
+    def dense(x, wname, bname, act, mask):
+      z = torch.addmm(p[bname], x, p[wname])
+      y = z if (act == ACT_NONE and mask is None) else self._act(z, None, None, act, mask)
+      tape.append(("dense", x, wname, bname, y, act, mask))
+      return y
+    e = dense(enc_in, "mfcc_encoder/dense/kernel", "mfcc_encoder/dense/bias", ACT_LRELU, mk("enc", 256))
+    c1 = dense(e, "rnn_module/dense/kernel", "rnn_module/dense/bias", ACT_LRELU, None)
+    wg, wc = p[GRU + "gates/kernel"], p[GRU + "candidate/kernel"]
+    xg = torch.addmm(p[GRU + "gates/bias"], c1, wg[:256])
+    xc = torch.addmm(p[GRU + "candidate/bias"], c1, wc[:256])
+    whg, whc = wg[256:].contiguous(), wc[256:].contiguous()
+    rnn, sr, su, scand, shp = (torch.empty(B * T, 256, dtype=torch.float32, device=self.dev) for _ in range(5))
+    _lib.check(L.vp_gru_train_fwd(_ptr(xg), _ptr(xc), _ptr(whg), _ptr(whc), _ptr(seq), _ptr(rnn), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), B, T,
+                                  _stream()), "vp_gru_train_fwd")
+    mr = mk("rnn", 256)
+    rnn_m = rnn if mr is None else self._act(rnn, None, None, ACT_NONE, mr)
+    d0 = dense(rnn_m, "bfm_coeff_decoder/dense/kernel", "bfm_coeff_decoder/dense/bias", ACT_LRELU, mk("d0", 128))
+    d1 = dense(d0, "bfm_coeff_decoder/dense_1/kernel", "bfm_coeff_decoder/dense_1/bias", ACT_LRELU, mk("d1", 64))
+    o = dense(d1, "bfm_coeff_decoder/dense_2/kernel", "bfm_coeff_decoder/dense_2/bias", ACT_NONE, None)
+    o = o.clone()
+    o[:, 16:20] += (ears.reshape(B * T, 1) * self.ears_scale)                       # + tf.pad(ears * [-2,-2,-2,-4], [16, 44])
+    self.last_out = o.view(B, T, 64)
+
+    # ---- add_cost_function: both face shapes share the identity coefficients, so their difference is exBase . (ex_true - ex_pred)
+    delta = bfm_coeffs.reshape(B * T, -1)[:, 80:144] - o
+    D = torch.mm(delta, self.exbase.t())                                             # [B*T, 3n]
+    gD = torch.empty_like(D)
+    npart = L.vp_vertex_loss_partials(B, self.J)
+    part = torch.empty(npart, dtype=torch.float64, device=self.dev)
+    _lib.check(L.vp_bfm_vertex_loss(_ptr(D), _ptr(self.vmask), _ptr(seq), B, T, self.J, _ptr(gD), _ptr(part), _stream()), "vp_bfm_vertex_loss")
+    loss_data = part.sum()
+    do = -torch.mm(gD, self.exbase)                                                  # d loss / d o  [B*T, 64]
+
+    # ---- backward ----------------------------------------------------------------------------------------------------------------
+    self.grads.zero_()
+
+    def dense_bwd(dy):
+      _, x, wname, bname, y, act, mask = tape.pop()
+      dz = dy if (act == ACT_NONE and mask is None) else self._act_bwd(dy, y, act, mask)
+      g[wname].copy_(torch.mm(x.t(), dz))
+      g[bname].copy_(dz.sum(0))
+      return torch.mm(dz, p[wname].t())
+    d = dense_bwd(do)
+    d = dense_bwd(d)
+    d = dense_bwd(d)                                                                 # d loss / d rnn_m
+    if mr is not None:
+      d = d * mr
+    dag, dac = torch.empty(B * T, 512, dtype=torch.float32, device=self.dev), torch.empty(B * T, 256, dtype=torch.float32, device=self.dev)
+    _lib.check(L.vp_gru_train_bwd(_ptr(d.contiguous()), _ptr(whg), _ptr(whc), _ptr(seq), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), _ptr(dag), _ptr(dac),
+                                  B, T, _stream()), "vp_gru_train_bwd")
+    g[GRU + "gates/kernel"][:256].copy_(torch.mm(c1.t(), dag))
+    g[GRU + "gates/kernel"][256:].copy_(torch.mm(shp.t(), dag))
+    g[GRU + "gates/bias"].copy_(dag.sum(0))
+    g[GRU + "candidate/kernel"][:256].copy_(torch.mm(c1.t(), dac))
+    g[GRU + "candidate/kernel"][256:].copy_(torch.mm((sr * shp).t(), dac))
+    g[GRU + "candidate/bias"].copy_(dac.sum(0))
+    d = torch.mm(dag, wg[:256].t()) + torch.mm(dac, wc[:256].t())                      # d loss / d c1
+    d = dense_bwd(d)
+    d = dense_bwd(d)                                                                 # d loss / d enc_in  [B*T, 256]
+
+    def cba_bwd(da):
+      _, x, kernel, y, mean, var, rstd, a, act, scope = tape.pop()
+      dy = self._bn_act_bwd(da, y, mean, rstd, a, act, scope)
+      if apply:
+        self._moving(scope, mean, var, y.shape[0])
+      return dy, x, kernel
+    while tape:
+      kind = tape[-1][0]
+      if kind == "pool":
+        _, x, h_, w_, k_, s_ = tape.pop()
+        d = self._pool_bwd(x, d, h_, w_, k_, s_)
+        H, W = h_, w_
+      elif kind in ("add_sc", "add_id"):
+        tape.pop()
+        dsum = d
+        sc_bwd = cba_bwd(dsum) if kind == "add_sc" else None                         # shortcut conv (its tape entry lies on top)
+        dyp, xp, kp = cba_bwd(dsum)                                                  # projection conv
+        self._store_kernel_grad(kp, torch.mm(xp.t(), dyp))
+        dad = torch.mm(dyp, kp.t())
+        _, a_in, wd, yd, mean, var, rstd, ad, b, h_, w_ = tape.pop()
+        dz = self._act_bwd(dad, ad, ACT_RELU6)
+        dyd = self._bn_bwd(yd, dz, mean, rstd, g[b + "/depthwise_conv2d/BatchNorm/beta"])
+        if apply:
+          self._moving(b + "/depthwise_conv2d", mean, var, yd.shape[0])
+        g[b + "/depthwise_conv2d/SeparableConv2d/depthwise_weights"].copy_(self._dw_wgrad(a_in, dyd, h_, w_).view(7, 3, -1, 1))
+        da = self._dw(dyd, wd.flip(0).contiguous(), h_, w_)
+        dye, xe, ke = cba_bwd(da)                                                    # expansion conv
+        self._store_kernel_grad(ke, torch.mm(xe.t(), dye))
+        dinp = torch.mm(dye, ke.t())
+        if kind == "add_sc":
+          dys, xs, ks = sc_bwd
+          self._store_kernel_grad(ks, torch.mm(xs.t(), dys))
+          dinp = dinp + torch.mm(dys, ks.t())
+        else:
+          dinp = dinp + dsum
+        d = dinp
+      elif kind == "cba":                                                            # block8_0 (1x1) or the stem
+        dy, x, kernel = cba_bwd(d)
+        if x.shape[1] == 48:                                                         # stem: no input gradient
+          g[PREFIX + "block0_0/conv2d/conv2d/kernel"].copy_(torch.mm(x.t(), dy)[:45].view(9, 5, 1, 32))
+          d = None
+        else:
+          self._store_kernel_grad(kernel, torch.mm(x.t(), dy))
+          d = torch.mm(dy, kernel.t())
+      else:
+        raise AssertionError(kind)
+
+    # ---- regulariser, clip_by_global_norm, Adam ----------------------------------------------------------------------------------------
+    reg = torch.zeros((), dtype=torch.float64, device=self.dev)
+    for n in p:
+      if regularised(n):
+        reg = reg + self._sumsq(p[n])
+        g[n].add_(p[n], alpha=L2_SCALE)
+    loss = loss_data + 0.5 * L2_SCALE * reg
+    gn = torch.sqrt(self._sumsq(self.grads))
+    scale = self.clip / torch.clamp(gn, min=self.clip)
+    self.grads.mul_(scale.to(torch.float32))
+    if apply:
+      self.step_t += 1
+      _lib.check(L.vp_adam_tf(_ptr(self.arena), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.ntrain, self.step_t, self.lr, 0.9, 0.999, 1e-8,
+                              _stream()), "vp_adam_tf")
+    return {"loss": float(loss), "loss_data": float(loss_data), "global_norm": float(gn)}
+
+  def _store_kernel_grad(self, kernel_view, dw):
+    """kernel_view is a reshaped view of one variable of the arena: find it by its storage offset."""
+    off = kernel_view.storage_offset()
+    name = self._by_offset().get(off)
+    self.g[name].copy_(dw.view(self.shapes[name]))
+
+  def _by_offset(self):
+    if not hasattr(self, "_off"):
+      self._off = {t.storage_offset(): n for n, t in self.p.items()}
+    return self._off

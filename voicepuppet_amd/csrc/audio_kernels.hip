@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void dwconv7x3_kernel(const T* __restrict__ x,
     float4 wv[21];
 #pragma unroll
     for (int k = 0; k < 21; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (size_t)k * C + c4);
-    const float4 bv = *reinterpret_cast<const float4*>(bias + c4);
+    // bias == nullptr: the raw convolution (training forward / backward-data, bfm_train.hip): no bias, no relu6
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[RH];
 #pragma unroll
     for (int r = 0; r < RH; ++r) acc[r] = bv;
@@ -128,8 +129,10 @@ __global__ __launch_bounds__(256) void dwconv7x3_kernel(const T* __restrict__ x,
     for (int r = 0; r < RH; ++r) {
       if (oh0 + r >= H) break;
       float4 a = acc[r];
-      a.x = fminf(fmaxf(a.x, 0.f), 6.f); a.y = fminf(fmaxf(a.y, 0.f), 6.f);
-      a.z = fminf(fmaxf(a.z, 0.f), 6.f); a.w = fminf(fmaxf(a.w, 0.f), 6.f);
+      if (bias) {
+        a.x = fminf(fmaxf(a.x, 0.f), 6.f); a.y = fminf(fmaxf(a.y, 0.f), 6.f);
+        a.z = fminf(fmaxf(a.z, 0.f), 6.f); a.w = fminf(fmaxf(a.w, 0.f), 6.f);
+      }
       st4<T>(y + (((size_t)b * H + oh0 + r) * W + ow) * C + c4, a);
     }
   }

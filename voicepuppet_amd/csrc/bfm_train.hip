@@ -1,0 +1,518 @@
+// Kernels of the BFMNet TRAINING step (voicepuppet/bfmnet/bfmnet.py:215-323 over tinynet.py:7-212), f32, NHWC with any
+// channel count that is a multiple of 4 (MfccNet's expanded widths 192 ... 1536 are not powers of two, which the batch-norm / weight-
+// gradient kernels of the PixReferNet executor assume).  Everything that is NOT a plain matrix product lives here:
+//   training-mode contrib batch_norm (no gamma) forward statistics and backward, relu / relu6 / leaky-relu forward + backward,
+//   depthwise 7x3 weight gradient (forward and backward-data reuse dwconv7x3_kernel with its raw flag), SAME max-pool backward,
+//   the 9x5 stem as im2col, the GRU recurrence forward (with saved gates) and backward through time, the vertex-space loss with
+//   its gradient, sums of squares (regulariser, global-norm clipping).
+// The matrix products themselves (1x1 convolutions, dense layers, GRU input / recurrent weight gradients, the [B*T,64] x [64,3n]
+// face-shape products) are plain GEMMs and go to rocBLAS through torch.mm in voicepuppet_amd/bfmnet/train_engine.py.
+#include <math.h>
+
+#include "audio_args.h"
+#include "errors.h"
+#include "vp_common.h"
+
+namespace vp {
+
+static inline int tblk(size_t work, int cap = 4096) {
+  size_t b = (work + 255) / 256;
+  if (b > (size_t)cap) b = cap;
+  return b < 1 ? 1 : (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel sums over the P rows of a [P, C] tensor.  MODE 0: sum x, sum x^2.  MODE 1: sum dz, sum dz * (x - mean) * rstd.
+// grid (nchunk, ceil(C / 64)); a block = 4 row lanes x 64 channels; f64 partials [nchunk][2][C]
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, size_t P, int C, double* __restrict__ partial) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const size_t per = (P + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
+  double s0 = 0, s1 = 0;
+  if (c < C) {
+    const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
+    for (size_t p = p0 + rl; p < p1; p += 4) {
+      const float v = x[p * C + c];
+      if (MODE == 0) { s0 += v; s1 += (double)v * v; }
+      else { const float d = dz[p * C + c]; s0 += d; s1 += (double)d * ((v - mu) * rs); }
+    }
+  }
+  __shared__ double sm[2][256];
+  sm[0][threadIdx.x] = s0; sm[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const int l = threadIdx.x;
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = sm[0][l] + sm[0][l + 64] + sm[0][l + 128] + sm[0][l + 192];
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = sm[1][l] + sm[1][l + 64] + sm[1][l + 128] + sm[1][l + 192];
+  }
+}
+
+// forward finalize: mean, biased variance, rstd = 1/sqrt(var + eps), scale = rstd, shift = beta - mean * rstd
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nchunk, size_t P, int C, const float* __restrict__ beta,
+                                                              float eps, float* mean, float* var, float* rstd, float* scale, float* shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0;
+  for (int k = 0; k < nchunk; ++k) { s0 += partial[((size_t)k * 2) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
+  const double m = s0 / (double)P;
+  double v = s1 / (double)P - m * m;
+  if (v < 0) v = 0;
+  const float r = (float)(1.0 / sqrt(v + (double)eps));
+  mean[c] = (float)m; var[c] = (float)v; rstd[c] = r; scale[c] = r; shift[c] = (float)((double)beta[c] - m * (double)r);
+}
+
+// backward finalize: c1 = mean(dz), c2 = mean(dz * xhat); dbeta = sum dz
+__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const double* __restrict__ partial, int nchunk, size_t P, int C, float* c1, float* c2,
+                                                               float* dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0;
+  for (int k = 0; k < nchunk; ++k) { s0 += partial[((size_t)k * 2) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
+  c1[c] = (float)(s0 / (double)P); c2[c] = (float)(s1 / (double)P); dbeta[c] = (float)s0;
+}
+
+// dx = rstd * (dz - c1 - xhat * c2)       (no gamma: tf.contrib batch_norm scale=False)
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ c1, const float* __restrict__ c2,
+                                                            size_t P, int C, float* __restrict__ dx) {
+  const int cq = C >> 2;
+  const size_t total = P * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % cq) * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(x + i * 4), dv = *reinterpret_cast<const float4*>(dz + i * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 a = *reinterpret_cast<const float4*>(c1 + c), b = *reinterpret_cast<const float4*>(c2 + c);
+    float4 o;
+    o.x = rs.x * (dv.x - a.x - (xv.x - mu.x) * rs.x * b.x); o.y = rs.y * (dv.y - a.y - (xv.y - mu.y) * rs.y * b.y);
+    o.z = rs.z * (dv.z - a.z - (xv.z - mu.z) * rs.z * b.z); o.w = rs.w * (dv.w - a.w - (xv.w - mu.w) * rs.w * b.w);
+    *reinterpret_cast<float4*>(dx + i * 4) = o;
+  }
+}
+
+// act: 0 none, 1 leaky-relu(0.2), 2 relu, 5 relu6 (vp::Act numbering)
+__device__ __forceinline__ float act_f(int act, float v) {
+  if (act == ACT_LRELU || act == ACT_LEAKY) return v >= 0.f ? v : 0.2f * v;
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+  return v;
+}
+// derivative as a function of the OUTPUT y = act(v)
+__device__ __forceinline__ float act_d(int act, float y) {
+  if (act == ACT_LRELU || act == ACT_LEAKY) return y >= 0.f ? 1.f : 0.2f;
+  if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == ACT_RELU6) return (y > 0.f && y < 6.f) ? 1.f : 0.f;
+  return 1.f;
+}
+
+// y = act(scale[c] * x + shift[c]) * mask   (scale / shift / mask optional)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mask, size_t P, int C, int act, float* __restrict__ y) {
+  const int cq = C >> 2;
+  const size_t total = P * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % cq) * 4;
+    float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    if (scale) {
+      const float4 s = *reinterpret_cast<const float4*>(scale + c), b = *reinterpret_cast<const float4*>(shift + c);
+      v.x = fmaf(s.x, v.x, b.x); v.y = fmaf(s.y, v.y, b.y); v.z = fmaf(s.z, v.z, b.z); v.w = fmaf(s.w, v.w, b.w);
+    }
+    v.x = act_f(act, v.x); v.y = act_f(act, v.y); v.z = act_f(act, v.z); v.w = act_f(act, v.w);
+    if (mask) { const float4 m = *reinterpret_cast<const float4*>(mask + i * 4); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
+    *reinterpret_cast<float4*>(y + i * 4) = v;
+  }
+}
+
+// dx = dy * mask * act'(y_pre_mask)   where ya = act output BEFORE the mask
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ya, const float* __restrict__ mask, size_t n4,
+                                                      int act, float* __restrict__ dx) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 d = *reinterpret_cast<const float4*>(dy + i * 4);
+    const float4 y = *reinterpret_cast<const float4*>(ya + i * 4);
+    if (mask) { const float4 m = *reinterpret_cast<const float4*>(mask + i * 4); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
+    d.x *= act_d(act, y.x); d.y *= act_d(act, y.y); d.z *= act_d(act, y.z); d.w *= act_d(act, y.w);
+    *reinterpret_cast<float4*>(dx + i * 4) = d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise 7x3 weight gradient: dW[kh*3+kw][c] = sum_{b,h,w} x[b, h+kh-3, w+kw-1, c] * dy[b,h,w,c]
+// grid (G, ceil(C/64)); block = 4 lanes x 64 channels; a lane walks NP (b, w) columns, sliding a 7 x 3 window of x down the column
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv7x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C,
+                                                              float* __restrict__ partial /*[G][21][C]*/) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float acc[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) acc[k] = 0.f;
+  const int ncol = B * W;
+  if (c < C) {
+    for (int col = blockIdx.x * 4 + rl; col < ncol; col += gridDim.x * 4) {
+      const int b = col / W, w = col - b * W;
+      const float* xb = x + ((size_t)b * H * W) * C + c;
+      const float* db = dy + ((size_t)b * H * W) * C + c;
+      float win[7][3];      // win[r][kw] = x[h + r - 3][w + kw - 1] for the current h
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) win[r][kw] = 0.f;
+      // rows h-3 .. h+3: prime rows 0..2 into win[4..6] (h = -1 state), then slide
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = w + kw - 1;
+          win[r + 4][kw] = (r < H && (unsigned)iw < (unsigned)W) ? xb[((size_t)r * W + iw) * C] : 0.f;
+        }
+      for (int h = 0; h < H; ++h) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) win[r][kw] = win[r + 1][kw];
+        const int ih = h + 3;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = w + kw - 1;
+          win[6][kw] = (ih < H && (unsigned)iw < (unsigned)W) ? xb[((size_t)ih * W + iw) * C] : 0.f;
+        }
+        const float d = db[((size_t)h * W + w) * C];
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[r * 3 + kw] = fmaf(win[r][kw], d, acc[r * 3 + kw]);
+      }
+    }
+  }
+  __shared__ float sm[4][64];
+  for (int k = 0; k < 21; ++k) {
+    __syncthreads();
+    sm[rl][threadIdx.x & 63] = acc[k];
+    __syncthreads();
+    if (rl == 0 && c < C) partial[((size_t)blockIdx.x * 21 + k) * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+  }
+}
+
+// out[i] = sum_g partial[g][i]
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ partial, int G, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += partial[(size_t)g * n + i];
+    out[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SAME max-pool backward (gather form): an input element collects dy of every window that contains it and whose FIRST maximum
+// (row-major window scan, as TF's MaxPoolGrad) it is
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_same_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B, int H,
+                                                               int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo) {
+  const int cq = C >> 2;
+  const size_t total = (size_t)B * H * W * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % cq) * 4;
+    size_t t = i / cq;
+    const int iw = (int)(t % W); t /= W;
+    const int ih = (int)(t % H);
+    const int b = (int)(t / H);
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    // windows (oh, ow) with oh*sh - pt <= ih < oh*sh - pt + kh
+    int oh0 = (ih + pt - kh + sh) / sh; if (oh0 < 0) oh0 = 0;      // ceil((ih + pt - kh + 1) / sh)
+    int oh1 = (ih + pt) / sh; if (oh1 > Ho - 1) oh1 = Ho - 1;
+    int ow0 = (iw + pl - kw + sw) / sw; if (ow0 < 0) ow0 = 0;
+    int ow1 = (iw + pl) / sw; if (ow1 > Wo - 1) ow1 = Wo - 1;
+    for (int oh = oh0; oh <= oh1; ++oh)
+      for (int ow = ow0; ow <= ow1; ++ow) {
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {-1, -1, -1, -1};
+        for (int a = 0; a < kh; ++a) {
+          const int yh = oh * sh + a - pt;
+          if ((unsigned)yh >= (unsigned)H) continue;
+          for (int bb = 0; bb < kw; ++bb) {
+            const int yw = ow * sw + bb - pl;
+            if ((unsigned)yw >= (unsigned)W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + yh) * W + yw) * C + c4);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            const int id = yh * W + yw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (vv[e] > best[e]) { best[e] = vv[e]; arg[e] = id; }
+          }
+        }
+        const float4 d = *reinterpret_cast<const float4*>(dy + (((size_t)b * Ho + oh) * Wo + ow) * C + c4);
+        const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (arg[e] == ih * W + iw) g[e] += dd[e];
+      }
+    *reinterpret_cast<float4*>(dx + i * 4) = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+
+// stem 9x5 stride (1,2) SAME on [B,H,W,1]: col[p][kh*5+kw] (48 columns, the last 3 zero), p = (b, oh, ow)
+__global__ __launch_bounds__(256) void im2col_9x5_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int Wo, int pt, int pl) {
+  const size_t total = (size_t)B * H * Wo * 48;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % 48);
+    size_t t = i / 48;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % H);
+    const int b = (int)(t / H);
+    float v = 0.f;
+    if (k < 45) {
+      const int ih = oh + k / 5 - pt, iw = ow * 2 + k % 5 - pl;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((size_t)b * H + ih) * W + iw];
+    }
+    col[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GRU (tf.contrib.rnn.GRUCell under dynamic_rnn, 256 units), training form.  One block per sequence, thread j = unit j.
+//   forward : saves r, u, c and h_prev per step (what the backward needs); out = h past-the-end zero, state frozen
+//   backward: d_ag [B,T,512] (gate pre-activations), d_ac [B,T,256] (candidate pre-activation) from d_out; the weight / input
+//             gradients are GEMMs over these (train_engine.py)
+// whg [256][512], whc [256][256]: recurrent halves of the kernels (row = h unit)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru_train_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ xc, const float* __restrict__ whg,
+                                                            const float* __restrict__ whc, const int* __restrict__ seq_len, float* __restrict__ out,
+                                                            float* __restrict__ sr, float* __restrict__ su, float* __restrict__ sc, float* __restrict__ shp,
+                                                            int T) {
+  __shared__ float h[256], rh[256];
+  const int b = blockIdx.x, j = threadIdx.x, n = seq_len[b];
+  h[j] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const size_t o = (size_t)b * T + t;
+    if (t >= n) { out[o * 256 + j] = 0.f; sr[o * 256 + j] = 0.f; su[o * 256 + j] = 0.f; sc[o * 256 + j] = 0.f; shp[o * 256 + j] = h[j]; continue; }
+    float ar = xg[o * 512 + j], au = xg[o * 512 + 256 + j];
+    for (int k = 0; k < 256; ++k) { const float hk = h[k]; ar = fmaf(hk, whg[(size_t)k * 512 + j], ar); au = fmaf(hk, whg[(size_t)k * 512 + 256 + j], au); }
+    const float r = 1.f / (1.f + expf(-ar)), u = 1.f / (1.f + expf(-au));
+    rh[j] = r * h[j];
+    __syncthreads();
+    float ac = xc[o * 256 + j];
+    for (int k = 0; k < 256; ++k) ac = fmaf(rh[k], whc[(size_t)k * 256 + j], ac);
+    const float c = tanhf(ac);
+    const float hp = h[j];
+    const float hn = u * hp + (1.f - u) * c;
+    sr[o * 256 + j] = r; su[o * 256 + j] = u; sc[o * 256 + j] = c; shp[o * 256 + j] = hp;
+    out[o * 256 + j] = hn;
+    __syncthreads();
+    h[j] = hn;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_train_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ whg, const float* __restrict__ whc,
+                                                            const int* __restrict__ seq_len, const float* __restrict__ sr, const float* __restrict__ su,
+                                                            const float* __restrict__ sc, const float* __restrict__ shp, float* __restrict__ dag,
+                                                            float* __restrict__ dac, int T) {
+  __shared__ float s_dag[512], s_dac[256];
+  const int b = blockIdx.x, j = threadIdx.x, n = seq_len[b];
+  float dh = 0.f;                                    // d loss / d h_t carried backwards (unit j)
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t o = (size_t)b * T + t;
+    if (t >= n) { dag[o * 512 + j] = 0.f; dag[o * 512 + 256 + j] = 0.f; dac[o * 256 + j] = 0.f; continue; }   // frozen state: dh passes through
+    const float r = sr[o * 256 + j], u = su[o * 256 + j], c = sc[o * 256 + j], hp = shp[o * 256 + j];
+    const float g = dout[o * 256 + j] + dh;
+    const float d_u = g * (hp - c), d_c = g * (1.f - u);
+    float dhp = g * u;
+    const float d_ac = d_c * (1.f - c * c);
+    s_dac[j] = d_ac;
+    __syncthreads();
+    float d_rh = 0.f;                                // d / d (r * h_prev)[j] = sum_m whc[j][m] * d_ac[m]
+    for (int m = 0; m < 256; ++m) d_rh = fmaf(whc[(size_t)j * 256 + m], s_dac[m], d_rh);
+    const float d_r = d_rh * hp;
+    dhp = fmaf(d_rh, r, dhp);
+    const float d_ar = d_r * r * (1.f - r), d_au = d_u * u * (1.f - u);
+    s_dag[j] = d_ar; s_dag[256 + j] = d_au;
+    __syncthreads();
+    for (int m = 0; m < 512; ++m) dhp = fmaf(whg[(size_t)j * 512 + m], s_dag[m], dhp);
+    dag[o * 512 + j] = d_ar; dag[o * 512 + 256 + j] = d_au; dac[o * 256 + j] = d_ac;
+    dh = dhp;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vertex-space loss (bfmnet.py:215-262) on D[b,t,j] = face_shape(true) - face_shape(pred) (a GEMM of the expression difference):
+//   loss = (1/B) sum_b [ sum_t fm[b,t] sum_j |D[b,t,j]| vm[j]  +  sum_{t<T-1} vd[b,t] sum_j |D[b,t+1,j] - D[b,t,j]| vm[j] ]
+// thread = (b, j) walks t; writes gD = d loss / d D and one f64 partial per block
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vertex_loss_kernel(const float* __restrict__ D, const float* __restrict__ vmask, const int* __restrict__ seq_len, int B,
+                                                          int T, int J, float* __restrict__ gD, double* __restrict__ partial) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double acc = 0;
+  if (i < (size_t)B * J) {
+    const int b = (int)(i / J), j = (int)(i - (size_t)b * J);
+    const int n = seq_len[b];
+    const float vm = vmask[j], inv = 1.f / (float)B;
+    const float* d = D + (size_t)b * T * J + j;
+    float* g = gD + (size_t)b * T * J + j;
+    float prev = 0.f, gprev = 0.f;                   // gprev: gradient already owed to D[t] by the difference (t-1, t)
+    for (int t = 0; t < T; ++t) {
+      const float v = d[(size_t)t * J];
+      float gt = gprev;
+      gprev = 0.f;
+      if (t < n) { acc += (double)(fabsf(v) * vm); gt += (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * vm * inv; }
+      if (t + 1 < T && t < n - 1) {                  // video term between t and t + 1
+        const float w = d[(size_t)(t + 1) * J] - v;
+        acc += (double)(fabsf(w) * vm);
+        const float s = (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f)) * vm * inv;
+        gt -= s; gprev = s;
+      }
+      g[(size_t)t * J] = gt;
+      prev = v;
+    }
+    (void)prev;
+  }
+  __shared__ double sm[256];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] / (double)B;
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, double* __restrict__ partial) {
+  double acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += (double)x[i] * x[i];
+  __shared__ double sm[256];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+}  // namespace vp
+
+using namespace vp;
+
+extern "C" {
+
+#define VP_NCHUNK(P) ((int)((P) < 4096 ? 1 : ((P) / 1024 > 512 ? 512 : (P) / 1024)))
+
+// workspace (bytes) of vp_bn_train_fwd / vp_bn_train_bwd for a [pixels, c] tensor
+size_t vp_bn_train_workspace_bytes(size_t pixels, int c) { return (size_t)VP_NCHUNK(pixels) * 2 * c * sizeof(double) + 2 * (size_t)c * sizeof(float) + 256; }
+
+// tf.contrib.layers.batch_norm(is_training=True, scale=False): batch statistics of x [pixels, c]; y = x * scale + shift normalises
+int vp_bn_train_fwd(const float* x, size_t pixels, int c, const float* beta, float eps, float* mean, float* var, float* rstd, float* scale,
+                    float* shift, void* workspace, void* stream) {
+  if (!x || !beta || !mean || !var || !rstd || !scale || !shift || !workspace || pixels < 1 || c < 4 || c % 4) { set_err("vp_bn_train_fwd: bad argument"); return VP_ERR_ARG; }
+  const int nch = VP_NCHUNK(pixels);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((chan_sums_kernel<0>), dim3(nch, (c + 63) / 64), dim3(256), 0, st, x, nullptr, nullptr, nullptr, pixels, c, (double*)workspace);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, st, (const double*)workspace, nch, pixels, c, beta, eps, mean, var, rstd, scale, shift);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// backward of the same: dz = d loss / d (normalised + beta) -> dx (may alias dz), dbeta
+int vp_bn_train_bwd(const float* x, const float* dz, size_t pixels, int c, const float* mean, const float* rstd, float* dx, float* dbeta,
+                    void* workspace, void* stream) {
+  if (!x || !dz || !mean || !rstd || !dx || !dbeta || !workspace || pixels < 1 || c < 4 || c % 4) { set_err("vp_bn_train_bwd: bad argument"); return VP_ERR_ARG; }
+  const int nch = VP_NCHUNK(pixels);
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)workspace;
+  float* c1 = (float*)((char*)workspace + (size_t)nch * 2 * c * sizeof(double));
+  float* c2 = c1 + c;
+  hipLaunchKernelGGL((chan_sums_kernel<1>), dim3(nch, (c + 63) / 64), dim3(256), 0, st, x, dz, mean, rstd, pixels, c, part);
+  hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((c + 255) / 256), dim3(256), 0, st, (const double*)part, nch, pixels, c, c1, c2, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(tblk(pixels * (c / 4))), dim3(256), 0, st, x, dz, mean, rstd, c1, c2, pixels, c, dx);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// y = act(scale[c] * x + shift[c]) * mask   (scale / shift and mask may be null); act: 0 none, 1 leaky-relu(0.2), 2 relu, 5 relu6
+int vp_affine_act_fwd(const float* x, const float* scale, const float* shift, const float* mask, size_t pixels, int c, int act, float* y, void* stream) {
+  if (!x || !y || (scale && !shift) || pixels < 1 || c < 4 || c % 4) { set_err("vp_affine_act_fwd: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(affine_act_kernel, dim3(tblk(pixels * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, scale, shift, mask, pixels, c, act, y);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// dx = dy * mask * act'(ya): ya = the activation's output before the mask (n elements, n % 4 == 0)
+int vp_act_bwd(const float* dy, const float* ya, const float* mask, size_t n, int act, float* dx, void* stream) {
+  if (!dy || !ya || !dx || n < 4 || n % 4) { set_err("vp_act_bwd: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(tblk(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, ya, mask, n / 4, act, dx);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// depthwise [7,3] stride 1 SAME without bias / activation (training forward; backward-data = the same call with the taps reversed)
+int vp_dwconv7x3_raw(const float* x, const float* w, float* y, int b, int h, int wd, int c, void* stream) {
+  if (!x || !w || !y || b < 1 || h < 1 || wd < 1 || c < 4 || c % 4) { set_err("vp_dwconv7x3_raw: bad argument"); return VP_ERR_ARG; }
+  VP_HIP_CHECK(launch_dwconv7x3(x, w, nullptr, y, 0, b, h, wd, c, (hipStream_t)stream));
+  return VP_OK;
+}
+
+size_t vp_dwconv7x3_wgrad_workspace_bytes(int b, int wd, int c) {
+  int g = (b * wd + 31) / 32; if (g < 1) g = 1; if (g > 256) g = 256;
+  return (size_t)g * 21 * c * sizeof(float);
+}
+// dw [21][c]
+int vp_dwconv7x3_wgrad(const float* x, const float* dy, float* dw, int b, int h, int wd, int c, void* workspace, void* stream) {
+  if (!x || !dy || !dw || !workspace || b < 1 || h < 1 || wd < 1 || c < 4) { set_err("vp_dwconv7x3_wgrad: bad argument"); return VP_ERR_ARG; }
+  int g = (b * wd + 31) / 32; if (g < 1) g = 1; if (g > 256) g = 256;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dwconv7x3_wgrad_kernel, dim3(g, (c + 63) / 64), dim3(256), 0, st, x, dy, b, h, wd, c, (float*)workspace);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(tblk((size_t)21 * c)), dim3(256), 0, st, (const float*)workspace, g, (size_t)21 * c, dw);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// backward of vp_maxpool_hw (tf.layers.max_pooling2d 'same')
+int vp_maxpool_hw_bwd(const float* x, const float* dy, float* dx, int b, int h, int w, int c, int kh, int kw, int sh, int sw, void* stream) {
+  if (!x || !dy || !dx || b < 1 || c < 4 || c % 4 || kh < 1 || kw < 1 || sh < 1 || sw < 1) { set_err("vp_maxpool_hw_bwd: bad argument"); return VP_ERR_ARG; }
+  const int ho = (h + sh - 1) / sh, wo = (w + sw - 1) / sw;
+  int th = (ho - 1) * sh + kh - h; if (th < 0) th = 0;
+  int tw = (wo - 1) * sw + kw - w; if (tw < 0) tw = 0;
+  hipLaunchKernelGGL(maxpool_same_bwd_kernel, dim3(tblk((size_t)b * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, dy, dx, b, h, w, c, kh, kw, sh,
+                     sw, th / 2, tw / 2, ho, wo);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// col [b*h*wo][48] of the 9x5 stride-(1,2) SAME stem on x [b,h,w,1] (columns 45..47 zero)
+int vp_stem_im2col(const float* x, float* col, int b, int h, int w, void* stream) {
+  if (!x || !col || b < 1 || h < 1 || w < 2) { set_err("vp_stem_im2col: bad argument"); return VP_ERR_ARG; }
+  const int wo = (w + 1) / 2;
+  int tw = (wo - 1) * 2 + 5 - w; if (tw < 0) tw = 0;
+  hipLaunchKernelGGL(im2col_9x5_kernel, dim3(tblk((size_t)b * h * wo * 48)), dim3(256), 0, (hipStream_t)stream, x, col, b, h, w, wo, 4, tw / 2);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+int vp_gru_train_fwd(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, float* r, float* u, float* c,
+                     float* hprev, int b, int t, void* stream) {
+  if (!xg || !xc || !whg || !whc || !seq_len || !out || !r || !u || !c || !hprev || b < 1 || t < 1) { set_err("vp_gru_train_fwd: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, xg, xc, whg, whc, seq_len, out, r, u, c, hprev, t);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+int vp_gru_train_bwd(const float* dout, const float* whg, const float* whc, const int* seq_len, const float* r, const float* u, const float* c,
+                     const float* hprev, float* dag, float* dac, int b, int t, void* stream) {
+  if (!dout || !whg || !whc || !seq_len || !r || !u || !c || !hprev || !dag || !dac || b < 1 || t < 1) { set_err("vp_gru_train_bwd: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(gru_train_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, dout, whg, whc, seq_len, r, u, c, hprev, dag, dac, t);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// number of f64 partials vp_bfm_vertex_loss / vp_sumsq write (sum them on the host or with one more reduction)
+int vp_vertex_loss_partials(int b, int j) { return (int)(((size_t)b * j + 255) / 256); }
+int vp_bfm_vertex_loss(const float* d, const float* vmask, const int* seq_len, int b, int t, int j, float* gd, double* partial, void* stream) {
+  if (!d || !vmask || !seq_len || !gd || !partial || b < 1 || t < 1 || j < 1) { set_err("vp_bfm_vertex_loss: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(vertex_loss_kernel, dim3(vp_vertex_loss_partials(b, j)), dim3(256), 0, (hipStream_t)stream, d, vmask, seq_len, b, t, j, gd, partial);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+int vp_sumsq_partials(size_t n) { return tblk(n, 1024); }
+int vp_sumsq(const float* x, size_t n, double* partial, void* stream) {
+  if (!x || !partial || n < 1) { set_err("vp_sumsq: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(sumsq_kernel, dim3(tblk(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, partial);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+}  // extern "C"
