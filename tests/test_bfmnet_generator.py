@@ -1,0 +1,93 @@
+"""CPU checks of BFMNetDataGenerator's host half (generator/generator.py:377-481 of the reference): the silence trim, the 24-frame slicing
+with its PCM window arithmetic, the list/file formats.  The log-mel step (process_data) runs on the device and is covered by -m gpu."""
+import os
+
+import numpy as np
+
+from oracle import audio_ref as ar
+from voicepuppet_amd.generator.generator import BFMNetDataGenerator, first_nonsilent_sample
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "config", "params.yml")
+
+
+def _frame_db(y, frame_length=2048, hop=512):
+  """Literal per-frame loop of the published librosa.effects.split pre-processing (reflect-padded centred frames)."""
+  yp = np.pad(y, frame_length // 2, mode="reflect")
+  n = 1 + (len(yp) - frame_length) // hop
+  mse = np.array([np.mean(yp[i * hop:i * hop + frame_length].astype(np.float64) ** 2) for i in range(n)])
+  return 10 * np.log10(np.maximum(1e-10, mse)) - 10 * np.log10(np.maximum(1e-10, mse.max()))
+
+
+def test_first_nonsilent_sample_matches_frame_loop():
+  rng = np.random.default_rng(0)
+  sr = 16000
+  for lead in (0, 3000, 9000, 20000):
+    t = np.arange(sr) / sr
+    y = np.concatenate([1e-4 * rng.normal(size=lead), 0.4 * np.sin(2 * np.pi * 220 * t) * np.minimum(1, t * 8)]).astype(np.float32)
+    db = _frame_db(y)
+    want = min(int(np.flatnonzero(db > -20)[0]) * 512, len(y))
+    got = first_nonsilent_sample(y, top_db=20)
+    assert got == want
+    assert got <= lead + 4000 and (lead == 0 or got > lead - 2048)
+  assert first_nonsilent_sample(np.zeros(100, np.float32)) == 0
+
+
+def _write_clip(folder, frames, lead_silence, rng):
+  from scipy.io import wavfile
+  os.makedirs(folder)
+  sr = 16000
+  n = int(frames * sr / 25)
+  t = np.arange(n) / sr
+  y = 0.4 * np.sin(2 * np.pi * 200 * t)
+  y[:lead_silence] = 0
+  wavfile.write(os.path.join(folder, "audio.wav"), sr, (y * 32767).astype(np.int16))
+  coeff = rng.normal(0, 1, (frames, 257)).astype(np.float32)
+  np.savetxt(os.path.join(folder, "bfmcoeff.txt"), coeff, delimiter=",", fmt="%.6f")
+  lm = rng.uniform(10, 200, (frames, 212)).astype(np.float32)
+  np.savetxt(os.path.join(folder, "landmark.txt"), lm, delimiter=",", fmt="%.4f")
+  return coeff, lm
+
+
+def test_slices_of_a_clip_folder(tmp_path):
+  rng = np.random.default_rng(1)
+  frames, lead = 80, 16000 * 12 // 25 + 100           # a little over 12 video frames of leading silence
+  coeff, lm = _write_clip(str(tmp_path / "clipA"), frames, lead, rng)
+  _write_clip(str(tmp_path / "short"), 10, 0, rng)      # fewer than 24 frames: yields nothing
+  lst = tmp_path / "train.txt"
+  lst.write_text("%s|%d\n%s|%d\n%s|5\n" % (tmp_path / "clipA", frames, tmp_path / "short", 10, tmp_path / "missing"))
+  gen = BFMNetDataGenerator(CFG)
+  p = gen.params
+  p.dataset_path = str(lst)
+  p.amd = dict(p.amd, synthetic_data=False)
+  gen.set_params(p)
+  got = list(gen.iterator())
+  from voicepuppet_amd.generator.loader import WavLoader
+  pcm = WavLoader(sr=16000).get_data(str(tmp_path / "clipA" / "audio.wav"))
+  start = first_nonsilent_sample(pcm)
+  skip = int(start // 640)
+  assert 11 <= skip <= 13
+  assert len(got) == (frames - skip) // 24
+  ear_all = 1 - gen.ear_compute(lm)
+  for i, (c, e, w, n) in enumerate(got):
+    assert c.shape == (24, 257) and e.shape == (24, 1) and n == 24
+    # identity coefficients: the mean over the trimmed clip, the same on every frame; the rest untouched
+    assert np.allclose(c[:, :80], coeff[skip:, :80].mean(0, keepdims=True), atol=1e-5)
+    assert np.allclose(c[:, 80:], coeff[skip + 24 * i: skip + 24 * (i + 1), 80:], atol=1e-5)
+    # reference quirk (generator.py:471-472): `ear` is sliced from the un-trimmed start
+    assert np.allclose(e, ear_all[24 * i:24 * (i + 1)], atol=1e-5)
+    # the PCM window gives exactly 24 * 5 log-mel rows and starts 24 * i video frames after the trim point
+    assert w.shape == (128 * (24 * 5 - 1) + 512,)
+    assert ar.extract_mfcc(w[None].astype(np.float64)).shape[1] == 120
+    seg = pcm[start + i * 24 * 640: start + i * 24 * 640 + w.shape[0]]
+    assert np.array_equal(w[:seg.shape[0]], seg) and not w[seg.shape[0]:].any()
+
+
+def test_synthetic_fallback_shapes():
+  gen = BFMNetDataGenerator(CFG)
+  p = gen.params
+  p.dataset_path = "/nonexistent/train.txt"
+  gen.set_params(p)
+  c, e, w, n = next(gen.iterator())
+  assert c.shape == (24, 257) and e.shape == (24, 1) and w.shape == (gen.pcm_length(24),) and n == 24
+  assert np.array_equal(c[:, :80], np.repeat(c[:1, :80], 24, 0))

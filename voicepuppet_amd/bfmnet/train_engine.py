@@ -92,6 +92,10 @@ class BFMNetTrainEngine:
       if n in params:
         t.copy_(torch.tensor(np.asarray(params[n], dtype=np.float32).reshape(self.shapes[n]), device=self.dev))
 
+  def trainables(self):
+    """[(name, shape)] in the order of the flat gradient / Adam buffers."""
+    return [(n, self.shapes[n]) for n in self.p if trainable(n)]
+
   def get_params(self):
     return {n: t.detach().cpu().numpy().copy() for n, t in self.p.items()}
 
@@ -252,15 +256,7 @@ class BFMNetTrainEngine:
     o[:, 16:20] += (ears.reshape(B * T, 1) * self.ears_scale)                       # + tf.pad(ears * [-2,-2,-2,-4], [16, 44])
     self.last_out = o.view(B, T, 64)
 
-    # ---- add_cost_function: both face shapes share the identity coefficients, so their difference is exBase . (ex_true - ex_pred)
-    delta = bfm_coeffs.reshape(B * T, -1)[:, 80:144] - o
-    D = torch.mm(delta, self.exbase.t())                                             # [B*T, 3n]
-    gD = torch.empty_like(D)
-    npart = L.vp_vertex_loss_partials(B, self.J)
-    part = torch.empty(npart, dtype=torch.float64, device=self.dev)
-    _lib.check(L.vp_bfm_vertex_loss(_ptr(D), _ptr(self.vmask), _ptr(seq), B, T, self.J, _ptr(gD), _ptr(part), _stream()), "vp_bfm_vertex_loss")
-    loss_data = part.sum()
-    do = -torch.mm(gD, self.exbase)                                                  # d loss / d o  [B*T, 64]
+    loss_data, do = self._vertex_loss(o, bfm_coeffs, seq)
 
     # ---- backward ----------------------------------------------------------------------------------------------------------------
     self.grads.zero_()
@@ -351,6 +347,44 @@ class BFMNetTrainEngine:
       _lib.check(L.vp_adam_tf(_ptr(self.arena), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.ntrain, self.step_t, self.lr, 0.9, 0.999, 1e-8,
                               _stream()), "vp_adam_tf")
     return {"loss": float(loss), "loss_data": float(loss_data), "global_norm": float(gn)}
+
+  def _vertex_loss(self, o, bfm_coeffs, seq):
+    """add_cost_function (bfmnet.py:229-271): both face shapes share the identity coefficients, so their difference is
+    exBase . (ex_true - ex_pred).  o [B*T,64] -> (data loss as a float64 device scalar, d loss / d o [B*T,64])."""
+    B, T, L = self.B, self.T, self.L
+    delta = bfm_coeffs.reshape(B * T, -1)[:, 80:144] - o
+    D = torch.mm(delta, self.exbase.t())                                             # [B*T, 3n]
+    gD = torch.empty_like(D)
+    npart = L.vp_vertex_loss_partials(B, self.J)
+    part = torch.empty(npart, dtype=torch.float64, device=self.dev)
+    _lib.check(L.vp_bfm_vertex_loss(_ptr(D), _ptr(self.vmask), _ptr(seq), B, T, self.J, _ptr(gD), _ptr(part), _stream()), "vp_bfm_vertex_loss")
+    return part.sum(), -torch.mm(gD, self.exbase)
+
+  def regulariser(self):
+    reg = torch.zeros((), dtype=torch.float64, device=self.dev)
+    for n in self.p:
+      if regularised(n):
+        reg = reg + self._sumsq(self.p[n])
+    return 0.5 * L2_SCALE * reg
+
+  def eval_loss(self, coeff, bfm_coeffs, seq_len):
+    """The Loss node of build_eval_op (bfmnet.py:273-289): the same cost on coefficients predicted in inference mode."""
+    seq = torch.as_tensor(seq_len, dtype=torch.int32, device=self.dev).contiguous()
+    o = coeff.to(self.dev, torch.float32).reshape(self.B * self.T, 64).contiguous()
+    ld, _ = self._vertex_loss(o, bfm_coeffs.to(self.dev, torch.float32), seq)
+    return float(ld + self.regulariser())
+
+  def draw_masks(self, drop_rate, inner_rate=0.25, generator=None):
+    """One draw of the four dropout masks: keep with probability 1-rate, kept entries scaled by 1/(1-rate).  `drop_rate` is
+    params.training['drop_rate'] and reaches only the tf.layers.dropout after the encoder's dense layer (bfmnet.py:199); RNNModule's
+    DropoutWrapper and BFMCoeffDecoder's two tf.nn.dropout keep their constructor default 0.25 (bfmnet.py:45,77,209).  The draws come
+    from torch's device generator, not TensorFlow's stream."""
+    def mk(c, rate):
+      if not rate:
+        return None
+      keep = 1.0 - float(rate)
+      return (torch.rand(self.B, self.T, c, device=self.dev, generator=generator) < keep).to(torch.float32) / keep
+    return {"enc": mk(256, drop_rate), "rnn": mk(256, inner_rate), "d0": mk(128, inner_rate), "d1": mk(64, inner_rate)}
 
   def _store_kernel_grad(self, kernel_view, dw):
     """kernel_view is a reshaped view of one variable of the arena: find it by its storage offset."""

@@ -12,8 +12,8 @@ import random
 import numpy as np
 
 from ..config.configure import YParams
-from ..runtime import Dataset
-from .loader import ImageLoader
+from ..runtime import Dataset, DatasetIterator, IteratorNext
+from .loader import BFMCoeffLoader, ImageLoader, LandmarkLoader, WavLoader
 
 logging.basicConfig(level=logging.INFO, format='%(asctime)s - %(name)s - %(levelname)s - %(message)s')
 logger = logging.getLogger(__name__)
@@ -79,6 +79,164 @@ class DataGenerator(object):
 
   def pose_compute(self, bfmcoeffs):
     return np.array([self.split_bfmcoeff(c)[3] for c in bfmcoeffs])
+
+
+def first_nonsilent_sample(pcm, top_db=20, frame_length=2048, hop_length=512):
+  """Start of the first interval librosa.effects.split(pcm, top_db) returns (generator.py:457-459).  librosa is a third-party
+  dependency the reference does not pin; this restates the published algorithm of the 0.7/0.8 releases contemporary with it: frame-wise
+  mean square over centred frames (reflect padding), in dB relative to the loudest frame (amin 1e-10); a frame is non-silent above
+  -top_db; frame index -> sample by * hop_length, clipped to the signal length."""
+  y = np.asarray(pcm, dtype=np.float32)
+  pad = frame_length // 2
+  yp = np.pad(y, (pad, pad), mode='reflect' if y.shape[0] > pad else 'constant')
+  n = 1 + (yp.shape[0] - frame_length) // hop_length
+  if n <= 0:
+    return 0
+  sq = np.concatenate([[0.0], np.cumsum(yp.astype(np.float64) ** 2)])
+  idx = np.arange(n) * hop_length
+  mse = (sq[idx + frame_length] - sq[idx]) / frame_length
+  amin = 1e-10
+  db = 10.0 * np.log10(np.maximum(amin, mse)) - 10.0 * np.log10(np.maximum(amin, mse.max()))
+  loud = np.flatnonzero(db > -top_db)
+  if loud.size == 0:
+    return 0
+  return int(min(loud[0] * hop_length, y.shape[0]))
+
+
+class BFMNetDataGenerator(DataGenerator):
+  """(bfmcoeff [T,257], ear [T,1], pcm, T) slices of 24 frames per clip folder, batched and turned into log-mel features on the
+  device (generator.py:377-500).  The list format is the one of makelist: `folder|frame count` per line."""
+
+  SLICE = 24   # generator.py:455 (rnd_len)
+
+  def __init__(self, config_path):
+    if (not os.path.exists(config_path)):
+      logger.error('config_path not exists.')
+      exit(0)
+    self._params = BFMNetDataGenerator.default_hparams(config_path)
+    self._logmel = {}
+
+  @staticmethod
+  def default_hparams(config_path, name='default'):
+    params = YParams(config_path, name)
+    params.add_hparam('dataset_path', params.train_dataset_path)
+    params.add_hparam('max_squence_len', 30)
+    params.add_hparam('min_squence_len', 20)
+    params.add_hparam('shuffle_bufsize', 1000)
+    params.add_hparam('batch_size', 8)
+    return params
+
+  def set_params(self, params):
+    DataGenerator.set_params(self, params)
+    amd = params.get('amd') or {}
+    self.synthetic = amd.get('synthetic_data', 'auto')
+    if os.path.exists(params.dataset_path):
+      self.data_list = open(params.dataset_path).readlines()
+    elif self.synthetic in ('auto', True, 'true', 'yes'):
+      logger.warning('%s not found: using synthetic BFMNet clips', params.dataset_path)
+      self.data_list = None
+    else:
+      raise IOError('dataset list not found: %s' % params.dataset_path)
+    self.shuffle_bufsize = params.shuffle_bufsize
+    self.landmark_name = params.sample_file['landmark_name']
+    self.wav_name = params.sample_file['wav_name']
+    self.bfmcoeff_name = params.sample_file['bfmcoeff_name']
+    self.max_squence_len = params.max_squence_len
+    self.min_squence_len = params.min_squence_len
+    self.batch_size = params.batch_size
+
+  def pcm_length(self, frames):
+    """Samples that give exactly frames * frame_mfcc_scale log-mel rows (generator.py:476)."""
+    return self.hop_step * (frames * self.frame_mfcc_scale - 1) + self.win_length
+
+  def slices(self, bfmcoeffs, ear, pcm):
+    """The slicing of one clip (generator.py:455-481): drop the leading silence, replace the identity coefficients by the clip mean,
+    cut consecutive 24-frame slices with the PCM window that keeps log-mel rows and frames aligned."""
+    rnd_len = self.SLICE
+    start = first_nonsilent_sample(pcm, top_db=20)
+    sil_rm_start = int(start // self.frame_wav_scale)
+    pcm = pcm[start:]
+    bfmcoeffs = np.array(bfmcoeffs[sil_rm_start:, :], dtype=np.float32)
+    if bfmcoeffs.shape[0] == 0:
+      return
+    bfmcoeffs[:, :80] = np.mean(bfmcoeffs[:, :80], 0, keepdims=True)
+    # the reference slices `ear` from the un-trimmed start while the coefficients are trimmed (generator.py:471-472)
+    for i in range(bfmcoeffs.shape[0] // rnd_len):
+      bfmcoeff_slice = bfmcoeffs[i * rnd_len: (i + 1) * rnd_len, :]
+      ear_slice = ear[i * rnd_len: (i + 1) * rnd_len, :]
+      pcm_start = int(i * rnd_len * self.frame_wav_scale)
+      pcm_length = self.pcm_length(rnd_len)
+      if (pcm.shape[0] < pcm_start + pcm_length):
+        pcm = np.pad(pcm, (0, pcm_start + pcm_length - pcm.shape[0]), 'constant', constant_values=(0))
+      yield bfmcoeff_slice, ear_slice.astype(np.float32), pcm[pcm_start: pcm_start + pcm_length].astype(np.float32), bfmcoeff_slice.shape[0]
+
+  def _synthetic(self):
+    rng = np.random.default_rng(random.randint(0, 2 ** 31))
+    T = self.SLICE
+    n = self.pcm_length(T)
+    t = np.arange(n) / self.sample_rate
+    while True:
+      coeff = rng.normal(0, 0.5, (T, 257)).astype(np.float32)
+      coeff[:, :80] = coeff[:1, :80]
+      f0 = rng.uniform(90, 300)
+      pcm = (0.3 * np.sin(2 * np.pi * f0 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.02 * rng.normal(size=n)).astype(np.float32)
+      yield coeff, rng.uniform(0.6, 0.9, (T, 1)).astype(np.float32), pcm, T
+
+  def iterator(self):
+    if self.data_list is None:
+      for s in self._synthetic():
+        yield s
+      return
+    bfmcoeff_loader = BFMCoeffLoader()
+    landmark_loader = LandmarkLoader(norm_size=1)
+    wav_loader = WavLoader(sr=self.sample_rate)
+    random.shuffle(self.data_list)
+    for line in self.data_list:
+      folder, img_count = line.strip().split('|')
+      img_count = int(img_count)
+      paths = [os.path.join(folder, n) for n in (self.bfmcoeff_name, self.landmark_name, self.wav_name)]
+      if img_count <= 0 or not all(os.path.exists(p) for p in paths):
+        continue
+      bfmcoeffs = bfmcoeff_loader.get_data(paths[0])
+      landmark = landmark_loader.get_data(paths[1])
+      pcm = wav_loader.get_data(paths[2])
+      if (bfmcoeffs.shape[0] == img_count and landmark.shape[0] == img_count):
+        ear = 1 - self.ear_compute(landmark)
+        for s in self.slices(bfmcoeffs, ear, pcm):
+          yield s
+
+  def process_data(self, bfmcoeff, ear, pcm, seq_len):
+    return bfmcoeff, ear, self.extract_mfcc(pcm), seq_len
+
+  def get_dataset(self):
+    """Batches of (bfmcoeff [B,24,257], ear [B,24,1], mfcc [B,120,80] (device), seq_len [B]); every slice has the same length, so the
+    reference's padded_batch pads nothing."""
+    self.set_params(self._params)
+    T = self.SLICE
+    return _MfccDataset(self, self.iterator, ([T, 257], [T, 1], [self.pcm_length(T)], []), self.batch_size, self.shuffle_bufsize)
+
+
+class _MfccIterator(DatasetIterator):
+  def get_next(self):
+    g, b = self.ds.owner, self.ds.batch_size
+    T = g.SLICE
+    shapes = ((b, T, 257), (b, T, 1), (b, T * g.frame_mfcc_scale, g.num_mel_bins), (b,))
+    return tuple(IteratorNext(self, k, s) for k, s in enumerate(shapes))
+
+  def next_batch(self):
+    coeff, ear, pcm, n = DatasetIterator.next_batch(self)
+    return self.ds.owner.process_data(coeff, ear, pcm, n.astype(np.int32))
+
+
+class _MfccDataset(Dataset):
+  """dataset.map(process_data): PCM -> log-mel on the device after batching (generator.py:483-500)."""
+
+  def __init__(self, owner, *a, **kw):
+    Dataset.__init__(self, *a, **kw)
+    self.owner = owner
+
+  def make_one_shot_iterator(self):
+    return _MfccIterator(self)
 
 
 def pack_sample(example_rgb3, img_rgb3, img_size):

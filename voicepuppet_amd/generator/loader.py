@@ -54,6 +54,23 @@ class WavLoader(Loader):
     return data
 
 
+def _text_rows(path):
+  with open(path) as f:
+    return np.array([[float(v) for v in line.strip().split(",")] for line in f if line.strip()], dtype=np.float32)
+
+
+class LandmarkLoader(Loader):
+  """landmark.txt: one frame per line, 2x106 comma-separated coordinates, divided by norm_size (loader.py:58-66)."""
+
+  def __init__(self, root_path=None, norm_size=128):
+    Loader.__init__(self, root_path)
+    self.norm_size = norm_size
+
+  def get_data(self, file_path):
+    path = self._path(file_path)
+    return _text_rows(path) / self.norm_size if os.path.exists(path) else None
+
+
 class BFMCoeffLoader(Loader):
   def get_data(self, file_path):
     with open(self._path(file_path)) as f:
