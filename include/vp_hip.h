@@ -301,6 +301,7 @@ int vp_bfm_reconstruct(const vp_bfm_model* m, const float* coeff, const double* 
  * any channel count that is a multiple of 4.  voicepuppet_amd/bfmnet/train_engine.py chains them with plain GEMMs (rocBLAS).
  *   vp_bn_train_fwd / _bwd   tf.contrib.layers.batch_norm(is_training=True, scale=False, eps 1e-3): batch statistics + the affine that
  *                            normalises (y = x * scale + shift), and its backward (dx, dbeta)
+ *   vp_bn_act_train_bwd      the same with the backward of the relu / relu6 that follows folded in (no dz tensor is materialised)
  *   vp_affine_act_fwd        y = act(scale[c] * x + shift[c]) * mask (affine and mask optional: relu / relu6 / leaky-relu, dropout)
  *   vp_act_bwd               dx = dy * mask * act'(y)
  *   vp_dwconv7x3_raw         depthwise [7,3] SAME without bias / activation (forward; backward-data with reversed taps);
@@ -309,17 +310,22 @@ int vp_bfm_reconstruct(const vp_bfm_model* m, const float* coeff, const double* 
  *   vp_stem_im2col           the 9x5 stride-(1,2) stem as a [pixels, 48] matrix (GEMM operand for forward and weight gradient)
  *   vp_gru_train_fwd / _bwd  GRUCell recurrence with saved gates, and backward through time to the gate / candidate pre-activations
  *   vp_bfm_vertex_loss       add_cost_function on D = face_shape(true) - face_shape(pred): loss partials (f64) and dLoss/dD
- *   vp_sumsq                 sum of squares partials (f64): regulariser value, global-norm clipping
+ *   vp_sumsq                 sum of squares partials (f64): global-norm clipping
+ *   vp_l2_regulariser        tf.losses.get_regularization_loss() over the flat arena: gradient contribution + value partials
+ *   vp_adam_tf_clipped       tf.clip_by_global_norm + tf.train.AdamOptimizer (bfmnet.py:313-318) with the step scalars on the device
+ *   vp_moving_update         the moving-average updates of every batch_norm in one pass (decay 0.999, tinynet.py:20-27)
  * ---------------------------------------------------------------------------------------------- */
 size_t vp_bn_train_workspace_bytes(size_t pixels, int c);
 int vp_bn_train_fwd(const float* x, size_t pixels, int c, const float* beta, float eps, float* mean, float* var, float* rstd, float* scale,
                     float* shift, void* workspace, void* stream);
 int vp_bn_train_bwd(const float* x, const float* dz, size_t pixels, int c, const float* mean, const float* rstd, float* dx, float* dbeta,
                     void* workspace, void* stream);
+int vp_bn_act_train_bwd(const float* x, const float* da, size_t pixels, int c, const float* mean, const float* rstd, const float* shift, int act,
+                        float* dx, float* dbeta, void* workspace, void* stream);
 int vp_affine_act_fwd(const float* x, const float* scale, const float* shift, const float* mask, size_t pixels, int c, int act, float* y, void* stream);
 int vp_act_bwd(const float* dy, const float* ya, const float* mask, size_t n, int act, float* dx, void* stream);
 int vp_dwconv7x3_raw(const float* x, const float* w, float* y, int b, int h, int wd, int c, void* stream);
-size_t vp_dwconv7x3_wgrad_workspace_bytes(int b, int wd, int c);
+size_t vp_dwconv7x3_wgrad_workspace_bytes(int b, int h, int wd, int c);
 int vp_dwconv7x3_wgrad(const float* x, const float* dy, float* dw, int b, int h, int wd, int c, void* workspace, void* stream);
 int vp_maxpool_hw_bwd(const float* x, const float* dy, float* dx, int b, int h, int w, int c, int kh, int kw, int sh, int sw, void* stream);
 int vp_stem_im2col(const float* x, float* col, int b, int h, int w, void* stream);
@@ -331,6 +337,10 @@ int vp_vertex_loss_partials(int b, int j);
 int vp_bfm_vertex_loss(const float* d, const float* vmask, const int* seq_len, int b, int t, int j, float* gd, double* partial, void* stream);
 int vp_sumsq_partials(size_t n);
 int vp_sumsq(const float* x, size_t n, double* partial, void* stream);
+int vp_l2_regulariser(const float* params, const float* mask, float* grads, size_t n, float scale, double* partial, void* stream);
+int vp_adam_tf_clipped(float* params, float* grads, float* m, float* v, size_t n, const float* lr_t, const double* sumsq, float clip, float beta1,
+                       float beta2, float eps, void* stream);
+int vp_moving_update(float* moving, const float* batch, const float* factor, size_t n, float decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,4 @@
-"""ms per BFMNet training step on one MI355X: `python scripts/bench_bfmnet_train.py [steps] [batch] [nver]`.
+"""ms per BFMNet training step on one MI355X: `python scripts/bench_bfmnet_train.py [steps] [batch] [nver] [eager|graph]`.
 Synthetic clips of 24 frames (the generator's slice length), a random stand-in face model of `nver` vertices (35709 = BFM_model_front),
 dropout on, loss fetched every step as train_bfmnet.py does.  Prints one JSON line."""
 import json
@@ -17,6 +17,7 @@ def main():
   steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
   B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
   nver = int(sys.argv[3]) if len(sys.argv) > 3 else 35709
+  mode = sys.argv[4] if len(sys.argv) > 4 else "graph"
   T = 24
   rng = np.random.default_rng(0)
   vm = np.ones((nver, 3), np.float32)
@@ -29,16 +30,20 @@ def main():
   mfccs = torch.randn(B, 5 * T, 80, device=dev)
   coeff = torch.randn(B, T, 257, device=dev) * 0.5
   seq = torch.full((B,), T, dtype=torch.int32, device=dev)
+  if mode == "graph":
+    step = lambda: eng.train_step_graphed(ears, mfccs, coeff, seq, 0.25)
+  else:
+    step = lambda: eng.train_step(ears, mfccs, coeff, seq, masks=eng.draw_masks(0.25))
   for _ in range(5):
-    eng.train_step(ears, mfccs, coeff, seq, masks=eng.draw_masks(0.25))
+    step()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(steps):
-    r = eng.train_step(ears, mfccs, coeff, seq, masks=eng.draw_masks(0.25))
+    r = step()
   torch.cuda.synchronize()
   ms = (time.perf_counter() - t0) / steps * 1e3
   print(json.dumps({"metric": "bfmnet_train_clips_per_sec", "value": B / ms * 1e3, "unit": "clips/s", "ms_per_step": ms, "steps": steps,
-                    "config": {"workload": "BFMNet build_train_op", "batch": B, "frames": T, "vertices": nver, "dropout": True},
+                    "config": {"workload": "BFMNet build_train_op", "batch": B, "frames": T, "vertices": nver, "dropout": True, "mode": mode},
                     "dtype": "f32", "loss": r["loss"], "global_norm": r["global_norm"]}))
 
 

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 b=${1:-4}
 o=gpurun_out/kstats_f4_b$b
 rm -rf $o; mkdir -p $o
-rocprofv3 --kernel-trace --stats -d $o/r -o r --output-format csv -- python3 scripts/bench_bfmnet_train.py 20 $b > $o/r.log 2>&1
+rocprofv3 --kernel-trace --stats -d $o/r -o r --output-format csv -- python3 scripts/bench_bfmnet_train.py 20 $b 35709 ${2:-graph} > $o/r.log 2>&1
 rm -f $o/r/*kernel_trace.csv
 tail -2 $o/r.log
 python3 - "$o/r/r_kernel_stats.csv" <<'P'

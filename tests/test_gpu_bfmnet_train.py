@@ -83,7 +83,7 @@ def test_single_kernels_against_numpy():
   dy = rng.normal(size=(b, h, w, c)).astype(np.float32)
   xt, dyt = torch.tensor(x, device="cuda"), torch.tensor(dy, device="cuda")
   dw = torch.empty(21, c, device="cuda")
-  ws = torch.empty(L.vp_dwconv7x3_wgrad_workspace_bytes(b, w, c), dtype=torch.uint8, device="cuda")
+  ws = torch.empty(L.vp_dwconv7x3_wgrad_workspace_bytes(b, h, w, c), dtype=torch.uint8, device="cuda")
   _lib.check(L.vp_dwconv7x3_wgrad(P(xt), P(dyt), P(dw), b, h, w, c, P(ws), st))
   xp = np.pad(x.astype(np.float64), ((0, 0), (3, 3), (1, 1), (0, 0)))
   ref = np.stack([(xp[:, kh:kh + h, kw:kw + w, :] * dy).sum((0, 1, 2)) for kh in range(7) for kw in range(3)])
@@ -101,3 +101,28 @@ def test_single_kernels_against_numpy():
     _lib.check(L.vp_maxpool_hw_bwd(P(xd), P(gd), P(dx), b, hh, ww, c, k[0], k[1], s[0], s[1], st))
     torch.cuda.synchronize()
     assert np.allclose(dx.cpu().numpy(), xg.grad.numpy(), atol=1e-6)
+
+
+def test_graphed_step_equals_eager_step():
+  """train_step_graphed replays the launches train_step issues: from the same state and batch (dropout off) both reach the same
+  parameters, Adam slots and moving statistics, step after step; with dropout on every replay draws new masks."""
+  from voicepuppet_amd.bfmnet.bfmnet import random_variables
+  B, T = 2, 4
+  rng = np.random.default_rng(3)
+  model = bt.synthetic_model(120, 1)
+  mk = lambda: BFMNetTrainEngine(B, T, {"exBase": model["exBase"], "vmask": model["vmask"]}, lr=1e-3)
+  a, b = mk(), mk()
+  w = random_variables(5)
+  a.load_params(w); b.load_params(w)
+  for i in range(3):
+    ears = torch.tensor(rng.uniform(0.1, 0.4, (B, T, 1)), dtype=torch.float32, device="cuda")
+    mfccs = torch.tensor(rng.normal(0, 1, (B, 5 * T, 80)), dtype=torch.float32, device="cuda")
+    coeff = torch.tensor(rng.normal(0, 0.5, (B, T, 257)), dtype=torch.float32, device="cuda")
+    seq = [T, T - 1 - (i % 2)]
+    ra = a.train_step(ears, mfccs, coeff, seq)
+    rb = b.train_step_graphed(ears, mfccs, coeff, seq, 0.0, 0.0)
+    assert ra["loss"] == pytest.approx(rb["loss"], rel=1e-6) and ra["global_norm"] == pytest.approx(rb["global_norm"], rel=1e-5)
+    assert torch.allclose(a.arena, b.arena, rtol=1e-5, atol=1e-7) and torch.allclose(a.v, b.v, rtol=1e-4, atol=1e-12)
+  assert a.step_t == b.step_t == 3
+  losses = {b.train_step_graphed(ears, mfccs, coeff, seq, 0.25)["loss"] for _ in range(3)}
+  assert len(losses) == 3 and all(np.isfinite(l) for l in losses)

@@ -110,7 +110,11 @@ _SIGNATURES = {
     "vp_affine_act_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P, _P]),
     "vp_act_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_int, _P, _P]),
     "vp_dwconv7x3_raw": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    "vp_dwconv7x3_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vp_dwconv7x3_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vp_bn_act_train_bwd": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int, _P, _P, _P, ctypes.c_int, _P, _P, _P, _P]),
+    "vp_l2_regulariser": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_float, _P, _P]),
+    "vp_adam_tf_clipped": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
+    "vp_moving_update": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_float, _P]),
     "vp_dwconv7x3_wgrad": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "vp_maxpool_hw_bwd": (ctypes.c_int, [_P, _P, _P] + [ctypes.c_int] * 8 + [_P]),
     "vp_stem_im2col": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),

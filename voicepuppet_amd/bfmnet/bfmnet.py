@@ -250,9 +250,11 @@ class BFMNet(ModelBuilder):
       apply = 'Train_op' in names
       if any(n in names for n in ('Train_op', 'Loss', 'Grads', 'BFMCoeffDecoder')):
         eng.lr = lr
-        aux = eng.train_step(t(vals['Ears']), t(vals['Mfccs']), t(vals['BFM_coeff_seq']), seq, masks=eng.draw_masks(self.drop_rate), apply=apply)
-        if apply:
+        if apply:    # the whole step replays from a hipGraph (dropout draws included)
+          aux = eng.train_step_graphed(t(vals['Ears']), t(vals['Mfccs']), t(vals['BFM_coeff_seq']), seq, self.drop_rate)
           self.global_step += 1
+        else:
+          aux = eng.train_step(t(vals['Ears']), t(vals['Mfccs']), t(vals['BFM_coeff_seq']), seq, masks=eng.draw_masks(self.drop_rate), apply=False)
       coeff = eng.last_out
       aux['Lr'] = np.float32(lr)
     else:

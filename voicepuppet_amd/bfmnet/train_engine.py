@@ -11,7 +11,11 @@ audio_kernels.hip, pointwise.hip).  No CPU fallback: the constructor raises with
 
 Layouts: activations NHWC float32 viewed as [pixels, channels]; parameters live in ONE flat float32 arena (trainable variables first,
 moving statistics behind them) in the order of oracle/audio_ref.bfmnet_manifest() = the TF variable order, so the Adam slots and the
-gradient arena are flat too."""
+gradient arena are flat too, the batch statistics of every batch-norm land in one flat buffer laid out like the arena's moving-statistics
+tail (one kernel updates all 114 moving averages), and regulariser / clipping / Adam are three launches over the whole arena.
+
+The step's shapes are static, so `train_step_graphed` captures the ~900 launches of one step (dropout draws included) into a hipGraph
+once and replays it: the per-step host work is four small copies into the graph's input buffers and one read of three scalars."""
 import ctypes
 import math
 
@@ -65,26 +69,38 @@ class BFMNetTrainEngine:
     man = [(n, s) for n, _, s in bfmnet_manifest()]
     order = [(n, s) for n, s in man if trainable(n)] + [(n, s) for n, s in man if not trainable(n)]
     self.ntrain = sum(int(np.prod(s)) for n, s in order if trainable(n))
+    assert self.ntrain % 4 == 0
     total = sum(int(np.prod(s)) for n, s in order)
     self.arena = torch.zeros(total, dtype=torch.float32, device=dev)
     self.grads = torch.zeros(self.ntrain, dtype=torch.float32, device=dev)
     self.m = torch.zeros(self.ntrain, dtype=torch.float32, device=dev)
     self.v = torch.zeros(self.ntrain, dtype=torch.float32, device=dev)
-    self.p, self.g, self.shapes = {}, {}, {}
+    self.bstats = torch.zeros(total - self.ntrain, dtype=torch.float32, device=dev)     # batch mean / variance, laid out like the arena's tail
+    self.bfactor = None                                                                 # (1 - decay) [* n / (n - 1) on variance slots]
+    self._bn_rows = {}
+    l2 = np.zeros(self.ntrain, np.float32)
+    self.p, self.g, self.bs, self.shapes = {}, {}, {}, {}
     off = 0
     for n, s in order:
       k = int(np.prod(s))
       self.p[n] = self.arena[off:off + k].view(s)
       if trainable(n):
         self.g[n] = self.grads[off:off + k].view(s)
+        if regularised(n):
+          l2[off:off + k] = 1.0
+      else:
+        self.bs[n] = self.bstats[off - self.ntrain:off - self.ntrain + k]
       self.shapes[n] = s
       off += k
+    self.l2mask = torch.from_numpy(l2).to(dev)
     self.step_t = 0
+    self.lr_t = torch.zeros(1, dtype=torch.float32, device=dev)
     self.exbase = torch.tensor(np.asarray(model["exBase"], dtype=np.float32), device=dev).contiguous()       # [3n, 64]
     self.vmask = torch.tensor(np.asarray(model["vmask"], dtype=np.float32).reshape(-1), device=dev).contiguous()
     self.J = self.exbase.shape[0]
     self.ears_scale = torch.tensor([-2.0, -2.0, -2.0, -4.0], device=dev)
     self._ws = {}
+    self._graphs = {}
 
   # ---- parameters -----------------------------------------------------------------------------------------------------------
   def load_params(self, params):
@@ -106,23 +122,30 @@ class BFMNetTrainEngine:
   def _work(self, key, nbytes):
     w = self._ws.get(key)
     if w is None or w.numel() < nbytes:
+      if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("workspace %s must exist before a graph capture (run one eager step first)" % key)
       w = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
       self._ws[key] = w
     return w
 
-  def _bn_fwd(self, y, beta):
+  def _bn_fwd(self, y, scope):
+    """batch statistics of y [P, C] -> (mean, rstd, shift); mean / biased variance go to the flat batch-statistics buffer."""
     P, C = y.shape
-    mean, var, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=self.dev) for _ in range(5))
+    self._bn_rows[scope] = P
+    mean, var = self.bs[scope + "/BatchNorm/moving_mean"], self.bs[scope + "/BatchNorm/moving_variance"]
+    rs = torch.empty(3, C, dtype=torch.float32, device=self.dev)
     ws = self._work("bn", self.L.vp_bn_train_workspace_bytes(P, C))
-    _lib.check(self.L.vp_bn_train_fwd(_ptr(y), P, C, _ptr(beta), BN_EPS, _ptr(mean), _ptr(var), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(ws),
-                                      _stream()), "vp_bn_train_fwd")
-    return mean, var, rstd, scale, shift
+    _lib.check(self.L.vp_bn_train_fwd(_ptr(y), P, C, _ptr(self.p[scope + "/BatchNorm/beta"]), BN_EPS, _ptr(mean), _ptr(var), _ptr(rs[0]), _ptr(rs[1]),
+                                      _ptr(rs[2]), _ptr(ws), _stream()), "vp_bn_train_fwd")
+    return mean, rs[0], rs[2]
 
-  def _bn_bwd(self, y, dz, mean, rstd, dbeta):
+  def _bn_act_bwd(self, da, y, mean, rstd, shift, act, scope):
+    """backward of act(batch_norm(y)): the activation's derivative is recomputed from y inside the kernels."""
     P, C = y.shape
     dx = torch.empty_like(y)
     ws = self._work("bn", self.L.vp_bn_train_workspace_bytes(P, C))
-    _lib.check(self.L.vp_bn_train_bwd(_ptr(y), _ptr(dz), P, C, _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dbeta), _ptr(ws), _stream()), "vp_bn_train_bwd")
+    _lib.check(self.L.vp_bn_act_train_bwd(_ptr(y), _ptr(da), P, C, _ptr(mean), _ptr(rstd), _ptr(shift), act, _ptr(dx),
+                                          _ptr(self.g[scope + "/BatchNorm/beta"]), _ptr(ws), _stream()), "vp_bn_act_train_bwd")
     return dx
 
   def _act(self, x, scale, shift, act, mask=None):
@@ -142,12 +165,10 @@ class BFMNetTrainEngine:
     _lib.check(self.L.vp_dwconv7x3_raw(_ptr(x2d), _ptr(w21), _ptr(y), self.B, H, W, C, _stream()), "vp_dwconv7x3_raw")
     return y
 
-  def _dw_wgrad(self, x2d, dy2d, H, W):
+  def _dw_wgrad(self, x2d, dy2d, H, W, out):
     C = x2d.shape[1]
-    dw = torch.empty(21, C, dtype=torch.float32, device=self.dev)
-    ws = self._work("dw", self.L.vp_dwconv7x3_wgrad_workspace_bytes(self.B, W, C))
-    _lib.check(self.L.vp_dwconv7x3_wgrad(_ptr(x2d), _ptr(dy2d), _ptr(dw), self.B, H, W, C, _ptr(ws), _stream()), "vp_dwconv7x3_wgrad")
-    return dw
+    ws = self._work("dw", self.L.vp_dwconv7x3_wgrad_workspace_bytes(self.B, H, W, C))
+    _lib.check(self.L.vp_dwconv7x3_wgrad(_ptr(x2d), _ptr(dy2d), _ptr(out), self.B, H, W, C, _ptr(ws), _stream()), "vp_dwconv7x3_wgrad")
 
   def _pool(self, x2d, H, W, k, s):
     C = x2d.shape[1]
@@ -172,28 +193,87 @@ class BFMNetTrainEngine:
   def _cba_fwd(self, x, kernel, bn_scope, act, tape):
     """x [P, cin] @ kernel [cin, cout] -> batch_norm -> act.  tape gets what the backward needs."""
     y = torch.mm(x, kernel)
-    mean, var, rstd, scale, shift = self._bn_fwd(y, self.p[bn_scope + "/BatchNorm/beta"])
-    a = self._act(y, scale, shift, act)
-    tape.append(("cba", x, kernel, y, mean, var, rstd, a, act, bn_scope))
+    mean, rstd, shift = self._bn_fwd(y, bn_scope)
+    a = self._act(y, rstd, shift, act)
+    tape.append(("cba", x, kernel, y, mean, rstd, shift, act, bn_scope))
     return a
 
-  def _bn_act_bwd(self, da, y, mean, rstd, a, act, bn_scope):
-    dz = da if act == ACT_NONE else self._act_bwd(da, a, act)
-    return self._bn_bwd(y, dz, mean, rstd, self.g[bn_scope + "/BatchNorm/beta"])
+  def _grad2d(self, kernel_view):
+    """the gradient slot of the variable a [cin, cout] view of the arena belongs to, as a matrix of the same shape (GEMM output)"""
+    name = self._by_offset()[kernel_view.storage_offset()]
+    return self.g[name].view(kernel_view.shape)
 
-  def _moving(self, bn_scope, mean, var, n):
-    self.p[bn_scope + "/BatchNorm/moving_mean"].mul_(BN_DECAY).add_(mean, alpha=1 - BN_DECAY)
-    self.p[bn_scope + "/BatchNorm/moving_variance"].mul_(BN_DECAY).add_(var, alpha=(1 - BN_DECAY) * n / max(n - 1, 1))   # fused kernel: unbiased
+  def _by_offset(self):
+    if not hasattr(self, "_off"):
+      self._off = {t.storage_offset(): n for n, t in self.p.items()}
+    return self._off
+
+  def _moving_factor(self):
+    if self.bfactor is None:
+      f = torch.full_like(self.bstats, 1 - BN_DECAY)
+      for scope, n in self._bn_rows.items():
+        v = self.bs[scope + "/BatchNorm/moving_variance"]
+        off = v.storage_offset() - self.bstats.storage_offset()
+        f[off:off + v.numel()] = (1 - BN_DECAY) * n / max(n - 1, 1)                                  # fused kernel: unbiased estimate
+      self.bfactor = f
+    return self.bfactor
 
   # ---- the step -------------------------------------------------------------------------------------------------------------
   def train_step(self, ears, mfccs, bfm_coeffs, seq_len, masks=None, apply=True):
     """ears [B,T,1], mfccs [B,5T,80], bfm_coeffs [B,T,>=144] (device float32 tensors); seq_len: list / int32 tensor [B];
     masks: optional dict 'enc' [B,T,256], 'rnn' [B,T,256], 'd0' [B,T,128], 'd1' [B,T,64] with entries 0 or 1/keep_prob (dropout draws).
-    Returns dict(loss, loss_data, global_norm) of python floats.  apply=False: gradients only (self.g), no update."""
-    B, T, L, p, g = self.B, self.T, self.L, self.p, self.g
-    masks = masks or {}
-    H, W = 5 * T, self.W0
+    Returns dict(loss, loss_data, global_norm) of python floats.  apply=False: gradients only (self.g, clipped), no update."""
     seq = torch.as_tensor(seq_len, dtype=torch.int32, device=self.dev).contiguous()
+    if apply:
+      self._advance()
+    res = self._body(ears, mfccs, bfm_coeffs, seq, masks or {}, apply)
+    loss, loss_data, gn = res.tolist()
+    return {"loss": loss, "loss_data": loss_data, "global_norm": gn}
+
+  def train_step_graphed(self, ears, mfccs, bfm_coeffs, seq_len, drop_rate=0.25, inner_rate=0.25):
+    """The same step (apply=True) replayed from a hipGraph captured on first use; the dropout masks are drawn inside the graph
+    (draw_masks) from torch's device generator.  One eager step's worth of scratch stays resident in the graph's private pool."""
+    key = (float(drop_rate or 0), float(inner_rate or 0))
+    g = self._graphs.get(key)
+    if g is None:
+      g = self._capture(ears, mfccs, bfm_coeffs, seq_len, *key)
+      self._graphs[key] = g
+    graph, s_in, res = g
+    s_in[0].copy_(ears.reshape(s_in[0].shape)); s_in[1].copy_(mfccs); s_in[2].copy_(bfm_coeffs)
+    s_in[3].copy_(torch.as_tensor(seq_len, dtype=torch.int32), non_blocking=False)
+    self._advance()
+    graph.replay()
+    loss, loss_data, gn = res.tolist()
+    return {"loss": loss, "loss_data": loss_data, "global_norm": gn}
+
+  def _advance(self):
+    self.step_t += 1
+    self.lr_t.fill_(self.lr * math.sqrt(1 - 0.999 ** self.step_t) / (1 - 0.9 ** self.step_t))
+
+  def _capture(self, ears, mfccs, bfm_coeffs, seq_len, drop_rate, inner_rate):
+    s_in = [torch.empty_like(ears.to(self.dev, torch.float32).contiguous()), torch.empty_like(mfccs.to(self.dev, torch.float32).contiguous()),
+            torch.empty_like(bfm_coeffs.to(self.dev, torch.float32).contiguous()), torch.zeros(self.B, dtype=torch.int32, device=self.dev)]
+    s_in[0].copy_(ears); s_in[1].copy_(mfccs); s_in[2].copy_(bfm_coeffs); s_in[3].copy_(torch.as_tensor(seq_len, dtype=torch.int32))
+    # warm-up on a side stream (allocator, rocBLAS handles, workspaces) without touching parameters or optimiser state
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(2):
+        self._body(s_in[0], s_in[1], s_in[2], s_in[3], self.draw_masks(drop_rate, inner_rate), False)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    self._moving_factor()                                                            # built from the row counts the warm-up recorded
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+      res = self._body(s_in[0], s_in[1], s_in[2], s_in[3], self.draw_masks(drop_rate, inner_rate), True)
+    return graph, s_in, res
+
+  def _body(self, ears, mfccs, bfm_coeffs, seq, masks, apply):
+    """Every launch of one step, on the current stream, without host synchronisation (capturable).  Returns a float64 device tensor
+    [loss, data loss, global norm]."""
+    B, T, L, p, g = self.B, self.T, self.L, self.p, self.g
+    H, W = 5 * T, self.W0
+    masks = masks or {}
     mk = lambda k, c: (masks[k].reshape(B * T, c).contiguous() if masks.get(k) is not None else None)
     tape = []
     # stem: 9x5 stride (1,2) as im2col + GEMM
@@ -212,9 +292,9 @@ class BFMNetTrainEngine:
       a = self._cba_fwd(inp, p[b + "/expansion_1x1_conv2d/conv2d/kernel"].reshape(cin, cin * exp), b + "/expansion_1x1_conv2d", ACT_RELU6, tape)
       wd = p[b + "/depthwise_conv2d/SeparableConv2d/depthwise_weights"].reshape(21, cin * exp)
       yd = self._dw(a, wd, H, W)
-      mean, var, rstd, scale, shift = self._bn_fwd(yd, p[b + "/depthwise_conv2d/BatchNorm/beta"])
-      ad = self._act(yd, scale, shift, ACT_RELU6)
-      tape.append(("dw", a, wd, yd, mean, var, rstd, ad, b, H, W))
+      mean, rstd, shift = self._bn_fwd(yd, b + "/depthwise_conv2d")
+      ad = self._act(yd, rstd, shift, ACT_RELU6)
+      tape.append(("dw", a, wd, yd, mean, rstd, shift, b, H, W))
       out = self._cba_fwd(ad, p[b + "/projection_1x1_conv2d/conv2d/kernel"].reshape(cin * exp, cout), b + "/projection_1x1_conv2d", ACT_NONE, tape)
       if cout != cin:
         sc = self._cba_fwd(inp, p[b + "/1x1_conv2d/conv2d/kernel"].reshape(cin, cout), b + "/1x1_conv2d", ACT_NONE, tape)
@@ -264,8 +344,8 @@ class BFMNetTrainEngine:
     def dense_bwd(dy):
       _, x, wname, bname, y, act, mask = tape.pop()
       dz = dy if (act == ACT_NONE and mask is None) else self._act_bwd(dy, y, act, mask)
-      g[wname].copy_(torch.mm(x.t(), dz))
-      g[bname].copy_(dz.sum(0))
+      torch.mm(x.t(), dz, out=g[wname])
+      torch.sum(dz, 0, out=g[bname])
       return torch.mm(dz, p[wname].t())
     d = dense_bwd(do)
     d = dense_bwd(d)
@@ -275,22 +355,25 @@ class BFMNetTrainEngine:
     dag, dac = torch.empty(B * T, 512, dtype=torch.float32, device=self.dev), torch.empty(B * T, 256, dtype=torch.float32, device=self.dev)
     _lib.check(L.vp_gru_train_bwd(_ptr(d.contiguous()), _ptr(whg), _ptr(whc), _ptr(seq), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), _ptr(dag), _ptr(dac),
                                   B, T, _stream()), "vp_gru_train_bwd")
-    g[GRU + "gates/kernel"][:256].copy_(torch.mm(c1.t(), dag))
-    g[GRU + "gates/kernel"][256:].copy_(torch.mm(shp.t(), dag))
-    g[GRU + "gates/bias"].copy_(dag.sum(0))
-    g[GRU + "candidate/kernel"][:256].copy_(torch.mm(c1.t(), dac))
-    g[GRU + "candidate/kernel"][256:].copy_(torch.mm((sr * shp).t(), dac))
-    g[GRU + "candidate/bias"].copy_(dac.sum(0))
+    torch.mm(c1.t(), dag, out=g[GRU + "gates/kernel"][:256])
+    torch.mm(shp.t(), dag, out=g[GRU + "gates/kernel"][256:])
+    torch.sum(dag, 0, out=g[GRU + "gates/bias"])
+    torch.mm(c1.t(), dac, out=g[GRU + "candidate/kernel"][:256])
+    torch.mm((sr * shp).t(), dac, out=g[GRU + "candidate/kernel"][256:])
+    torch.sum(dac, 0, out=g[GRU + "candidate/bias"])
     d = torch.mm(dag, wg[:256].t()) + torch.mm(dac, wc[:256].t())                      # d loss / d c1
     d = dense_bwd(d)
     d = dense_bwd(d)                                                                 # d loss / d enc_in  [B*T, 256]
 
-    def cba_bwd(da):
-      _, x, kernel, y, mean, var, rstd, a, act, scope = tape.pop()
-      dy = self._bn_act_bwd(da, y, mean, rstd, a, act, scope)
-      if apply:
-        self._moving(scope, mean, var, y.shape[0])
-      return dy, x, kernel
+    def cba_bwd(da, wgrad=True):
+      """-> d loss / d x (None for the stem)"""
+      _, x, kernel, y, mean, rstd, shift, act, scope = tape.pop()
+      dy = self._bn_act_bwd(da, y, mean, rstd, shift, act, scope)
+      if x.shape[1] == 48:                                                           # stem: no input gradient
+        g[PREFIX + "block0_0/conv2d/conv2d/kernel"].view(45, 32).copy_(torch.mm(x.t(), dy)[:45])
+        return None
+      torch.mm(x.t(), dy, out=self._grad2d(kernel))
+      return torch.mm(dy, kernel.t())
     while tape:
       kind = tape[-1][0]
       if kind == "pool":
@@ -300,53 +383,33 @@ class BFMNetTrainEngine:
       elif kind in ("add_sc", "add_id"):
         tape.pop()
         dsum = d
-        sc_bwd = cba_bwd(dsum) if kind == "add_sc" else None                         # shortcut conv (its tape entry lies on top)
-        dyp, xp, kp = cba_bwd(dsum)                                                  # projection conv
-        self._store_kernel_grad(kp, torch.mm(xp.t(), dyp))
-        dad = torch.mm(dyp, kp.t())
-        _, a_in, wd, yd, mean, var, rstd, ad, b, h_, w_ = tape.pop()
-        dz = self._act_bwd(dad, ad, ACT_RELU6)
-        dyd = self._bn_bwd(yd, dz, mean, rstd, g[b + "/depthwise_conv2d/BatchNorm/beta"])
-        if apply:
-          self._moving(b + "/depthwise_conv2d", mean, var, yd.shape[0])
-        g[b + "/depthwise_conv2d/SeparableConv2d/depthwise_weights"].copy_(self._dw_wgrad(a_in, dyd, h_, w_).view(7, 3, -1, 1))
+        dsc = cba_bwd(dsum) if kind == "add_sc" else dsum                            # shortcut conv (its tape entry lies on top) / identity
+        dad = cba_bwd(dsum)                                                          # projection conv
+        _, a_in, wd, yd, mean, rstd, shift, b, h_, w_ = tape.pop()
+        dyd = self._bn_act_bwd(dad, yd, mean, rstd, shift, ACT_RELU6, b + "/depthwise_conv2d")
+        self._dw_wgrad(a_in, dyd, h_, w_, g[b + "/depthwise_conv2d/SeparableConv2d/depthwise_weights"])
         da = self._dw(dyd, wd.flip(0).contiguous(), h_, w_)
-        dye, xe, ke = cba_bwd(da)                                                    # expansion conv
-        self._store_kernel_grad(ke, torch.mm(xe.t(), dye))
-        dinp = torch.mm(dye, ke.t())
-        if kind == "add_sc":
-          dys, xs, ks = sc_bwd
-          self._store_kernel_grad(ks, torch.mm(xs.t(), dys))
-          dinp = dinp + torch.mm(dys, ks.t())
-        else:
-          dinp = dinp + dsum
-        d = dinp
+        d = cba_bwd(da)                                                              # expansion conv
+        d.add_(dsc)
       elif kind == "cba":                                                            # block8_0 (1x1) or the stem
-        dy, x, kernel = cba_bwd(d)
-        if x.shape[1] == 48:                                                         # stem: no input gradient
-          g[PREFIX + "block0_0/conv2d/conv2d/kernel"].copy_(torch.mm(x.t(), dy)[:45].view(9, 5, 1, 32))
-          d = None
-        else:
-          self._store_kernel_grad(kernel, torch.mm(x.t(), dy))
-          d = torch.mm(dy, kernel.t())
+        d = cba_bwd(d)
       else:
         raise AssertionError(kind)
 
-    # ---- regulariser, clip_by_global_norm, Adam ----------------------------------------------------------------------------------------
-    reg = torch.zeros((), dtype=torch.float64, device=self.dev)
-    for n in p:
-      if regularised(n):
-        reg = reg + self._sumsq(p[n])
-        g[n].add_(p[n], alpha=L2_SCALE)
-    loss = loss_data + 0.5 * L2_SCALE * reg
-    gn = torch.sqrt(self._sumsq(self.grads))
-    scale = self.clip / torch.clamp(gn, min=self.clip)
-    self.grads.mul_(scale.to(torch.float32))
+    # ---- regulariser, clip_by_global_norm, Adam, moving averages ------------------------------------------------------------------------
+    part = torch.empty(L.vp_sumsq_partials(self.ntrain), dtype=torch.float64, device=self.dev)
+    _lib.check(L.vp_l2_regulariser(_ptr(self.arena), _ptr(self.l2mask), _ptr(self.grads), self.ntrain, L2_SCALE, _ptr(part), _stream()), "vp_l2_regulariser")
+    loss = loss_data + 0.5 * L2_SCALE * part.sum()
+    ss = self._sumsq(self.grads)
     if apply:
-      self.step_t += 1
-      _lib.check(L.vp_adam_tf(_ptr(self.arena), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.ntrain, self.step_t, self.lr, 0.9, 0.999, 1e-8,
-                              _stream()), "vp_adam_tf")
-    return {"loss": float(loss), "loss_data": float(loss_data), "global_norm": float(gn)}
+      _lib.check(L.vp_adam_tf_clipped(_ptr(self.arena), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.ntrain, _ptr(self.lr_t), _ptr(ss), self.clip,
+                                      0.9, 0.999, 1e-8, _stream()), "vp_adam_tf_clipped")
+      _lib.check(L.vp_moving_update(_ptr(self.arena[self.ntrain:]), _ptr(self.bstats), _ptr(self._moving_factor()), self.bstats.numel(), BN_DECAY,
+                                    _stream()), "vp_moving_update")
+    else:
+      gn = torch.sqrt(ss)
+      self.grads.mul_((self.clip / torch.clamp(gn, min=self.clip)).to(torch.float32))
+    return torch.stack([loss, loss_data, torch.sqrt(ss)])
 
   def _vertex_loss(self, o, bfm_coeffs, seq):
     """add_cost_function (bfmnet.py:229-271): both face shapes share the identity coefficients, so their difference is
@@ -386,13 +449,3 @@ class BFMNetTrainEngine:
       return (torch.rand(self.B, self.T, c, device=self.dev, generator=generator) < keep).to(torch.float32) / keep
     return {"enc": mk(256, drop_rate), "rnn": mk(256, inner_rate), "d0": mk(128, inner_rate), "d1": mk(64, inner_rate)}
 
-  def _store_kernel_grad(self, kernel_view, dw):
-    """kernel_view is a reshaped view of one variable of the arena: find it by its storage offset."""
-    off = kernel_view.storage_offset()
-    name = self._by_offset().get(off)
-    self.g[name].copy_(dw.view(self.shapes[name]))
-
-  def _by_offset(self):
-    if not hasattr(self, "_off"):
-      self._off = {t.storage_offset(): n for n, t in self.p.items()}
-    return self._off

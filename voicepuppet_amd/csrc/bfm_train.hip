@@ -22,41 +22,102 @@ static inline int tblk(size_t work, int cap = 4096) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-channel sums over the P rows of a [P, C] tensor.  MODE 0: sum x, sum x^2.  MODE 1: sum dz, sum dz * (x - mean) * rstd.
-// grid (nchunk, ceil(C / 64)); a block = 4 row lanes x 64 channels; f64 partials [nchunk][2][C]
+// per-channel sums over the P rows of a [P, C] tensor.  MODE 0: sum x, sum x^2.  MODE 1: sum dz, sum dz * (x - mean) * rstd, where
+// dz = da * act'(rstd * x + shift) when an activation follows the batch-norm (its backward is folded in: no dz tensor exists).
+// A thread owns one channel quad (float4 loads: a row group of QL = 2^ql lanes reads QL*16 contiguous bytes) and every RL-th row of
+// its row chunk, four rows in flight; grid (nchunk, ceil(C/4 / QL)); f64 partials [nchunk][2][C].
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_d(int act, float y);
+
+struct ChanSumsArgs {
+  const float* x; const float* dz; const float* mean; const float* rstd; const float* shift;
+  size_t P; int C; int ql; int act; double* partial;
+};
+
 template <int MODE>
-__global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, size_t P, int C, double* __restrict__ partial) {
-  const int c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  const size_t per = (P + gridDim.x - 1) / gridDim.x;
-  const size_t p0 = blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
-  double s0 = 0, s1 = 0;
-  if (c < C) {
-    const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
-    for (size_t p = p0 + rl; p < p1; p += 4) {
-      const float v = x[p * C + c];
-      if (MODE == 0) { s0 += v; s1 += (double)v * v; }
-      else { const float d = dz[p * C + c]; s0 += d; s1 += (double)d * ((v - mu) * rs); }
+__global__ __launch_bounds__(256) void chan_sums_kernel(const ChanSumsArgs a) {
+  const int QL = 1 << a.ql, RL = 256 >> a.ql;
+  const int q = blockIdx.y * QL + (threadIdx.x & (QL - 1)), rl = threadIdx.x >> a.ql, cq = a.C >> 2;
+  const size_t per = (a.P + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = blockIdx.x * per, p1 = p0 + per < a.P ? p0 + per : a.P;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (q < cq) {
+    float4 mu = {0, 0, 0, 0}, rs = mu, sh = mu;
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const float4*>(a.mean + q * 4); rs = *reinterpret_cast<const float4*>(a.rstd + q * 4);
+      if (a.act) sh = *reinterpret_cast<const float4*>(a.shift + q * 4);
+    }
+    const int act = a.act;
+    auto fold = [&](const float4 v, float4 d) {
+      if (MODE == 0) {
+        s0[0] += v.x; s0[1] += v.y; s0[2] += v.z; s0[3] += v.w;
+        s1[0] += (double)v.x * v.x; s1[1] += (double)v.y * v.y; s1[2] += (double)v.z * v.z; s1[3] += (double)v.w * v.w;
+      } else {
+        if (act) {
+          d.x *= act_d(act, fmaf(rs.x, v.x, sh.x)); d.y *= act_d(act, fmaf(rs.y, v.y, sh.y));
+          d.z *= act_d(act, fmaf(rs.z, v.z, sh.z)); d.w *= act_d(act, fmaf(rs.w, v.w, sh.w));
+        }
+        s0[0] += d.x; s0[1] += d.y; s0[2] += d.z; s0[3] += d.w;
+        s1[0] += (double)d.x * ((v.x - mu.x) * rs.x); s1[1] += (double)d.y * ((v.y - mu.y) * rs.y);
+        s1[2] += (double)d.z * ((v.z - mu.z) * rs.z); s1[3] += (double)d.w * ((v.w - mu.w) * rs.w);
+      }
+    };
+    const size_t rs4 = (size_t)a.C, step = (size_t)RL;
+    size_t p = p0 + rl;
+    for (; p + 3 * step < p1; p += 4 * step) {
+      const float* xp = a.x + p * rs4 + q * 4;
+      const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + step * rs4),
+                   v2 = *reinterpret_cast<const float4*>(xp + 2 * step * rs4), v3 = *reinterpret_cast<const float4*>(xp + 3 * step * rs4);
+      float4 d0 = v0, d1 = v0, d2 = v0, d3 = v0;
+      if (MODE == 1) {
+        const float* dp = a.dz + p * rs4 + q * 4;
+        d0 = *reinterpret_cast<const float4*>(dp); d1 = *reinterpret_cast<const float4*>(dp + step * rs4);
+        d2 = *reinterpret_cast<const float4*>(dp + 2 * step * rs4); d3 = *reinterpret_cast<const float4*>(dp + 3 * step * rs4);
+      }
+      fold(v0, d0); fold(v1, d1); fold(v2, d2); fold(v3, d3);
+    }
+    for (; p < p1; p += step) {
+      const float4 v = *reinterpret_cast<const float4*>(a.x + p * rs4 + q * 4);
+      float4 d = v;
+      if (MODE == 1) d = *reinterpret_cast<const float4*>(a.dz + p * rs4 + q * 4);
+      fold(v, d);
     }
   }
-  __shared__ double sm[2][256];
-  sm[0][threadIdx.x] = s0; sm[1][threadIdx.x] = s1;
-  __syncthreads();
-  if (rl == 0 && c < C) {
-    const int l = threadIdx.x;
-    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = sm[0][l] + sm[0][l + 64] + sm[0][l + 128] + sm[0][l + 192];
-    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = sm[1][l] + sm[1][l + 64] + sm[1][l + 128] + sm[1][l + 192];
+  __shared__ double sm[256];
+  for (int k = 0; k < 8; ++k) {
+    __syncthreads();
+    sm[threadIdx.x] = k < 4 ? s0[k] : s1[k - 4];
+    __syncthreads();
+    if (rl == 0 && q < cq) {
+      double t = 0;
+      for (int r = 0; r < RL; ++r) t += sm[threadIdx.x + (r << a.ql)];
+      a.partial[((size_t)blockIdx.x * 2 + (k >> 2)) * a.C + q * 4 + (k & 3)] = t;
+    }
   }
+}
+
+// sum of the nchunk partials of one channel: a block = 16 channels x 16 lanes (the partial rows are read 128 bytes at a time, sixteen
+// rows in flight); valid in the lanes with threadIdx.x < 16 afterwards
+__device__ __forceinline__ void chunk_sums(const double* __restrict__ partial, int nchunk, int C, int c, double& s0, double& s1) {
+  __shared__ double sm[2][256];
+  const int lane = threadIdx.x >> 4;
+  double a = 0, b = 0;
+  if (c < C)
+    for (int k = lane; k < nchunk; k += 16) { a += partial[((size_t)k * 2) * C + c]; b += partial[((size_t)k * 2 + 1) * C + c]; }
+  sm[0][threadIdx.x] = a; sm[1][threadIdx.x] = b;
+  __syncthreads();
+  s0 = 0; s1 = 0;
+  if (threadIdx.x < 16)
+    for (int l = 0; l < 16; ++l) { s0 += sm[0][threadIdx.x + 16 * l]; s1 += sm[1][threadIdx.x + 16 * l]; }
 }
 
 // forward finalize: mean, biased variance, rstd = 1/sqrt(var + eps), scale = rstd, shift = beta - mean * rstd
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nchunk, size_t P, int C, const float* __restrict__ beta,
                                                               float eps, float* mean, float* var, float* rstd, float* scale, float* shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0, s1 = 0;
-  for (int k = 0; k < nchunk; ++k) { s0 += partial[((size_t)k * 2) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s0, s1;
+  chunk_sums(partial, nchunk, C, c, s0, s1);
+  if (c >= C || threadIdx.x >= 16) return;
   const double m = s0 / (double)P;
   double v = s1 / (double)P - m * m;
   if (v < 0) v = 0;
@@ -67,24 +128,31 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __re
 // backward finalize: c1 = mean(dz), c2 = mean(dz * xhat); dbeta = sum dz
 __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const double* __restrict__ partial, int nchunk, size_t P, int C, float* c1, float* c2,
                                                                float* dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0, s1 = 0;
-  for (int k = 0; k < nchunk; ++k) { s0 += partial[((size_t)k * 2) * C + c]; s1 += partial[((size_t)k * 2 + 1) * C + c]; }
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s0, s1;
+  chunk_sums(partial, nchunk, C, c, s0, s1);
+  if (c >= C || threadIdx.x >= 16) return;
   c1[c] = (float)(s0 / (double)P); c2[c] = (float)(s1 / (double)P); dbeta[c] = (float)s0;
 }
 
-// dx = rstd * (dz - c1 - xhat * c2)       (no gamma: tf.contrib batch_norm scale=False)
+// dx = rstd * (dz - c1 - xhat * c2)       (no gamma: tf.contrib batch_norm scale=False); dz = da * act'(rstd * x + shift) when act != 0
 __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, const float* __restrict__ c1, const float* __restrict__ c2,
-                                                            size_t P, int C, float* __restrict__ dx) {
+                                                            const float* __restrict__ rstd, const float* __restrict__ shift, int act,
+                                                            const float* __restrict__ c1, const float* __restrict__ c2, size_t P, int C,
+                                                            float* __restrict__ dx) {
   const int cq = C >> 2;
   const size_t total = P * cq;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % cq) * 4;
-    const float4 xv = *reinterpret_cast<const float4*>(x + i * 4), dv = *reinterpret_cast<const float4*>(dz + i * 4);
+    const float4 xv = *reinterpret_cast<const float4*>(x + i * 4);
+    float4 dv = *reinterpret_cast<const float4*>(dz + i * 4);
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
     const float4 a = *reinterpret_cast<const float4*>(c1 + c), b = *reinterpret_cast<const float4*>(c2 + c);
+    if (act) {
+      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+      dv.x *= act_d(act, fmaf(rs.x, xv.x, sh.x)); dv.y *= act_d(act, fmaf(rs.y, xv.y, sh.y));
+      dv.z *= act_d(act, fmaf(rs.z, xv.z, sh.z)); dv.w *= act_d(act, fmaf(rs.w, xv.w, sh.w));
+    }
     float4 o;
     o.x = rs.x * (dv.x - a.x - (xv.x - mu.x) * rs.x * b.x); o.y = rs.y * (dv.y - a.y - (xv.y - mu.y) * rs.y * b.y);
     o.z = rs.z * (dv.z - a.z - (xv.z - mu.z) * rs.z * b.z); o.w = rs.w * (dv.w - a.w - (xv.w - mu.w) * rs.w * b.w);
@@ -139,45 +207,59 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // depthwise 7x3 weight gradient: dW[kh*3+kw][c] = sum_{b,h,w} x[b, h+kh-3, w+kw-1, c] * dy[b,h,w,c]
-// grid (G, ceil(C/64)); block = 4 lanes x 64 channels; a lane walks NP (b, w) columns, sliding a 7 x 3 window of x down the column
+// grid (G, ceil(C/64)); block = 4 waves x 64 channels; a wave walks work items (b, w, row segment of HS rows), sliding a 7 x 3 window
+// of x down the column with the next row's four loads in flight under the 21 FMAs of the current one
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dwconv7x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C,
-                                                              float* __restrict__ partial /*[G][21][C]*/) {
+__global__ __launch_bounds__(256) void dwconv7x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C, int HS,
+                                                              int nseg, float* __restrict__ partial /*[G][21][C]*/) {
   const int c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   float acc[21];
 #pragma unroll
   for (int k = 0; k < 21; ++k) acc[k] = 0.f;
-  const int ncol = B * W;
+  const int nitem = B * W * nseg;
   if (c < C) {
-    for (int col = blockIdx.x * 4 + rl; col < ncol; col += gridDim.x * 4) {
+    for (int item = blockIdx.x * 4 + rl; item < nitem; item += gridDim.x * 4) {
+      const int seg = item % nseg, col = item / nseg;
       const int b = col / W, w = col - b * W;
+      const int h0 = seg * HS, h1 = h0 + HS < H ? h0 + HS : H;
       const float* xb = x + ((size_t)b * H * W) * C + c;
       const float* db = dy + ((size_t)b * H * W) * C + c;
+      const bool wl = w > 0, wr = w + 1 < W;
       float win[7][3];      // win[r][kw] = x[h + r - 3][w + kw - 1] for the current h
 #pragma unroll
-      for (int r = 0; r < 7; ++r)
+      for (int kw = 0; kw < 3; ++kw) win[0][kw] = 0.f;
+      // state of "h0 - 1": win[r] = x[h0 + r - 4]; rows h0-3 .. h0+2 go to win[1..6]
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) win[r][kw] = 0.f;
-      // rows h-3 .. h+3: prime rows 0..2 into win[4..6] (h = -1 state), then slide
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int iw = w + kw - 1;
-          win[r + 4][kw] = (r < H && (unsigned)iw < (unsigned)W) ? xb[((size_t)r * W + iw) * C] : 0.f;
-        }
-      for (int h = 0; h < H; ++h) {
+      for (int r = 1; r < 7; ++r) {
+        const int ih = h0 + r - 4;
+        const bool ok = ih >= 0 && ih < H;
+        const float* row = xb + ((size_t)(ok ? ih : 0) * W + w) * C;
+        win[r][0] = (ok && wl) ? row[-C] : 0.f;
+        win[r][1] = ok ? row[0] : 0.f;
+        win[r][2] = (ok && wr) ? row[C] : 0.f;
+      }
+      float nx0, nx1, nx2, nd;
+      {
+        const int ih = h0 + 3;
+        const bool ok = ih < H;
+        const float* row = xb + ((size_t)(ok ? ih : 0) * W + w) * C;
+        nx0 = (ok && wl) ? row[-C] : 0.f; nx1 = ok ? row[0] : 0.f; nx2 = (ok && wr) ? row[C] : 0.f;
+        nd = db[((size_t)h0 * W + w) * C];
+      }
+      for (int h = h0; h < h1; ++h) {
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) win[r][kw] = win[r + 1][kw];
-        const int ih = h + 3;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int iw = w + kw - 1;
-          win[6][kw] = (ih < H && (unsigned)iw < (unsigned)W) ? xb[((size_t)ih * W + iw) * C] : 0.f;
+        win[6][0] = nx0; win[6][1] = nx1; win[6][2] = nx2;
+        const float d = nd;
+        if (h + 1 < h1) {
+          const int ih = h + 4;
+          const bool ok = ih < H;
+          const float* row = xb + ((size_t)(ok ? ih : 0) * W + w) * C;
+          nx0 = (ok && wl) ? row[-C] : 0.f; nx1 = ok ? row[0] : 0.f; nx2 = (ok && wr) ? row[C] : 0.f;
+          nd = db[((size_t)(h + 1) * W + w) * C];
         }
-        const float d = db[((size_t)h * W + w) * C];
 #pragma unroll
         for (int r = 0; r < 7; ++r)
 #pragma unroll
@@ -194,13 +276,23 @@ __global__ __launch_bounds__(256) void dwconv7x3_wgrad_kernel(const float* __res
   }
 }
 
-// out[i] = sum_g partial[g][i]
+// out[i] = sum_g partial[g][i]; a block = 64 outputs x 4 lanes over g
 __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ partial, int G, size_t n, float* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += partial[(size_t)g * n + i];
-    out[i] = s;
+  const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int lane = threadIdx.x >> 6;
+  float s = 0.f;
+  if (i < n) {
+    int g = lane;
+    for (; g + 12 < G; g += 16) {
+      const float a = partial[(size_t)g * n + i], b = partial[(size_t)(g + 4) * n + i], c = partial[(size_t)(g + 8) * n + i], d = partial[(size_t)(g + 12) * n + i];
+      s += (a + b) + (c + d);
+    }
+    for (; g < G; g += 4) s += partial[(size_t)g * n + i];
   }
+  __shared__ float sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (lane == 0 && i < n) out[i] = (sm[threadIdx.x] + sm[threadIdx.x + 64]) + (sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,43 +475,116 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
 
+// ------------------------------------------------------------------------------------------------
+// tf.clip_by_global_norm + tf.train.AdamOptimizer over a flat arena with the step scalars on the DEVICE (so a captured hipGraph of the
+// whole step replays with a new learning rate / step count): g *= clip / max(sqrt(*sumsq), clip), written back, then
+// theta -= *lr_t * m / (sqrt(v) + eps)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
+                                                        const float* __restrict__ lr_t, const double* __restrict__ sumsq, float clip, float b1, float b2,
+                                                        float eps) {
+  const float scale = (float)((double)clip / fmax(sqrt(*sumsq), (double)clip)), lr = *lr_t;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 gv = *reinterpret_cast<float4*>(g + i * 4), mv = *reinterpret_cast<float4*>(m + i * 4), vv = *reinterpret_cast<float4*>(v + i * 4),
+           pv = *reinterpret_cast<float4*>(p + i * 4);
+    float* G = &gv.x; float* M = &mv.x; float* V = &vv.x; float* Pp = &pv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = G[k] * scale;
+      G[k] = gg;
+      M[k] = b1 * M[k] + (1.f - b1) * gg;
+      V[k] = b2 * V[k] + (1.f - b2) * gg * gg;
+      Pp[k] -= lr * M[k] / (sqrtf(V[k]) + eps);
+    }
+    *reinterpret_cast<float4*>(g + i * 4) = gv; *reinterpret_cast<float4*>(m + i * 4) = mv;
+    *reinterpret_cast<float4*>(v + i * 4) = vv; *reinterpret_cast<float4*>(p + i * 4) = pv;
+  }
+}
+
+// moving = decay * moving + factor[i] * batch[i]   (every batch-norm's moving mean / variance in one pass; factor folds 1 - decay and the
+// n / (n - 1) of the variance slots)
+__global__ __launch_bounds__(256) void moving_update_kernel(float* __restrict__ moving, const float* __restrict__ batch, const float* __restrict__ factor,
+                                                            size_t n, float decay) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) moving[i] = decay * moving[i] + factor[i] * batch[i];
+}
+
+// g += scale * mask[i] * p[i]  and  partial sums of mask * p^2 (the l2 regulariser's gradient and value over the flat arena)
+__global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ p, const float* __restrict__ mask, float* __restrict__ g, size_t n, float scale,
+                                                     double* __restrict__ partial) {
+  double acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float w = p[i] * mask[i];
+    g[i] = fmaf(scale, w, g[i]);
+    acc += (double)w * w;
+  }
+  __shared__ double sm[256];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
 }  // namespace vp
 
 using namespace vp;
 
 extern "C" {
 
-#define VP_NCHUNK(P) ((int)((P) < 4096 ? 1 : ((P) / 1024 > 512 ? 512 : (P) / 1024)))
+// launch shape of chan_sums_kernel for a [pixels, c] tensor: ql = log2 of the lanes across channel quads, nchunk row chunks
+static inline void bn_shape(size_t pixels, int c, int& ql, int& nch) {
+  const int cq = c / 4;
+  ql = 3;
+  while (ql < 6 && (1 << ql) < cq) ++ql;
+  const size_t rl = 256 >> ql;
+  size_t n = pixels / (rl * 8);
+  nch = (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+}
 
 // workspace (bytes) of vp_bn_train_fwd / vp_bn_train_bwd for a [pixels, c] tensor
-size_t vp_bn_train_workspace_bytes(size_t pixels, int c) { return (size_t)VP_NCHUNK(pixels) * 2 * c * sizeof(double) + 2 * (size_t)c * sizeof(float) + 256; }
+size_t vp_bn_train_workspace_bytes(size_t pixels, int c) {
+  int ql, nch;
+  bn_shape(pixels, c, ql, nch);
+  return (size_t)nch * 2 * c * sizeof(double) + 2 * (size_t)c * sizeof(float) + 256;
+}
 
 // tf.contrib.layers.batch_norm(is_training=True, scale=False): batch statistics of x [pixels, c]; y = x * scale + shift normalises
 int vp_bn_train_fwd(const float* x, size_t pixels, int c, const float* beta, float eps, float* mean, float* var, float* rstd, float* scale,
                     float* shift, void* workspace, void* stream) {
   if (!x || !beta || !mean || !var || !rstd || !scale || !shift || !workspace || pixels < 1 || c < 4 || c % 4) { set_err("vp_bn_train_fwd: bad argument"); return VP_ERR_ARG; }
-  const int nch = VP_NCHUNK(pixels);
+  int ql, nch;
+  bn_shape(pixels, c, ql, nch);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((chan_sums_kernel<0>), dim3(nch, (c + 63) / 64), dim3(256), 0, st, x, nullptr, nullptr, nullptr, pixels, c, (double*)workspace);
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, st, (const double*)workspace, nch, pixels, c, beta, eps, mean, var, rstd, scale, shift);
+  ChanSumsArgs a{x, nullptr, nullptr, nullptr, nullptr, pixels, c, ql, 0, (double*)workspace};
+  hipLaunchKernelGGL((chan_sums_kernel<0>), dim3(nch, (c / 4 + (1 << ql) - 1) >> ql), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((c + 15) / 16), dim3(256), 0, st, (const double*)workspace, nch, pixels, c, beta, eps, mean, var, rstd, scale, shift);
   VP_HIP_CHECK(hipGetLastError());
   return VP_OK;
 }
 
-// backward of the same: dz = d loss / d (normalised + beta) -> dx (may alias dz), dbeta
-int vp_bn_train_bwd(const float* x, const float* dz, size_t pixels, int c, const float* mean, const float* rstd, float* dx, float* dbeta,
-                    void* workspace, void* stream) {
-  if (!x || !dz || !mean || !rstd || !dx || !dbeta || !workspace || pixels < 1 || c < 4 || c % 4) { set_err("vp_bn_train_bwd: bad argument"); return VP_ERR_ARG; }
-  const int nch = VP_NCHUNK(pixels);
+// backward of batch_norm followed by an activation: da = d loss / d act(normalised + beta) -> dx (may alias da), dbeta.  act 0: da is the
+// gradient at the batch-norm output itself (shift may be null); otherwise dz = da * act'(rstd * x + shift) is formed on the fly in both
+// passes (shift = beta - mean * rstd as vp_bn_train_fwd returned it).
+int vp_bn_act_train_bwd(const float* x, const float* da, size_t pixels, int c, const float* mean, const float* rstd, const float* shift, int act,
+                        float* dx, float* dbeta, void* workspace, void* stream) {
+  if (!x || !da || !mean || !rstd || !dx || !dbeta || !workspace || (act && !shift) || pixels < 1 || c < 4 || c % 4) { set_err("vp_bn_act_train_bwd: bad argument"); return VP_ERR_ARG; }
+  int ql, nch;
+  bn_shape(pixels, c, ql, nch);
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)workspace;
   float* c1 = (float*)((char*)workspace + (size_t)nch * 2 * c * sizeof(double));
   float* c2 = c1 + c;
-  hipLaunchKernelGGL((chan_sums_kernel<1>), dim3(nch, (c + 63) / 64), dim3(256), 0, st, x, dz, mean, rstd, pixels, c, part);
-  hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((c + 255) / 256), dim3(256), 0, st, (const double*)part, nch, pixels, c, c1, c2, dbeta);
-  hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(tblk(pixels * (c / 4))), dim3(256), 0, st, x, dz, mean, rstd, c1, c2, pixels, c, dx);
+  ChanSumsArgs a{x, da, mean, rstd, shift, pixels, c, ql, act, part};
+  hipLaunchKernelGGL((chan_sums_kernel<1>), dim3(nch, (c / 4 + (1 << ql) - 1) >> ql), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((c + 15) / 16), dim3(256), 0, st, (const double*)part, nch, pixels, c, c1, c2, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(tblk(pixels * (c / 4))), dim3(256), 0, st, x, da, mean, rstd, shift, act, c1, c2, pixels, c, dx);
   VP_HIP_CHECK(hipGetLastError());
   return VP_OK;
+}
+
+// the same without a following activation
+int vp_bn_train_bwd(const float* x, const float* dz, size_t pixels, int c, const float* mean, const float* rstd, float* dx, float* dbeta,
+                    void* workspace, void* stream) {
+  return vp_bn_act_train_bwd(x, dz, pixels, c, mean, rstd, nullptr, 0, dx, dbeta, workspace, stream);
 }
 
 // y = act(scale[c] * x + shift[c]) * mask   (scale / shift and mask may be null); act: 0 none, 1 leaky-relu(0.2), 2 relu, 5 relu6
@@ -445,17 +610,31 @@ int vp_dwconv7x3_raw(const float* x, const float* w, float* y, int b, int h, int
   return VP_OK;
 }
 
-size_t vp_dwconv7x3_wgrad_workspace_bytes(int b, int wd, int c) {
-  int g = (b * wd + 31) / 32; if (g < 1) g = 1; if (g > 256) g = 256;
+// work split of dwconv7x3_wgrad_kernel: row segments so that about 2048 (b, w, segment) items exist, G blocks of 4 items each
+static inline void dw_wgrad_shape(int b, int h, int wd, int& hs, int& nseg, int& g) {
+  const int cols = b * wd;
+  nseg = (2048 + cols - 1) / cols;
+  const int most = h / 8 > 0 ? h / 8 : 1;
+  if (nseg > most) nseg = most;
+  hs = (h + nseg - 1) / nseg;
+  nseg = (h + hs - 1) / hs;
+  g = (cols * nseg + 3) / 4;
+  if (g > 256) g = 256;
+}
+
+size_t vp_dwconv7x3_wgrad_workspace_bytes(int b, int h, int wd, int c) {
+  int hs, nseg, g;
+  dw_wgrad_shape(b, h, wd, hs, nseg, g);
   return (size_t)g * 21 * c * sizeof(float);
 }
 // dw [21][c]
 int vp_dwconv7x3_wgrad(const float* x, const float* dy, float* dw, int b, int h, int wd, int c, void* workspace, void* stream) {
   if (!x || !dy || !dw || !workspace || b < 1 || h < 1 || wd < 1 || c < 4) { set_err("vp_dwconv7x3_wgrad: bad argument"); return VP_ERR_ARG; }
-  int g = (b * wd + 31) / 32; if (g < 1) g = 1; if (g > 256) g = 256;
+  int hs, nseg, g;
+  dw_wgrad_shape(b, h, wd, hs, nseg, g);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(dwconv7x3_wgrad_kernel, dim3(g, (c + 63) / 64), dim3(256), 0, st, x, dy, b, h, wd, c, (float*)workspace);
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(tblk((size_t)21 * c)), dim3(256), 0, st, (const float*)workspace, g, (size_t)21 * c, dw);
+  hipLaunchKernelGGL(dwconv7x3_wgrad_kernel, dim3(g, (c + 63) / 64), dim3(256), 0, st, x, dy, b, h, wd, c, hs, nseg, (float*)workspace);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((21 * c + 63) / 64), dim3(256), 0, st, (const float*)workspace, g, (size_t)21 * c, dw);
   VP_HIP_CHECK(hipGetLastError());
   return VP_OK;
 }
@@ -511,6 +690,32 @@ int vp_sumsq_partials(size_t n) { return tblk(n, 1024); }
 int vp_sumsq(const float* x, size_t n, double* partial, void* stream) {
   if (!x || !partial || n < 1) { set_err("vp_sumsq: bad argument"); return VP_ERR_ARG; }
   hipLaunchKernelGGL(sumsq_kernel, dim3(tblk(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, partial);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// clip_by_global_norm + AdamOptimizer, step scalars on the device: *sumsq = the squared global norm, *lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t).
+// grads are scaled in place (they hold the clipped gradients afterwards); n % 4 == 0 and 16-byte aligned arenas
+int vp_adam_tf_clipped(float* params, float* grads, float* m, float* v, size_t n, const float* lr_t, const double* sumsq, float clip, float beta1,
+                       float beta2, float eps, void* stream) {
+  if (!params || !grads || !m || !v || !lr_t || !sumsq || n < 4 || n % 4 || !(clip > 0)) { set_err("vp_adam_tf_clipped: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(tblk(n / 4)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n / 4, lr_t, sumsq, clip, beta1, beta2, eps);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// moving[i] = decay * moving[i] + factor[i] * batch[i]
+int vp_moving_update(float* moving, const float* batch, const float* factor, size_t n, float decay, void* stream) {
+  if (!moving || !batch || !factor || n < 1) { set_err("vp_moving_update: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(moving_update_kernel, dim3(tblk(n)), dim3(256), 0, (hipStream_t)stream, moving, batch, factor, n, decay);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// l2 regulariser over a flat arena: grads += scale * mask * params; partial[vp_sumsq_partials(n)] (f64) sums to sum(mask * params^2)
+int vp_l2_regulariser(const float* params, const float* mask, float* grads, size_t n, float scale, double* partial, void* stream) {
+  if (!params || !mask || !grads || !partial || n < 1) { set_err("vp_l2_regulariser: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(l2_reg_kernel, dim3(tblk(n, 1024)), dim3(256), 0, (hipStream_t)stream, params, mask, grads, n, scale, partial);
   VP_HIP_CHECK(hipGetLastError());
   return VP_OK;
 }
