@@ -51,6 +51,7 @@ def parse_args(argv=None):
   ap.add_argument("--no-f32", action="store_true")
   ap.add_argument("--no-other-scaling", action="store_true")
   ap.add_argument("--no-input-pipeline", action="store_true")
+  ap.add_argument("--no-bfmnet-train", action="store_true", help="skip the BFMNet training-step sub-record (SURVEY.md 8f-4)")
   ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="vp_tune knob for experiments (repeatable)")
   return ap.parse_args(argv)
 
@@ -171,6 +172,55 @@ def cpu_baseline(h, ngf=64, ndf=64, cap_s=20.0):
                     "(oracle/pixrefer_ref.py) at the reference's batch 2, torch-CPU/oneDNN restatement (oracle/pixrefer_torch.py) "
                     "at batch 2 and 32, each after warm-up; value = the fastest of them (%s)" % (h, h, ngf, cores, best),
           "runs": out}
+
+
+def cpu_baseline_bfmnet_train(w, ex, vm, ears, mfccs, coeff, seq):
+  """ONE step of the float64 torch restatement of BFMNet.build_train_op (oracle/bfmnet_train_torch.py) on the host cores."""
+  import numpy as np
+  import torch
+  from oracle import bfmnet_train_torch as bt
+  torch.set_num_threads(min(usable_cores(), 64))
+  model = {"idBase": np.zeros((ex.shape[0], 80)), "exBase": ex, "meanshape": np.zeros(ex.shape[0]), "vmask": vm.reshape(-1)}
+  t0 = time.perf_counter()
+  bt.train_step(w, None, ears, mfccs, coeff, seq, {}, model)
+  s = time.perf_counter() - t0
+  return {"value": len(seq) / s, "unit": "clips/s", "cores": usable_cores(), "kind": "port",
+          "sample": "1 step of the float64 torch-CPU restatement at the same batch (%.1f s)" % s}
+
+
+def bfmnet_train_record(device, with_cpu, steps=30, batch=4, frames=24, nver=35709):
+  """SURVEY.md 8f-4 beside the headline: one BFMNet build_train_op step at the reference's batch (train_bfmnet.py:46: 4 clips of 24
+  frames, 35709-vertex face model, dropout on), replayed from its hipGraph; the CPU leg is ONE step of the float64 torch restatement
+  (oracle/bfmnet_train_torch.py) on the host cores."""
+  import numpy as np
+  import torch
+  from voicepuppet_amd.bfmnet.bfmnet import random_variables
+  from voicepuppet_amd.bfmnet.train_engine import BFMNetTrainEngine
+  rng = np.random.default_rng(0)
+  vm = np.ones((nver, 3), np.float32)
+  vm[rng.choice(nver, nver // 20, replace=False)] = 10
+  ex = rng.normal(0, 0.05, (3 * nver, 64)).astype(np.float32)
+  eng = BFMNetTrainEngine(batch, frames, {"exBase": ex, "vmask": vm.reshape(-1)})
+  w = random_variables(0)
+  eng.load_params(w)
+  ears = torch.rand(batch, frames, 1, device=device)
+  mfccs = torch.randn(batch, 5 * frames, 80, device=device)
+  coeff = torch.randn(batch, frames, 257, device=device) * 0.5
+  seq = [frames] * batch
+  for _ in range(5):
+    eng.train_step_graphed(ears, mfccs, coeff, seq, 0.25)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    eng.train_step_graphed(ears, mfccs, coeff, seq, 0.25)
+  torch.cuda.synchronize()
+  ms = (time.perf_counter() - t0) / steps * 1e3
+  rec = {"metric": "BFMNet training step clips/sec", "value": batch / ms * 1e3, "unit": "clips/s", "ms_per_step": ms, "steps": steps, "dtype": "f32",
+         "config": {"workload": "BFMNet build_train_op: fwd + vertex-space loss + bwd + clip + Adam, hipGraph replay", "batch": batch,
+                    "frames": frames, "vertices": nver, "dropout": True}}
+  if with_cpu:
+    rec["cpu_baseline"] = cpu_baseline_bfmnet_train(w, ex, vm, ears.cpu().numpy(), mfccs.cpu().numpy(), coeff.cpu().numpy(), seq)
+  return rec
 
 
 # ---- one measured configuration on this rank -----------------------------------------------------------------------------
@@ -325,6 +375,10 @@ def main():
   if world == 1 and not args.no_input_pipeline:
     pcie = run_with_input_pipeline(per_gpu_batch(args, args.scaling, world), args.height, args.dtype, max(5, args.steps // 2), 3, device)
 
+  f4 = None
+  if world == 1 and not args.no_bfmnet_train:
+    f4 = bfmnet_train_record(device, not args.no_cpu_baseline)
+
   if rank == 0:
     n, h = main_res["per_gpu_batch"], args.height
     out = {"metric": "PixReferNet G+D step frames/sec @256x256 bs=32", "value": main_res["frames_per_s"], "unit": "frames/s",
@@ -341,6 +395,8 @@ def main():
       out["f32"] = f32
     if pcie is not None:
       out["with_input_pipeline"] = pcie
+    if f4 is not None:
+      out["bfmnet_train"] = f4
     if not args.no_cpu_baseline and world == 1:
       out["cpu_baseline"] = cpu_baseline(args.height)
     print(json.dumps(out), flush=True)

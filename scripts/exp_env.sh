@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 o=gpurun_out/envsweep; mkdir -p $o
 run() {
   for gb in 32 4; do
-    env "$@" timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-input-pipeline --no-profile --global-batch $gb > $o/b.json 2> $o/b.err
+    env "$@" timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-input-pipeline --no-bfmnet-train --no-profile --global-batch $gb > $o/b.json 2> $o/b.err
     python -c "
 import json;d=json.load(open('$o/b.json'));print('$* bs$gb',d['ms_per_step'])"
   done

@@ -8,6 +8,6 @@ timeout 900 python -m pytest tests/test_gpu_step.py tests/test_gpu_fullwidth.py 
 grep -E "passed|failed" $o/pytest_step.log
 timeout 300 python scripts/layer_profile.py 32 256 bf16 > $o/layers.txt 2>&1
 grep "conv total" $o/layers.txt; grep "wgrad" $o/layers.txt | head -30
-timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-input-pipeline --no-profile > $o/bench.json 2> $o/bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-input-pipeline --no-bfmnet-train --no-profile > $o/bench.json 2> $o/bench.err
 python -c "
 import json;d=json.load(open('$o/bench.json'));print(d['ms_per_step'])"

@@ -5,6 +5,6 @@ export TMPDIR=/tmp
 o=gpurun_out/kstats
 rm -rf $o; mkdir -p $o
 if [ "$1" != "on" ]; then export VP_NO_OVERLAP=1; fi
-rocprofv3 --kernel-trace --stats -d $o/r -o r --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline > $o/r.log 2>&1
+rocprofv3 --kernel-trace --stats -d $o/r -o r --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline --no-bfmnet-train > $o/r.log 2>&1
 rm -f $o/r/*kernel_trace.csv
 python3 scripts/kstats_summary.py $o/r/r_kernel_stats.csv 13

@@ -150,7 +150,7 @@ def test_angle_sequence_follows_render_face_state_machine():
 
 
 def test_product_path_never_imports_the_oracle():
-  """oracle/ is test infrastructure: the package and the launchers must not import it, bench.py only inside cpu_baseline()."""
+  """oracle/ is test infrastructure: the package and the launchers must not import it, bench.py only inside its cpu_baseline*() legs."""
   import ast
   import glob
   import os
@@ -172,8 +172,8 @@ def test_product_path_never_imports_the_oracle():
   for f in files:
     assert not oracle_imports(f)[1], f
   tree, hits = oracle_imports(os.path.join(root, "bench.py"))
-  fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline"][0]
-  assert hits and all(fn.lineno <= h <= fn.end_lineno for h in hits), hits
+  fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name.startswith("cpu_baseline")]
+  assert hits and all(any(fn.lineno <= h <= fn.end_lineno for fn in fns) for h in hits), hits
 
 
 def test_pmc_kernel_classifier():
