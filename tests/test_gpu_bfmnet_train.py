@@ -126,3 +126,29 @@ def test_graphed_step_equals_eager_step():
   assert a.step_t == b.step_t == 3
   losses = {b.train_step_graphed(ears, mfccs, coeff, seq, 0.25)["loss"] for _ in range(3)}
   assert len(losses) == 3 and all(np.isfinite(l) for l in losses)
+
+
+def test_tuned_gemm_table_loads_and_matches_default_solutions():
+  """The shipped TunableOp table is accepted by this ROCm build and the step it selects solutions for agrees with the default-solution
+  step to float32 reassociation noise."""
+  from voicepuppet_amd.bfmnet import train_engine as te
+  from voicepuppet_amd.bfmnet.bfmnet import random_variables
+  B, T = 4, 24
+  rng = np.random.default_rng(9)
+  model = bt.synthetic_model(500, 3)
+  args = (torch.tensor(rng.uniform(0.1, 0.4, (B, T, 1)), dtype=torch.float32, device="cuda"),
+          torch.tensor(rng.normal(0, 1, (B, 5 * T, 80)), dtype=torch.float32, device="cuda"),
+          torch.tensor(rng.normal(0, 0.5, (B, T, 257)), dtype=torch.float32, device="cuda"), [T, T - 3, T, 5])
+  w = random_variables(2)
+  torch.cuda.tunable.enable(False)
+  a = BFMNetTrainEngine(B, T, {"exBase": model["exBase"], "vmask": model["vmask"]}, tuned_gemms=False)
+  a.load_params(w)
+  ra = a.train_step(*args, apply=False)
+  b = BFMNetTrainEngine(B, T, {"exBase": model["exBase"], "vmask": model["vmask"]})
+  assert b.tuned_gemms and torch.cuda.tunable.is_enabled() and not torch.cuda.tunable.tuning_is_enabled()
+  b.load_params(w)
+  rb = b.train_step(*args, apply=False)
+  assert ra["loss"] == pytest.approx(rb["loss"], rel=1e-5) and ra["global_norm"] == pytest.approx(rb["global_norm"], rel=1e-3)
+  ga, gb = a.grads, b.grads
+  assert float((ga - gb).norm() / ga.norm()) < 2e-2
+  torch.cuda.tunable.enable(False)

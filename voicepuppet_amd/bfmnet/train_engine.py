@@ -18,6 +18,7 @@ The step's shapes are static, so `train_step_graphed` captures the ~900 launches
 once and replays it: the per-step host work is four small copies into the graph's input buffers and one read of three scalars."""
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -55,13 +56,31 @@ def regularised(name):
   return "MfccNet" in name and (name.endswith("/kernel") or name.endswith("depthwise_weights"))
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning", "gfx950_batch4_batch32.csv")
+
+
+def use_tuned_gemms(path=TUNED_GEMMS):
+  """The step's ~170 f32 GEMMs are skinny (K = 32 ... 256 against 10^4 ... 10^5 rows) and rocBLAS's default heuristic picks solutions
+  that run at a third of the f32 MFMA peak; PyTorch's TunableOp looks each shape up in a results file (rocBLAS / hipBLASLt solution per
+  shape, searched once on an MI355X by scripts/tune_bfmnet_gemms.sh for the 24-frame clips at batch 4 and 32: 9.4 -> 7.9 ms and
+  31.8 -> 23.1 ms per step).  Shapes that are not in the file, or a file written for another ROCm build (its validator lines do not
+  match), fall back to the default solutions.  Process-wide: TunableOp is a torch global."""
+  if os.environ.get("VP_NO_TUNED_GEMMS") or not os.path.exists(path):
+    return False
+  tun = torch.cuda.tunable
+  tun.enable(True)
+  tun.tuning_enable(False)
+  return bool(tun.read_file(path))
+
+
 class BFMNetTrainEngine:
-  def __init__(self, batch, frames, model, lr=1e-4, max_grad_norm=50.0, num_mel_bins=80):
+  def __init__(self, batch, frames, model, lr=1e-4, max_grad_norm=50.0, num_mel_bins=80, tuned_gemms=True):
     """model: dict with exBase [3n,64] and vmask [3n] (the mouth-weighted vertex mask of bfmnet.py:131-134); idBase / meanshape cancel in
     every term of the loss (both face shapes share the identity coefficients) and are not needed on the device."""
     if not torch.cuda.is_available():
       raise RuntimeError("BFMNetTrainEngine needs an MI355X (no CPU fallback)")
     self.L = _lib.lib()
+    self.tuned_gemms = use_tuned_gemms() if tuned_gemms else False
     self.B, self.T, self.W0 = batch, frames, num_mel_bins
     self.lr, self.clip = lr, max_grad_norm
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -101,6 +120,25 @@ class BFMNetTrainEngine:
     self.ears_scale = torch.tensor([-2.0, -2.0, -2.0, -4.0], device=dev)
     self._ws = {}
     self._graphs = {}
+
+  def tune_gemms(self, ears, mfccs, bfm_coeffs, seq_len, path, max_ms_per_shape=20):
+    """Search the GEMM solutions for THIS batch / clip length (one gradient-only step with TunableOp's tuning on, a few minutes) and
+    write them to `path` in TunableOp's format; later engines pick them up with use_tuned_gemms(path)."""
+    tun = torch.cuda.tunable
+    tun.enable(True)
+    tun.set_max_tuning_duration(max_ms_per_shape)
+    tun.tuning_enable(True)
+    try:
+      self.train_step(ears, mfccs, bfm_coeffs, seq_len, apply=False)
+      torch.cuda.synchronize()
+    finally:
+      tun.tuning_enable(False)
+    with open(path, "w") as f:                                                     # TunableOp's own CSV layout
+      for k, v in tun.get_validators():
+        f.write("Validator,%s,%s\n" % (k, v))
+      for row in tun.get_results():
+        f.write(",".join(str(x) for x in row) + "\n")
+    return path
 
   # ---- parameters -----------------------------------------------------------------------------------------------------------
   def load_params(self, params):
