@@ -83,57 +83,84 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 }
 
 // depthwise 7x3 stride 1 SAME + folded BN + relu6     (tinynet.py:84-103)
-// A thread owns 4 channels of a column strip of RH = 8 consecutive output rows: the 21 taps live in registers and the (RH + 6) x 3
-// input pixels of the strip are loaded once each (5 loads per output instead of 21 + 21 weight loads: the pass was load-issue
-// bound).  Per output the products are still accumulated bias first, then kh = 0..6, kw = 0..2 (same sums as a per-pixel loop).
+// A thread owns 4 channels of one image column and walks a segment of HS output rows DOWN the column: the 21 taps live in registers,
+// every input row of the segment (+ 3 halo rows either side) is loaded once (3 pixels: w-1, w, w+1) and scattered into a rotating
+// window of 7 output accumulators (output q completes when input row q + 6 of the segment has been folded in, is stored and its
+// slot restarts from the bias).  The row loop is unrolled by 7 so that slot and ring indices are compile-time.  Loads are
+// branch-free (out-of-image rows / columns read a clamped, valid address and are multiplied by 0) and run PF rows ahead of the
+// FMAs through a register ring.  History: round 1 used 8-row strips and tested every pixel with a branch - the compiler drained
+// vmcnt to 0 after each load (one 1 KB load in flight per wave, 0.27 of HBM; r02 ISA: 64 loads, 43 s_waitcnt vmcnt(0)) and the 6
+// halo rows of every 8-row strip were re-read (1.75x).  Per output the products are accumulated bias first, then kh = 0..6,
+// kw = 0..2 (the same sums as a per-pixel loop; padding contributes exact zeros).
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv7x3_kernel(const T* __restrict__ x, const float* __restrict__ w /*[21][C]*/,
-                                                        const float* __restrict__ bias, T* __restrict__ y, int B, int H, int W, int C) {
-  constexpr int RH = 8;
-  const int cq = C >> 2, hb = (H + RH - 1) / RH;
-  const size_t total = (size_t)B * hb * W * cq;
+                                                        const float* __restrict__ bias, T* __restrict__ y, int B, int H, int W, int C, int HS,
+                                                        int nseg) {
+  constexpr int PF = 3;
+  const int cq = C >> 2;
+  const size_t total = (size_t)B * nseg * W * cq;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c4 = (int)(i % cq) * 4;
     size_t t = i / cq;
     const int ow = (int)(t % W); t /= W;
-    const int oh0 = (int)(t % hb) * RH;
-    const int b = (int)(t / hb);
+    const int h0 = (int)(t % nseg) * HS;
+    const int b = (int)(t / nseg);
+    const int hs = h0 + HS <= H ? HS : H - h0;         // output rows of this segment
     float4 wv[21];
 #pragma unroll
     for (int k = 0; k < 21; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (size_t)k * C + c4);
     // bias == nullptr: the raw convolution (training forward / backward-data, bfm_train.hip): no bias, no relu6
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 acc[RH];
+    float4 acc[7];
 #pragma unroll
-    for (int r = 0; r < RH; ++r) acc[r] = bv;
+    for (int r = 0; r < 7; ++r) acc[r] = bv;
+    const bool okl = ow > 0, okr = ow + 1 < W;
+    const T* xb = x + ((size_t)b * H) * W * C + c4;
+    T* yb = y + (((size_t)b * H + h0) * W + ow) * C + c4;
+    const size_t ol = (size_t)(okl ? ow - 1 : ow) * C, oc = (size_t)ow * C, orr = (size_t)(okr ? ow + 1 : ow) * C;
+    const size_t rowstride = (size_t)W * C;
+    float4 ring[7][3];
+    auto loadrow = [&](int rel, float4 (&r)[3]) {      // input row h0 - 3 + rel
+      int ih = h0 - 3 + rel;
+      ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+      const T* rp = xb + (size_t)ih * rowstride;
+      r[0] = ld4<T>(rp + ol); r[1] = ld4<T>(rp + oc); r[2] = ld4<T>(rp + orr);
+    };
 #pragma unroll
-    for (int j = 0; j < RH + 6; ++j) {
-      const int ih = oh0 + j - 3;
-      if ((unsigned)ih >= (unsigned)H) continue;
+    for (int j = 0; j < PF; ++j) loadrow(j, ring[j]);
+    const int nrows = hs + 6;
+    for (int k7 = 0; k7 < nrows; k7 += 7) {
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int iw = ow + kw - 1;
-        if ((unsigned)iw >= (unsigned)W) continue;
-        const float4 xv = ld4<T>(x + (((size_t)b * H + ih) * W + iw) * C + c4);
+      for (int u = 0; u < 7; ++u) {
+        const int rel = k7 + u;
+        loadrow(rel + PF, ring[(u + PF) % 7]);
+        const int ih = h0 - 3 + rel;
+        const bool okh = (unsigned)ih < (unsigned)H;
+        const float ml = (okh && okl) ? 1.f : 0.f, mc = okh ? 1.f : 0.f, mr = (okh && okr) ? 1.f : 0.f;
 #pragma unroll
-        for (int r = 0; r < RH; ++r) {
-          const int kh = j - r;                    // input row ih = (oh0 + r) + kh - 3
-          if (kh < 0 || kh > 6) continue;
-          const float4 ww = wv[kh * 3 + kw];
-          acc[r].x = fmaf(xv.x, ww.x, acc[r].x); acc[r].y = fmaf(xv.y, ww.y, acc[r].y);
-          acc[r].z = fmaf(xv.z, ww.z, acc[r].z); acc[r].w = fmaf(xv.w, ww.w, acc[r].w);
+        for (int kw = 0; kw < 3; ++kw) {
+          float4 xv = ring[u][kw];
+          const float m = kw == 0 ? ml : (kw == 1 ? mc : mr);
+          xv.x *= m; xv.y *= m; xv.z *= m; xv.w *= m;
+#pragma unroll
+          for (int kh = 0; kh < 7; ++kh) {             // output q = rel - kh lives in slot (u - kh) mod 7
+            const float4 ww = wv[kh * 3 + kw];
+            float4& a = acc[(u - kh + 7) % 7];
+            a.x = fmaf(xv.x, ww.x, a.x); a.y = fmaf(xv.y, ww.y, a.y); a.z = fmaf(xv.z, ww.z, a.z); a.w = fmaf(xv.w, ww.w, a.w);
+          }
+        }
+        // output q = rel - 6 is complete (slot (u + 1) mod 7): store it and restart the slot
+        const int q = rel - 6;
+        float4 a = acc[(u + 1) % 7];
+        acc[(u + 1) % 7] = bv;
+        if (q >= 0 && q < hs) {
+          if (bias) {
+            a.x = fminf(fmaxf(a.x, 0.f), 6.f); a.y = fminf(fmaxf(a.y, 0.f), 6.f);
+            a.z = fminf(fmaxf(a.z, 0.f), 6.f); a.w = fminf(fmaxf(a.w, 0.f), 6.f);
+          }
+          st4<T>(yb + (size_t)q * rowstride, a);
         }
       }
-    }
-#pragma unroll
-    for (int r = 0; r < RH; ++r) {
-      if (oh0 + r >= H) break;
-      float4 a = acc[r];
-      if (bias) {
-        a.x = fminf(fmaxf(a.x, 0.f), 6.f); a.y = fminf(fmaxf(a.y, 0.f), 6.f);
-        a.z = fminf(fmaxf(a.z, 0.f), 6.f); a.w = fminf(fmaxf(a.w, 0.f), 6.f);
-      }
-      st4<T>(y + (((size_t)b * H + oh0 + r) * W + ow) * C + c4, a);
     }
   }
 }
@@ -248,9 +275,17 @@ hipError_t launch_conv_first(const float* x, const float* w, const float* bias, 
   return hipGetLastError();
 }
 hipError_t launch_dwconv7x3(const void* x, const float* w, const float* bias, void* y, int is_bf16, int B, int H, int W, int C, hipStream_t st) {
-  const dim3 grid(nblk((size_t)B * ((H + 7) / 8) * W * (C / 4), 8192));
-  if (is_bf16) hipLaunchKernelGGL((dwconv7x3_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C);
-  else hipLaunchKernelGGL((dwconv7x3_kernel<float>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C);
+  // row segments per column: enough threads to fill the chip (>= ~128k), at least 8 rows each; a segment of HS rows reads HS + 6
+  const size_t cols = (size_t)B * W * (C / 4);
+  int nseg = (int)((131072 + cols - 1) / cols);
+  const int most = H / 8 > 0 ? H / 8 : 1;
+  if (nseg > most) nseg = most;
+  if (nseg < 1) nseg = 1;
+  const int hs = (H + nseg - 1) / nseg;
+  nseg = (H + hs - 1) / hs;
+  const dim3 grid(nblk(cols * nseg, 8192));
+  if (is_bf16) hipLaunchKernelGGL((dwconv7x3_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, hs, nseg);
+  else hipLaunchKernelGGL((dwconv7x3_kernel<float>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C, hs, nseg);
   return hipGetLastError();
 }
 hipError_t launch_maxpool_same(const void* x, void* y, int in_bf16, int out_bf16, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, hipStream_t st) {

@@ -207,11 +207,14 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // depthwise 7x3 weight gradient: dW[kh*3+kw][c] = sum_{b,h,w} x[b, h+kh-3, w+kw-1, c] * dy[b,h,w,c]
-// grid (G, ceil(C/64)); block = 4 waves x 64 channels; a wave walks work items (b, w, row segment of HS rows), sliding a 7 x 3 window
-// of x down the column with the next row's four loads in flight under the 21 FMAs of the current one
+// grid (G, ceil(C/64)); block = 4 waves x 64 channels; a wave walks work items (b, w, row segment of HS rows) down the column.  The
+// 7 x 3 window of x lives in a ring of U = 10 row slots (the 7 rows of the current output row + PF = 3 rows already requested), the
+// row loop is unrolled by U so every slot index is compile-time (no register shuffling), loads are branch-free (clamped address,
+// multiplied by 0 outside the image) - four 256-byte loads per row and wave, PF rows in flight.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dwconv7x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C, int HS,
                                                               int nseg, float* __restrict__ partial /*[G][21][C]*/) {
+  constexpr int U = 10, PF = 3;
   const int c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   float acc[21];
 #pragma unroll
@@ -221,49 +224,40 @@ __global__ __launch_bounds__(256) void dwconv7x3_wgrad_kernel(const float* __res
     for (int item = blockIdx.x * 4 + rl; item < nitem; item += gridDim.x * 4) {
       const int seg = item % nseg, col = item / nseg;
       const int b = col / W, w = col - b * W;
-      const int h0 = seg * HS, h1 = h0 + HS < H ? h0 + HS : H;
+      const int h0 = seg * HS, hs = h0 + HS <= H ? HS : H - h0;
+      const bool okl = w > 0, okr = w + 1 < W;
       const float* xb = x + ((size_t)b * H * W) * C + c;
-      const float* db = dy + ((size_t)b * H * W) * C + c;
-      const bool wl = w > 0, wr = w + 1 < W;
-      float win[7][3];      // win[r][kw] = x[h + r - 3][w + kw - 1] for the current h
+      const float* db = dy + (((size_t)b * H + h0) * W + w) * C + c;
+      const size_t ol = (size_t)(okl ? w - 1 : w) * C, oc = (size_t)w * C, orr = (size_t)(okr ? w + 1 : w) * C, rowstride = (size_t)W * C;
+      float ring[U][3], dring[U];
+      auto loadx = [&](int xrel, float (&r)[3]) {          // x row h0 - 3 + xrel
+        int ih = h0 - 3 + xrel;
+        const bool ok = (unsigned)ih < (unsigned)H;
+        ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+        const float* rp = xb + (size_t)ih * rowstride;
+        const float m = ok ? 1.f : 0.f;
+        r[0] = rp[ol] * (okl ? m : 0.f); r[1] = rp[oc] * m; r[2] = rp[orr] * (okr ? m : 0.f);
+      };
+      auto loadd = [&](int rel) {                          // dy row h0 + rel (0 beyond the segment)
+        const int rr = rel < hs ? rel : hs - 1;
+        return db[(size_t)rr * rowstride] * (rel < hs ? 1.f : 0.f);
+      };
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) win[0][kw] = 0.f;
-      // state of "h0 - 1": win[r] = x[h0 + r - 4]; rows h0-3 .. h0+2 go to win[1..6]
+      for (int j = 0; j < 6 + PF; ++j) loadx(j, ring[j]);
 #pragma unroll
-      for (int r = 1; r < 7; ++r) {
-        const int ih = h0 + r - 4;
-        const bool ok = ih >= 0 && ih < H;
-        const float* row = xb + ((size_t)(ok ? ih : 0) * W + w) * C;
-        win[r][0] = (ok && wl) ? row[-C] : 0.f;
-        win[r][1] = ok ? row[0] : 0.f;
-        win[r][2] = (ok && wr) ? row[C] : 0.f;
-      }
-      float nx0, nx1, nx2, nd;
-      {
-        const int ih = h0 + 3;
-        const bool ok = ih < H;
-        const float* row = xb + ((size_t)(ok ? ih : 0) * W + w) * C;
-        nx0 = (ok && wl) ? row[-C] : 0.f; nx1 = ok ? row[0] : 0.f; nx2 = (ok && wr) ? row[C] : 0.f;
-        nd = db[((size_t)h0 * W + w) * C];
-      }
-      for (int h = h0; h < h1; ++h) {
+      for (int j = 0; j < PF; ++j) dring[j] = loadd(j);
+      for (int k = 0; k < hs; k += U) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int u = 0; u < U; ++u) {
+          const int rel = k + u;
+          loadx(rel + 6 + PF, ring[(u + 6 + PF) % U]);
+          dring[(u + PF) % U] = loadd(rel + PF);
+          const float d = dring[u];
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) win[r][kw] = win[r + 1][kw];
-        win[6][0] = nx0; win[6][1] = nx1; win[6][2] = nx2;
-        const float d = nd;
-        if (h + 1 < h1) {
-          const int ih = h + 4;
-          const bool ok = ih < H;
-          const float* row = xb + ((size_t)(ok ? ih : 0) * W + w) * C;
-          nx0 = (ok && wl) ? row[-C] : 0.f; nx1 = ok ? row[0] : 0.f; nx2 = (ok && wr) ? row[C] : 0.f;
-          nd = db[((size_t)(h + 1) * W + w) * C];
+          for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc[r * 3 + kw] = fmaf(ring[(u + r) % U][kw], d, acc[r * 3 + kw]);
         }
-#pragma unroll
-        for (int r = 0; r < 7; ++r)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[r * 3 + kw] = fmaf(win[r][kw], d, acc[r * 3 + kw]);
       }
     }
   }
@@ -614,9 +608,10 @@ int vp_dwconv7x3_raw(const float* x, const float* w, float* y, int b, int h, int
 static inline void dw_wgrad_shape(int b, int h, int wd, int& hs, int& nseg, int& g) {
   const int cols = b * wd;
   nseg = (2048 + cols - 1) / cols;
-  const int most = h / 8 > 0 ? h / 8 : 1;
+  const int most = h / 10 > 0 ? h / 10 : 1;
   if (nseg > most) nseg = most;
   hs = (h + nseg - 1) / nseg;
+  hs = (hs + 9) / 10 * 10;               // the kernel's row loop is unrolled by 10
   nseg = (h + hs - 1) / hs;
   g = (cols * nseg + 3) / 4;
   if (g > 256) g = 256;
