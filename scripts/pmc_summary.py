@@ -23,8 +23,16 @@ def classify(name):
   garbled: bf16 'DF16b' confuses its demangler and swallows the first int) demangled one; None for other kernels."""
   if "conv_cin8_kernel" in name:
     return "cin8_bf16_64x16"
-  if "wgrad_tr_kernel" in name:
-    return "wgrad_bf16_256x128"
+  if "wgrad_tr_kernel" in name:   # wgrad_tr_kernel<WM, WN, TC, TP, NST, FAST, EXACT>: class = variant + tile (rows = WM*TC*16, columns = WN*TP*16)
+    m = re.search(r"wgrad_tr_kernel<(.*?)>", name)
+    if not m:
+      return "wgrad_tr_bf16_256x128"
+    args = [x.strip() for x in m.group(1).split(",")]
+    ints = [int(x) for x in args if x.isdigit()]
+    flags = [x == "true" for x in args if x in ("true", "false")]
+    wm, wn, tc, tp = ints[:4]
+    var = "tr_exact" if len(flags) > 1 and flags[1] else ("tr_fast" if flags and flags[0] else "tr")
+    return "wgrad_%s_bf16_%dx%d" % (var, wm * tc * 16, wn * tp * 16)
   for fam in ("igemm_patch3_kernel", "igemm_patch2_kernel", "igemm_patch_kernel"):
     if fam not in name:
       continue

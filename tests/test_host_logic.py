@@ -188,7 +188,9 @@ def test_pmc_kernel_classifier():
   assert p.classify("vp::adam_tf_kernel(vp::AdamArgs)") is None
   assert p.classify("_ZN2vp19igemm_patch3_kernelIDF16bLi2ELi4ELi8ELi2ELi8ELi16ELb0ELi4EEEvNS_9IgemmArgsE") == "patch3_bf16_256x128"
   assert p.classify("_ZN2vp19igemm_patch2_kernelIDF16bLi2ELi4ELi2ELi4ELi16ELi16ELb0ELi4ELb0EEEvNS_9IgemmArgsE") == "patch2_bf16_64x256"
-  assert p.classify("void vp::wgrad_tr_kernel<4, 2, 4, 4, 3, true, true>(vp::WgradArgs)") == "wgrad_bf16_256x128"
+  assert p.classify("void vp::wgrad_tr_kernel<4, 2, 4, 4, 3, true, true>(vp::WgradArgs)") == "wgrad_tr_exact_bf16_256x128"
+  assert p.classify("void vp::wgrad_tr_kernel<4, 2, 4, 4, 3, true, false>(vp::WgradArgs)") == "wgrad_tr_fast_bf16_256x128"
+  assert p.classify("void vp::wgrad_tr_kernel<4, 2, 2, 4, 3, false, false>(vp::WgradArgs)") == "wgrad_tr_bf16_128x128"
 
 
 def test_bench_launches_n_ranks_as_a_child_before_touching_the_gpu(monkeypatch):

@@ -1448,7 +1448,8 @@ struct ProfScope {
     if (!on) return;
     hipEventRecord(r.e1, st);
     char buf[96];
-    if (kind == "igemm" && g_prof_family) snprintf(buf, sizeof(buf), "igemm_%s_%s_%dx%d", g_prof_family, bf ? "bf16" : "f32", bc, bp);
+    // classes follow the kernel template instances rocprofv3 lists (family / variant, operand type, tile)
+    if ((kind == "igemm" || kind == "wgrad") && g_prof_family) snprintf(buf, sizeof(buf), "%s_%s_%s_%dx%d", kind.c_str(), g_prof_family, bf ? "bf16" : "f32", bc, bp);
     else snprintf(buf, sizeof(buf), "%s_%s_%dx%d", kind.c_str(), bf ? "bf16" : "f32", bc, bp);
     r.name = buf;
     if (g_prof_detail && !g_prof_tag.empty()) r.name = g_prof_tag + " " + r.name;
@@ -1803,7 +1804,7 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
     case 5: case 6: {                                               // 256 / 128 rows x 128 cols, LDS-DMA + transpose reads (wgrad_tr.hip; bf16, plain operands)
       const bool plain = a.zeros && !a.g.aff_a[0] && !a.g.aff_a[1] && a.g.act == ACT_NONE && !a.d.aff_a[0] && !a.d.aff_a[1] && a.d.act == ACT_NONE;
       if (sizeof(T) != 2 || !plain) return hipErrorInvalidValue;
-      e = launch_wgrad_tr(a, st);
+      e = launch_wgrad_tr(a, st, &g_prof_family);
       break;
     }
     default: return hipErrorInvalidValue;

@@ -15,7 +15,7 @@ hipError_t launch_igemm_patch3(const IgemmArgs& a, int is_bf16, int bc, int bp, 
 hipError_t launch_igemm_patch2(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                   // conv_patch2.hip
 hipError_t launch_igemm_db(const IgemmArgs& b, int is_bf16, int bc, dim3 grid, hipStream_t st);   // conv_db.hip
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
-hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st);                                          // wgrad_tr.hip
+hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st, const char** variant = nullptr);                                          // wgrad_tr.hip
 void wgrad_tile(int cfg, int* bm, int* bn);
 
 void profile_enable(int on);          // 1: per kernel kind, 2: per layer tag

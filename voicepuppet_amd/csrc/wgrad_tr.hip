@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradAr
 }
 
 template <int WM, int WN, int TC, int TP>
-static hipError_t launch_wgrad_tr_t(const WgradArgs& a, hipStream_t st) {
+static hipError_t launch_wgrad_tr_t(const WgradArgs& a, hipStream_t st, const char** variant) {
   constexpr int NST = 3;
   constexpr int BM = WM * TC * 16, BN = WN * TP * 16;
   const size_t smem = (size_t)NST * 32 * (BM / 8 + BN / 8) * 16;
@@ -297,6 +297,7 @@ static hipError_t launch_wgrad_tr_t(const WgradArgs& a, hipStream_t st) {
   static const bool xcd_on = !getenv("VP_NO_XCD_REMAP");
   b.xcd_remap = xcd_on ? 1 : 0;
   const bool exact = fast && a.Hb == (1 << a.lh) && a.Wb == (1 << a.lw);
+  if (variant) *variant = exact ? "tr_exact" : fast ? "tr_fast" : "tr";      // the template instance, for the profile's class names
   auto kern = exact ? wgrad_tr_kernel<WM, WN, TC, TP, NST, true, true> : fast ? wgrad_tr_kernel<WM, WN, TC, TP, NST, true> : wgrad_tr_kernel<WM, WN, TC, TP, NST, false>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, b);
@@ -305,9 +306,9 @@ static hipError_t launch_wgrad_tr_t(const WgradArgs& a, hipStream_t st) {
 
 // wgrad cfg 5: 256 rows x 128 columns; cfg 6: 128 x 128 (the 6- / 3-channel input layers: 16 taps x 8 padded channels = 128 rows,
 // 64 real columns - HBM-bound, the point is the loader: LDS-DMA instead of register loads + 8x8 transposes)
-hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st) {
-  if (a.Mpad % 256 == 0) return launch_wgrad_tr_t<4, 2, 4, 4>(a, st);
-  return launch_wgrad_tr_t<4, 2, 2, 4>(a, st);
+hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st, const char** variant) {
+  if (a.Mpad % 256 == 0) return launch_wgrad_tr_t<4, 2, 4, 4>(a, st, variant);
+  return launch_wgrad_tr_t<4, 2, 2, 4>(a, st, variant);
 }
 
 }  // namespace vp
