@@ -23,6 +23,10 @@ def classify(name):
   garbled: bf16 'DF16b' confuses its demangler and swallows the first int) demangled one; None for other kernels."""
   if "conv_cin8_kernel" in name:
     return "cin8_bf16_64x16"
+  if "deconv_cout4" in name:
+    return "cout4_bf16_16x16"
+  if "conv3x3_cout8_tile_kernel" in name:
+    return "cout8_bf16_16x64"
   if "wgrad_tr_kernel" in name:   # wgrad_tr_kernel<WM, WN, TC, TP, NST, FAST, EXACT>: class = variant + tile (rows = WM*TC*16, columns = WN*TP*16)
     m = re.search(r"wgrad_tr_kernel<(.*?)>", name)
     if not m:

@@ -1067,6 +1067,84 @@ __global__ __launch_bounds__(256) void deconv_cout4_tile_kernel(const IgemmArgs 
   }
 }
 
+// conv3x3_cout8_tile_kernel: 3x3 stride-1 convolution from 64 channels to <= 8 (VGG conv1_1 backward-data: the perceptual gradient
+// arriving at the composited image).  As a 16-row GEMM tile on the gather-per-tap kernel every dY pixel is fetched nine times
+// (0.193 ms for 0.04 ms of HBM traffic, r02 layer table).  Same plan as deconv_cout4_tile_kernel: a block owns 4 rows x 16 columns,
+// stages the 6 x 18 pixel halo once in LDS (one tile ahead in registers), wave w multiplies row w against the weight fragments -
+// which are only 18 x 16 bytes per lane and stay in registers.  Rows 0..7 of the MFMA tile are the channels: lanes g = 0 / 1 hold
+// channels 0..3 / 4..7 of pixel i, one cross-lane move joins them into the 16-byte output row (epi_store8).
+__global__ __launch_bounds__(256) void conv3x3_cout8_tile_kernel(const IgemmArgs a, int lgW, int lgH) {
+  constexpr int PIXB = 64 * 2 + 16, TPX = 6 * 18, NPIECE = TPX * 8, NJ = (NPIECE + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* stage = smem;                                             // [6][18][PIXB]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  uint4 af[18];
+  int toff[9];
+  {
+    const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      toff[t] = ((1 + a.taps[0].dh[t]) * 18 + 1 + a.taps[0].dw[t]) * PIXB;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int kk = t * 64 + k * 32 + g * 8;
+        af[t * 2 + k] = *reinterpret_cast<const uint4*>(wp + ((size_t)(kk >> 5) * a.wp_rows + i) * 32 + (kk & 31));
+      }
+    }
+  }
+  const int tw = 1 << (lgW - 4), th = 1 << (lgH - 2);
+  const int ntile = a.N * tw * th;
+  __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * 64 * 2));
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  int soff[NJ], spix_r[NJ], spix_c[NJ], sch[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int idx = threadIdx.x + 256 * j;
+    const int px = idx >> 3, c = (idx & 7) * 8;
+    spix_r[j] = px / 18; spix_c[j] = px - spix_r[j] * 18;
+    sch[j] = c;
+    soff[j] = idx < NPIECE ? px * PIXB + c * 2 : -1;
+  }
+  uint4 pre[NJ];
+  auto load_tile = [&](int tile) {
+    const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int ih = tr * 4 - 1 + spix_r[j], iw = tc * 16 - 1 + spix_c[j];
+      const bool ok = soff[j] >= 0 && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const unsigned off = ok ? (unsigned)((((n * a.Hin + ih) * a.Win + iw) * 64 + sch[j]) * 2) : DMA_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)off, 0, 0);
+      pre[j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntile) load_tile(tile);
+  while (tile < ntile) {
+    __syncthreads();                                              // previous tile's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) if (soff[j] >= 0) *reinterpret_cast<uint4*>(stage + soff[j]) = pre[j];
+    __syncthreads();
+    const int nxt = tile + gridDim.x;
+    if (nxt < ntile) load_tile(nxt);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const char* px = stage + (wv * 18 + i) * PIXB + g * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) acc = mma16<bf16>(af[t * 2 + k], *reinterpret_cast<const uint4*>(px + toff[t] + k * 64), acc);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = acc[e]; v[4 + e] = __shfl(acc[e], (lane + 16) & 63); }
+    if (g == 0) {
+      const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
+      const size_t off = ((size_t)(n * a.Hof + tr * 4 + wv) * a.Wof + tc * 16 + i) * a.ldY;
+      epi_store8<bf16>(a, 0, 0, off, v);
+    }
+    tile = nxt;
+  }
+}
+
 // sums the split-K slabs in a fixed order (deterministic) and applies the igemm epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArgs a) {
@@ -1697,6 +1775,26 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       while ((1 << lgH) < a.Hg) ++lgH;
       if (a.Kpad == 96) hipLaunchKernelGGL((conv_cin8_kernel<3>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
       else hipLaunchKernelGGL((conv_cin8_kernel<4>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // 3x3 stride-1 conv from 64 to <= 8 channels (conv1_1 backward-data): halo tile staged once (conv3x3_cout8_tile_kernel)
+    static const bool co8_on = !getenv("VP_NO_COUT8");
+    bool near = a.ntaps == 9;
+    for (int t = 0; near && t < 9; ++t) near = a.taps[0].dh[t] >= -1 && a.taps[0].dh[t] <= 1 && a.taps[0].dw[t] >= -1 && a.taps[0].dw[t] <= 1;
+    if (co8_on && near && a.zeros && a.nclass == 1 && a.sh == 1 && a.sw == 1 && a.os == 1 && a.Cin == 64 && a.x.C[0] == 64 && a.x.C[1] == 0 &&
+        a.CoutPad == 16 && a.Cout <= 8 && a.ldY == 8 && a.splitk == 1 && !a.rowperm && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
+        (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0 && a.Wg >= 16 && a.Hg >= 4 && a.Hof == a.Hg && a.Wof == a.Wg && a.Hin == a.Hg &&
+        a.Win == a.Wg && !a.y_f32 && (size_t)a.N * a.Hin * a.Win * 64 * 2 < 0x70000000ull) {
+      ProfScope prof("cout8", true, 16, 64, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.Cout + Pn * a.Cout), st);
+      int lgW = 0, lgH = 0;
+      while ((1 << lgW) < a.Wg) ++lgW;
+      while ((1 << lgH) < a.Hg) ++lgH;
+      int tblocks = a.N << (lgW - 4 + lgH - 2);
+      if (tblocks > 4096) tblocks = 4096;
+      hipLaunchKernelGGL(conv3x3_cout8_tile_kernel, dim3(tblocks), dim3(256), (size_t)6 * 18 * 144, st, a, lgW, lgH);
       return hipGetLastError();
     }
   }
