@@ -25,6 +25,8 @@ def classify(name):
     return "cin8_bf16_64x16"
   if "deconv_cout4" in name:
     return "cout4_bf16_16x16"
+  if "deconv_cout8_tile_kernel" in name:
+    return "dcout8_bf16_32x64"
   if "conv3x3_cout8_tile_kernel" in name:
     return "cout8_bf16_16x64"
   if "wgrad_tr_kernel" in name:   # wgrad_tr_kernel<WM, WN, TC, TP, NST, FAST, EXACT>: class = variant + tile (rows = WM*TC*16, columns = WN*TP*16)

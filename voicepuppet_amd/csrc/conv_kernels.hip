@@ -1145,6 +1145,106 @@ __global__ __launch_bounds__(256) void conv3x3_cout8_tile_kernel(const IgemmArgs
   }
 }
 
+// deconv_cout8_tile_kernel: 4x4 stride-2 transposed conv to <= 8 channels (discriminator layer_1 backward-data towards the generator:
+// 64 -> 6 (+2 pad) channels at 256x256).  deconv_cout4_tile_kernel with two MFMA tiles: rows 16T .. 16T+15 = parity classes 2T, 2T+1
+// x 8 channels; lane (i, g) of tile T holds channels 4 (g & 1) .. +3 of class 2T + (g >> 1) at base pixel i, its neighbour group
+// g ^ 1 the other half: one cross-lane move, then the even groups write the 16-byte bf16 rows (epi_store8).
+template <int SPT>
+__global__ __launch_bounds__(256) void deconv_cout8_tile_kernel(const IgemmArgs a, int lgW, int lgH) {
+  constexpr int S = 9 * SPT, CIN = SPT * 32, PPP = CIN / 8;
+  constexpr int PIXB = CIN * 2 + 16, TPX = 6 * 18, NPIECE = TPX * PPP, NJ = (NPIECE + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* wfrag = reinterpret_cast<uint4*>(smem);                  // [2][S][64]
+  char* stage = smem + (size_t)2 * S * 64 * 16;                   // [6][18][PIXB]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  {
+    const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
+    const int nchunk_c = a.Kpad / 32;
+    for (int idx = threadIdx.x; idx < 2 * S * 64; idx += 256) {
+      const int l = idx & 63, s = (idx >> 6) % S, T = idx / (S * 64);
+      const int u = s / SPT, c0 = (s % SPT) * 32 + (l >> 4) * 8;
+      const int dy = u / 3 - 1, dx = u % 3 - 1;
+      const int cls = 2 * T + ((l & 15) >> 3), co = l & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int tdh = 0, tdw = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c == cls) { tdh = a.taps[c].dh[t]; tdw = a.taps[c].dw[t]; }
+        if (tdh == dy && tdw == dx) {
+          const int k = t * CIN + c0;
+          v = *reinterpret_cast<const uint4*>(wp + (((size_t)cls * nchunk_c + (k >> 5)) * a.wp_rows + co) * 32 + (k & 31));
+        }
+      }
+      wfrag[idx] = v;
+    }
+  }
+  const int tw = 1 << (lgW - 4), th = 1 << (lgH - 2);
+  const int ntile = a.N * tw * th;
+  __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * CIN * 2));
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  int soff[NJ], spix_r[NJ], spix_c[NJ], sch[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int idx = threadIdx.x + 256 * j;
+    const int px = idx / PPP, c = (idx - px * PPP) * 8;
+    spix_r[j] = px / 18; spix_c[j] = px - spix_r[j] * 18;
+    sch[j] = c;
+    soff[j] = idx < NPIECE ? px * PIXB + c * 2 : -1;
+  }
+  uint4 pre[NJ];
+  auto load_tile = [&](int tile) {
+    const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int ih = tr * 4 - 1 + spix_r[j], iw = tc * 16 - 1 + spix_c[j];
+      const bool ok = soff[j] >= 0 && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const unsigned off = ok ? (unsigned)((((n * a.Hin + ih) * a.Win + iw) * CIN + sch[j]) * 2) : DMA_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)off, 0, 0);
+      pre[j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntile) load_tile(tile);
+  while (tile < ntile) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) if (soff[j] >= 0) *reinterpret_cast<uint4*>(stage + soff[j]) = pre[j];
+    __syncthreads();
+    const int nxt = tile + gridDim.x;
+    if (nxt < ntile) load_tile(nxt);
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    int wl = lane;
+    asm volatile("" : "+v"(wl));                                  // keep the weight image in LDS
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const char* px = stage + ((wv + u / 3) * 18 + i + u % 3) * PIXB + g * 16;
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        const uint4 b = *reinterpret_cast<const uint4*>(px + k * 64);
+        acc0 = mma16<bf16>(wfrag[(u * SPT + k) * 64 + wl], b, acc0);
+        acc1 = mma16<bf16>(wfrag[(S + u * SPT + k) * 64 + wl], b, acc1);
+      }
+    }
+    const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
+    const int q = tr * 4 + wv, r = tc * 16 + i;
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      const f32x4 acc = T ? acc1 : acc0;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[e]; v[4 + e] = __shfl(acc[e], (lane + 16) & 63); }
+      if ((g & 1) == 0) {
+        const int cls = 2 * T + (g >> 1);
+        const size_t off = ((size_t)(n * a.Hof + 2 * q + (cls >> 1)) * a.Wof + 2 * r + (cls & 1)) * a.ldY;
+        epi_store8<bf16>(a, 0, 0, off, v);
+      }
+    }
+    tile = nxt;
+  }
+}
+
 // sums the split-K slabs in a fixed order (deterministic) and applies the igemm epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArgs a) {
@@ -1795,6 +1895,26 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       int tblocks = a.N << (lgW - 4 + lgH - 2);
       if (tblocks > 4096) tblocks = 4096;
       hipLaunchKernelGGL(conv3x3_cout8_tile_kernel, dim3(tblocks), dim3(256), (size_t)6 * 18 * 144, st, a, lgW, lgH);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // 4x4 stride-2 transposed conv from 64 to <= 8 channels (layer_1 backward-data): deconv_cout8_tile_kernel
+    static const bool dco8_on = !getenv("VP_NO_DCOUT8");
+    if (dco8_on && a.zeros && a.nclass == 4 && a.os == 2 && a.ntaps == 4 && a.Cin == 64 && a.x.C[0] == 64 && a.x.C[1] == 0 && a.CoutPad == 16 && a.Cout <= 8 &&
+        a.ldY == 8 && !a.y_f32 && a.splitk == 1 && !a.rowperm && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE && (a.Wg & (a.Wg - 1)) == 0 &&
+        (a.Hg & (a.Hg - 1)) == 0 && a.Wg >= 16 && a.Hg >= 4 && a.Hof == 2 * a.Hg && a.Wof == 2 * a.Wg && a.Hin == a.Hg && a.Win == a.Wg &&
+        (size_t)a.N * a.Hin * a.Win * 64 * 2 < 0x70000000ull) {
+      ProfScope prof("dcout8", true, 32, 64, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+      int lgW = 0, lgH = 0;
+      while ((1 << lgW) < a.Wg) ++lgW;
+      while ((1 << lgH) < a.Hg) ++lgH;
+      int tblocks = a.N << (lgW - 4 + lgH - 2);
+      if (tblocks > 4096) tblocks = 4096;
+      const size_t smt = (size_t)2 * 18 * 64 * 16 + (size_t)6 * 18 * 144;
+      (void)hipFuncSetAttribute((const void*)deconv_cout8_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smt);
+      hipLaunchKernelGGL(deconv_cout8_tile_kernel<2>, dim3(tblocks), dim3(256), smt, st, a, lgW, lgH);
       return hipGetLastError();
     }
   }
