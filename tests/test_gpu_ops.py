@@ -47,6 +47,10 @@ FWD_CASES = [
     # transpose-read weight gradient (wgrad_tr.hip): 16 * Cin a multiple of 256, >= 128 output channels, plain operands
     (0, 3, 17, 19, 64, 128, 4, 1, 1, 0, 0, False),    # odd 16 x 18 output grid inside a 16 x 32 padded K grid, stride 1
     (1, 2, 8, 8, 128, 64, 4, 2, 1, 0, 0, False),      # transposed conv: the gathered operand is dY
+    # thin-output tile kernels (input halo staged once in LDS): power-of-two grids of at least 4 x 16 base pixels, plain operands, and
+    # large enough that the planner keeps split-K at 1 (decoder_1's f32-output kernel only exists inside the step: test_gpu_step.py)
+    (0, 4, 64, 128, 8, 64, 3, 1, 1, 0, 2, False),     # conv1_1 geometry: its backward-data runs conv3x3_cout8_tile_kernel
+    (0, 4, 128, 128, 8, 64, 4, 2, 1, 0, 0, False),    # layer_1 geometry: its backward-data runs deconv_cout8_tile_kernel (64 x 64 dY grid)
 ]
 
 
@@ -177,3 +181,27 @@ def test_batchnorm_stats_and_backward(pixels, c, dtype):
   assert gu.rel_l2(dyd.float().cpu().numpy(), dyr.reshape(pixels, c)) < TOL[dtype]
   assert gu.rel_l2(outs[4].cpu().numpy(), dgr) < 1e-4
   assert gu.rel_l2(outs[5].cpu().numpy(), dbr) < 1e-4
+
+
+def _profile_classes(fn):
+  import json
+  L = _lib.lib()
+  L.vp_profile_enable(1)
+  try:
+    fn()
+    torch.cuda.synchronize()
+    n = L.vp_profile_collect(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 16)
+    L.vp_profile_collect(buf, len(buf))
+  finally:
+    L.vp_profile_enable(0)
+  return {r["name"] for r in json.loads(buf.value.decode())}
+
+
+def test_thin_layer_cases_run_on_their_dedicated_kernels():
+  """The parity cases above are only worth something if the dedicated kernels are what runs: check the profile's class names."""
+  l1 = (0, 4, 128, 128, 8, 64, 4, 2, 1, 0, 0, False)
+  assert any(c.startswith("dcout8_") for c in _profile_classes(lambda: test_conv_bwd_data(l1, "bf16")))
+  c11 = (0, 4, 64, 128, 8, 64, 3, 1, 1, 0, 2, False)
+  assert any(c.startswith("cout8_") for c in _profile_classes(lambda: test_conv_bwd_data(c11, "bf16")))
+  assert any(c.startswith("cin8_") for c in _profile_classes(lambda: test_conv_fwd(c11, "bf16")))
