@@ -44,12 +44,23 @@ template <> struct Elem<float> {
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+#ifdef VP_SW_BF16_CVT   // A/B build only (make variant VAR=swcvt DEFS=-DVP_SW_BF16_CVT): the integer form round 1 used
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-  // round-to-nearest-even, NaN preserved
   uint32_t u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+#else
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  // round-to-nearest-even (NaN stays NaN): the hardware convert (v_cvt_pk_bf16_f32 on gfx950) instead of seven integer instructions -
+  // the batch-norm statistics epilogue rounds every value it sums this way
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 v = {f, 0.f};
+  const bf2 h = __builtin_convertvector(v, bf2);
+  return *reinterpret_cast<const uint32_t*>(&h) & 0xffffu;
+}
+#endif
 
 template <> struct Elem<bf16> {
   static constexpr int E = 8;
