@@ -295,3 +295,41 @@ def test_bfmnet_build_train_op_learns_a_fixed_batch():
     assert a == b
     wa, wb = net.train_engine.get_params(), net2.train_engine.get_params()
     assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+
+
+def test_bfmnet_train_cli_on_clip_folders(tmp_path, monkeypatch, capsys):
+  """train_bfmnet.py over real files in the reference's formats (folder list, audio.wav, landmark.txt, bfmcoeff.txt): silence trim,
+  24-frame slices, log-mel on the device, two training steps and an evaluation."""
+  import yaml
+  from scipy.io import wavfile
+  from voicepuppet_amd.bfmnet import train_bfmnet
+  rng = np.random.default_rng(0)
+  lines = []
+  for k, frames in enumerate((60, 75)):
+    folder = tmp_path / ("clip%d" % k)
+    folder.mkdir()
+    n = frames * 640
+    t = np.arange(n) / 16000.0
+    y = 0.4 * np.sin(2 * np.pi * (180 + 40 * k) * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t))
+    y[:3000] = 0
+    wavfile.write(str(folder / "audio.wav"), 16000, (y * 32767).astype(np.int16))
+    np.savetxt(str(folder / "bfmcoeff.txt"), rng.normal(0, 0.5, (frames, 257)), delimiter=",", fmt="%.6f")
+    np.savetxt(str(folder / "landmark.txt"), rng.uniform(10, 200, (frames, 212)), delimiter=",", fmt="%.4f")
+    lines.append("%s|%d" % (folder, frames))
+  (tmp_path / "train.txt").write_text("\n".join(lines) + "\n")
+  cfg = yaml.safe_load(open(CFG))
+  cfg["default"]["train_dataset_path"] = str(tmp_path / "train.txt")
+  cfg["default"]["eval_dataset_path"] = str(tmp_path / "train.txt")
+  cfg["default"]["amd"]["synthetic_data"] = False          # the dataset must be read; the face model still falls back to the stand-in
+  ypath = tmp_path / "params.yml"
+  ypath.write_text(yaml.safe_dump(cfg))
+  monkeypatch.chdir(tmp_path)
+  with pytest.raises(IOError):                              # no stand-in face model allowed either -> says so
+    train_bfmnet.main(["--config_path", str(ypath), "--steps", "1", "--batch_size", "2"])
+  cfg["default"]["amd"]["synthetic_data"] = "auto"
+  ypath.write_text(yaml.safe_dump(cfg))
+  train_bfmnet.main(["--config_path", str(ypath), "--steps", "2", "--batch_size", "2", "--eval_step", "2", "--save_step", "100"])
+  out = capsys.readouterr().out
+  assert out.count("Step ") == 2 and out.count("Evaluation >>> Loss=") == 1
+  losses = [float(l.split("Loss=")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Step ")]
+  assert all(np.isfinite(losses))
