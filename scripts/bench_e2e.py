@@ -1,0 +1,42 @@
+"""BASELINE config 5's per-GPU workload: one clip through infer_bfmvid.py end to end on ONE MI355X (wav -> log-mel -> BFMNet ->
+spliced coefficients -> device reconstruction + rasteriser -> resize / paste -> PixReferNet 512x512 -> jpg frames), with a synthetic
+face model of the real model's size class and random weights.  python scripts/bench_e2e.py [seconds of audio] [frame_batch]
+Prints one JSON object: frames, wall seconds, frames/s, x real time (25 fps)."""
+import json, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
+fb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+from PIL import Image
+from scipy.io import savemat, wavfile
+from oracle import bfm_ref as br            # test infrastructure: only used to MAKE the synthetic face model file
+from voicepuppet_amd.pixrefer import infer_bfmvid
+
+cfg = os.path.join(ROOT, "config", "params.yml")
+with tempfile.TemporaryDirectory() as d:
+  os.chdir(d)
+  rng = np.random.default_rng(0)
+  Image.fromarray((rng.uniform(size=(512, 1536, 3)) * 255).astype(np.uint8)).save("face.jpg")
+  n = int(secs * 16000)
+  t = np.arange(n) / 16000.0
+  wavfile.write("a.wav", 16000, (0.3 * np.sin(2 * np.pi * 220 * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t)) * 32767).astype(np.int16))
+  fm = br.synthetic_facemodel(0, nlat=189, nlon=189, smooth=True)     # 35,721 vertices / 70,688 triangles: the BFM_model_front size class
+  os.makedirs("BFM")
+  savemat(os.path.join("BFM", "BFM_model_front.mat"),
+          {"meanshape": fm.meanshape, "idBase": fm.idBase, "exBase": fm.exBase, "meantex": fm.meantex, "texBase": fm.texBase,
+           "point_buf": fm.point_buf, "tri": fm.tri, "keypoints": (fm.keypoints + 1).reshape(1, -1)})
+  coeff, _ = br.synthetic_coeffs(1, 5)
+  np.savez("photo.npz", bfmcoeff=coeff.reshape(1, 257), transform_params=np.array([512, 512, 1.0, 0.0, 0.0], np.float32),
+           center_x=256, center_y=256, ratio=0.9)
+  args = ["--config_path", cfg, "--frame_batch", str(fb), "--bfmcoeff", "photo.npz", "face.jpg", "a.wav"]
+  infer_bfmvid.main(args)                     # warm-up: library load, plans, first-touch
+  t0 = time.perf_counter()
+  infer_bfmvid.main(args)
+  dt = time.perf_counter() - t0
+  frames = len(os.listdir("output"))
+  os.chdir(ROOT)
+print(json.dumps({"config": "infer_bfmvid end to end, 1 clip, 512x512, 1 GPU (includes plan construction, D2H and jpg encoding)",
+                  "audio_seconds": secs, "frames": frames, "wall_s": dt, "frames_per_s": frames / dt, "x_realtime_25fps": frames / dt / 25.0,
+                  "vertices": int(fm.meanshape.size // 3), "triangles": int(fm.tri.shape[0]), "frame_batch": fb}))
