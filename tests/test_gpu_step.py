@@ -414,6 +414,32 @@ def test_overlapped_step_equals_single_stream_step():
 
 
 @pytest.mark.gpu
+def test_overlapped_step_equals_single_stream_step_at_full_width_batch_8():
+  """The same at ngf = ndf = 64 and batch 8, where the half-batch launches of the perceptual trunk (8 images) and its full-batch
+  launches (16) fall on different sides of the patch kernels' minimum-grid rule: the half-batch plans follow the full-batch kernel
+  choice, so the overlapped and the single-stream step still agree bit for bit (round 2: they did not - 2e-4 on the losses)."""
+  from voicepuppet_amd import _lib
+  L = _lib.lib()
+  g = torch.Generator(device="cuda").manual_seed(3)
+  batch = [torch.rand(8, 256, 256, c, device="cuda", generator=g) for c in (6, 6, 3, 3)]
+  runs = []
+  for overlap in (1, 0):
+    L.vp_tune(b"overlap", overlap)
+    try:
+      e = PixReferEngine(8, 256, 64, 64, dtype="bf16", training=True)
+      e.load_params(e.random_params(seed=0))
+      for _ in range(2):
+        e.train_step(*batch, lr=3e-4)
+      torch.cuda.synchronize()
+      runs.append((e.grads_g.clone(), e.grads_d.clone(), e.params_g.clone(), e.params_d.clone(), dict(e.losses())))
+    finally:
+      L.vp_tune(b"overlap", 1)
+  a, b = runs
+  assert a[4] == b[4]
+  assert all(torch.equal(x, y) for x, y in zip(a[:4], b[:4]))
+
+
+@pytest.mark.gpu
 def test_fused_backward_update_equals_separate_calls():
   """vp_pixrefer_backward_update (backward + Adam x 2 + weight re-pack, bucket by bucket under the backward pass) leaves exactly the
   parameters, Adam slots and next-step losses of vp_pixrefer_backward + vp_adam_tf x 2, over repeated steps and both dtypes."""

@@ -163,9 +163,10 @@ inline int patch_tile_rows(int rows, int on) {
   return 0;
 }
 
-inline bool plan_patch_eligible(const IgemmPlan& p, int rows, int is_bf16, bool single_src) {
+// any_grid: skip the minimum-block rule (a half-batch launch follows the kernel choice of the full-batch plan of its layer)
+inline bool plan_patch_eligible(const IgemmPlan& p, int rows, int is_bf16, bool single_src, bool any_grid = false) {
   const int on = patch_tiles_knob();
-  const int minblk = patch_minblk_knob();
+  const int minblk = any_grid ? 0 : patch_minblk_knob();
   const IgemmArgs& a = p.a;
   const int kc = kc_elems(is_bf16);
   if (!on || !single_src || a.nclass != 1 || a.sh != 1 || a.sw != 1 || a.os != 1 || a.ntaps < 9 || a.Cin % kc || a.Cin < kc) return false;

@@ -282,7 +282,11 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       ConvGeomX g2 = L.g;
       g2.N = alt_batch;
       L.fwd_half = plan_fwd(g2, L.w_off, bf16);
-      if (plan_patch_eligible(L.fwd_half, g2.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == g2.Cin)) plan_make_patch(L.fwd_half, g2.Cout, bf16);
+      // the half-batch launches take the kernel family of the layer's full-batch plan (the minimum-grid rule would otherwise pick the
+      // patch kernel for 2N images and the gather kernel for N at small batches: same result up to the order of the K sum, but then
+      // the overlapped step and the single-stream step are no longer bit-identical - seen at N = 8, 256x256)
+      if (L.fwd.a.patch == 1 && plan_patch_eligible(L.fwd_half, g2.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == g2.Cin, true))
+        plan_make_patch(L.fwd_half, g2.Cout, bf16);
       const PackDesc &pa = L.fwd.pack, &pb = L.fwd_half.pack;
       if (L.fwd_half.a.splitk == 1 && !L.fwd_half.a.wide) {
         if (pa.kswap != pb.kswap || pa.perm != pb.perm || pa.kc != pb.kc || pa.Kpad != pb.Kpad || pa.rows_pad != pb.rows_pad) {
