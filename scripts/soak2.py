@@ -9,16 +9,17 @@ from voicepuppet_amd.engine import PixReferEngine
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 dev = torch.device("cuda", 0)
 L = _lib.lib()
-a = PixReferEngine(n, 256, 64, 64, dtype="bf16", training=True)
-b = PixReferEngine(n, 256, 64, 64, dtype="bf16", training=True)
+a = PixReferEngine(n, H, 64, 64, dtype="bf16", training=True)
+b = PixReferEngine(n, H, 64, 64, dtype="bf16", training=True)
 p = a.random_params(seed=0)
 a.load_params(p); b.load_params(p)
 g = torch.Generator(device=dev).manual_seed(1)
 bad = 0
 for s in range(steps):
-  batch = [torch.rand(n, 256, 256, c, device=dev, generator=g) for c in (6, 6, 3, 3)]
+  batch = [torch.rand(n, H, H, c, device=dev, generator=g) for c in (6, 6, 3, 3)]
   L.vp_tune(b"overlap", 1); a.train_step(*batch, lr=3e-4); torch.cuda.synchronize()
   L.vp_tune(b"overlap", 0); b.train_step(*batch, lr=3e-4); torch.cuda.synchronize()
   for name, x, y in (("grads_g", a.grads_g, b.grads_g), ("grads_d", a.grads_d, b.grads_d), ("params_g", a.params_g, b.params_g), ("params_d", a.params_d, b.params_d)):
