@@ -12,8 +12,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 dev = torch.device("cuda", 0)
 L = _lib.lib()
-a = PixReferEngine(n, H, 64, 64, dtype="bf16", training=True)
-b = PixReferEngine(n, H, 64, 64, dtype="bf16", training=True)
+a = PixReferEngine(n, H, 64, 64, dtype=(sys.argv[4] if len(sys.argv) > 4 else "bf16"), training=True)
+b = PixReferEngine(n, H, 64, 64, dtype=(sys.argv[4] if len(sys.argv) > 4 else "bf16"), training=True)
 p = a.random_params(seed=0)
 a.load_params(p); b.load_params(p)
 g = torch.Generator(device=dev).manual_seed(1)
