@@ -602,12 +602,22 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeArgs 
       }
     }
     if (a.train) {
-      T* d = reinterpret_cast<T*>(a.din) + (2 * total + i) * 8 + 3;
+      // whole 8-channel rows with one store each (three 2-byte stores into the middle of a row are partial writes): the fake
+      // group's discriminator row keeps its first three channels (the conditioning image pack_inputs put there), read back exactly
+      T* d = reinterpret_cast<T*>(a.din) + (2 * total + i) * 8;
       T* v = reinterpret_cast<T*>(a.vin) + (total + i) * 8;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { Elem<T>::st(d + c, ofg[c]); Elem<T>::st(v + c, ofg[c]); }
-#pragma unroll
-      for (int c = 3; c < 8; ++c) Elem<T>::st(v + c, 0.f);
+      float head[3];
+      if (sizeof(T) == 2) {
+        const uint2 h = *reinterpret_cast<const uint2*>(d);
+        head[0] = __uint_as_float(h.x << 16); head[1] = __uint_as_float(h.x & 0xffff0000u); head[2] = __uint_as_float(h.y << 16);
+      } else {
+        const float4 h = *reinterpret_cast<const float4*>(d);
+        head[0] = h.x; head[1] = h.y; head[2] = h.z;
+      }
+      const float fd[8] = {head[0], head[1], head[2], ofg[0], ofg[1], ofg[2], 0.f, 0.f};
+      const float fv[8] = {ofg[0], ofg[1], ofg[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+      store8<T>(d, fd);
+      store8<T>(v, fv);
     }
   }
   if (a.train) {
