@@ -166,12 +166,13 @@ def write_v1():
   gs = np.asarray(123, np.int64)
 
   def tensor_proto(a, as_content):
-    p = vi(8) + vi(DT[a.dtype]) + ld(2, shape_proto(a.shape))
+    # TensorSliceWriter::SaveData -> Fill<T> sets ONLY the typed *_val field: no dtype, no tensor_shape in a slice's TensorProto
+    # (they live in the meta record under the empty key).  The tensor_content variant (another writer) carries its own header.
     if as_content:
-      return p + ld(4, a.tobytes())
+      return vi(8) + vi(DT[a.dtype]) + ld(2, shape_proto(a.shape)) + ld(4, a.tobytes())
     if a.dtype == np.float32:
-      return p + ld(5, a.tobytes())                          # packed repeated float float_val = 5
-    return p + ld(10, b"".join(vi(int(x)) for x in a.reshape(-1)))   # packed repeated int64 int64_val = 10
+      return ld(5, a.tobytes())                              # packed repeated float float_val = 5
+    return ld(10, b"".join(vi(int(x)) for x in a.reshape(-1)))       # packed repeated int64 int64_val = 10
 
   def rec(name, a, as_content):
     full_slice = b"".join(ld(1, b"") for _ in a.shape)       # TensorSliceProto: one Extent per dim, empty = full

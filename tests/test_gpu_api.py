@@ -297,6 +297,48 @@ def test_bfmnet_build_train_op_learns_a_fixed_batch():
     assert all(np.array_equal(wa[k], wb[k]) for k in wa)
 
 
+def test_bfmnet_restore_after_5000_steps_continues_bit_for_bit(tmp_path):
+  """float32 0.9 ** (t + 1) is exactly 0 from t ~ 1000 on, the first checkpoint is written at step 5000
+  (train_bfmnet.py:141) - restore must recover the Adam step count from beta2_power, in TF format, and the next step must be
+  the one the uninterrupted run takes."""
+  from voicepuppet_amd.bfmnet.bfmnet import BFMNet
+  from voicepuppet_amd.runtime import Session
+  from voicepuppet_amd.utils import tf_checkpoint
+  rng = np.random.default_rng(3)
+  B, T = 2, 24
+  coeff = rng.normal(0, 0.5, (B, T, 257)).astype(np.float32)
+  ears = rng.uniform(0.6, 0.9, (B, T, 1)).astype(np.float32)
+  mfccs = rng.normal(0, 1, (B, 5 * T, 80)).astype(np.float32)
+  seq = np.array([24, 20], np.int32)
+
+  def make():
+    net = BFMNet(CFG)
+    p = net.params
+    p.batch_size = B
+    p.training = dict(p.training, drop_rate=0.0)
+    net.set_params(p)
+    tr = net.build_train_op(coeff, ears, mfccs, seq)
+    net.train_engine.draw_masks = lambda *a, **k: None
+    return net, tr
+  sess = Session()
+  net, tr = make()
+  for _ in range(2):
+    sess.run([tr["Train_op"]])
+  net.train_engine.step_t = 5000          # as if 5000 updates had been applied (only the bias correction depends on it)
+  net.global_step = 5000
+  path = net.save(str(tmp_path / "bfmnet-5000"))
+  d = tf_checkpoint.read_checkpoint(path)
+  assert float(d["beta1_power"]) == 0.0 and 0.0 < float(d["beta2_power"]) < 1.0      # the situation the bug was about
+  net2, tr2 = make()
+  net2.restore(path)
+  assert net2.train_engine.step_t == 5000 and net2.global_step == 5000
+  a = sess.run([tr["Train_op"], tr["Loss"]])[1]
+  b = sess.run([tr2["Train_op"], tr2["Loss"]])[1]
+  assert a == b
+  wa, wb = net.train_engine.get_params(), net2.train_engine.get_params()
+  assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+
+
 def test_bfmnet_train_cli_on_clip_folders(tmp_path, monkeypatch, capsys):
   """train_bfmnet.py over real files in the reference's formats (folder list, audio.wav, landmark.txt, bfmcoeff.txt): silence trim,
   24-frame slices, log-mel on the device, two training steps and an evaluation."""

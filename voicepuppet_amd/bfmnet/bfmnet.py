@@ -207,8 +207,11 @@ class BFMNet(ModelBuilder):
           buf.copy_(torch.from_numpy(flat).to(buf.device))
         if 'adam_t' in d:
           eng.step_t = int(d['adam_t'])
-        elif 'beta1_power' in d:
-          eng.step_t = max(int(round(math.log(float(d['beta1_power'])) / math.log(self.BETA1))) - 1, 0)
+        elif 'beta1_power' in d or 'beta2_power' in d:
+          # beta2_power first: float32 0.9 ** (t + 1) underflows to exactly 0 after ~1000 updates (the first save is at 5000),
+          # 0.999 ** (t + 1) stays representable for ~100k; both 0 -> 'very many' (the bias correction is 1 by then)
+          from ..utils import tf_checkpoint
+          eng.step_t = tf_checkpoint.adam_steps_from_beta_powers(d.get('beta1_power', 0), d.get('beta2_power', 0), self.BETA1, self.BETA2)
       else:
         logger.warning('%s holds no Adam slots: the optimiser state starts from zero', path)
       if 'global_step' in d:
@@ -278,8 +281,8 @@ class BFMNet(ModelBuilder):
       elif n == 'Train_op':
         out[n] = None
       elif n == 'Grads':
-        g = self.train_engine.get_grads()
-        out[n] = [g[k] for k, _ in self.train_engine.trainables()]   # after clip_by_global_norm (the reference returns them unclipped)
+        g = self.train_engine.get_grads(unclipped=True)               # as the reference: compute_gradients' outputs, before the clip
+        out[n] = [g[k] for k, _ in self.train_engine.trainables()]
       elif n == 'Tvars':
         w = self.train_engine.get_params()
         out[n] = [w[k] for k, _ in self.train_engine.trainables()]

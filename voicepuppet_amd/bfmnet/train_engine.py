@@ -153,8 +153,15 @@ class BFMNetTrainEngine:
   def get_params(self):
     return {n: t.detach().cpu().numpy().copy() for n, t in self.p.items()}
 
-  def get_grads(self):
-    return {n: t.detach().cpu().numpy().copy() for n, t in self.g.items()}
+  def get_grads(self, unclipped=False):
+    """Gradients of the last step.  The arena holds them after clip_by_global_norm (the Adam kernel scales in place);
+    unclipped=True undoes that scale, i.e. returns what tf.gradients / compute_gradients hand out (bfmnet.py:300-303: the
+    reference's nodes['Grads'] are taken before the clip)."""
+    scale = 1.0
+    if unclipped and getattr(self, "_last_ss", None) is not None:
+      gn = float(torch.sqrt(self._last_ss))
+      scale = max(gn, self.clip) / self.clip
+    return {n: t.detach().cpu().numpy().copy() * np.float32(scale) for n, t in self.g.items()}
 
   # ---- kernel wrappers ------------------------------------------------------------------------------------------------------
   def _work(self, key, nbytes):
@@ -439,6 +446,7 @@ class BFMNetTrainEngine:
     _lib.check(L.vp_l2_regulariser(_ptr(self.arena), _ptr(self.l2mask), _ptr(self.grads), self.ntrain, L2_SCALE, _ptr(part), _stream()), "vp_l2_regulariser")
     loss = loss_data + 0.5 * L2_SCALE * part.sum()
     ss = self._sumsq(self.grads)
+    self._last_ss = ss
     if apply:
       _lib.check(L.vp_adam_tf_clipped(_ptr(self.arena), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.ntrain, _ptr(self.lr_t), _ptr(ss), self.clip,
                                       0.9, 0.999, 1e-8, _stream()), "vp_adam_tf_clipped")

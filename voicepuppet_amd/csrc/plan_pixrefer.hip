@@ -126,6 +126,7 @@ struct vp_pixrefer {
   hipStream_t side, branch;
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
   bool overlap, forked;
+  int dfork_pending;          // vp_pixrefer_backward only: where the generator-loss pass still has to start the discriminator-loss pass on the side stream (0: nowhere)
   void* zeros;
   size_t scratch_bytes;
   int n_comp, n_perc;
@@ -715,7 +716,6 @@ void vp_overlap_enable(int on) { g_overlap_on = on != 0; }
 // through the discriminator, 2 = behind its pass through the VGG trunk as well (i.e. under the generator's own backward)
 static int g_dfork_point = 2;
 void vp_dfork_point(int p) { g_dfork_point = p < 0 ? 0 : (p > 2 ? 2 : p); }
-static int g_dfork_pending = 0;
 static bool g_dsplit_on = true;      // discriminator fwd / generator-loss bwd through it on the branch stream, beside the VGG passes
 void vp_dsplit_enable(int on) { g_dsplit_on = on != 0; }
 
@@ -1088,16 +1088,19 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
     return vp_pixrefer_backward_g(h, stream);
   }
   int rc;
-  g_dfork_pending = g_dfork_point;
-  if (g_dfork_pending == 0 && (rc = fork_d(h, st))) return rc;
+  // per handle, and cleared on every way out: a failed call must not leave a pending fork behind for a later stand-alone
+  // vp_pixrefer_backward_g_stage (data-parallel path), which would start an un-joined discriminator pass
+  h->dfork_pending = g_dfork_point;
+  if (h->dfork_pending == 0 && (rc = fork_d(h, st))) { h->dfork_pending = 0; return rc; }
   rc = vp_pixrefer_backward_g(h, stream);
+  h->dfork_pending = 0;
   if (rc) return rc;
   VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
   return VP_OK;
 }
 
 static int fork_d(vp_pixrefer_t* h, hipStream_t st) {
-  g_dfork_pending = 0;
+  h->dfork_pending = 0;
   VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
   VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
   int rc = backward_d_on(h, h->side, true);
@@ -1224,7 +1227,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     if ((rc = run_layer_bwd(h, D, L, dy, false, true, 2 * N, N, 2, sd, ssd, true))) return rc;
   }
   if (split_d) VP_HIP_CHECK(hipEventRecord(h->ev_bjoin, h->branch));
-  if (g_dfork_pending == 1 && (rc = fork_d(h, st))) return rc;
+  if (h->dfork_pending == 1 && (rc = fork_d(h, st))) return rc;
   // (b) perceptual term through the VGG trunk, fake half only (dX only: VGG is frozen)
   for (Tens& t : V.t) t.dz_written = false;
   for (int i = (int)V.l.size() - 1; i >= 0; --i) {
@@ -1258,7 +1261,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     }
   }
   if (split_d) VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
-  if (g_dfork_pending == 2 && (rc = fork_d(h, st))) return rc;
+  if (h->dfork_pending == 2 && (rc = fork_d(h, st))) return rc;
   // (c) composite + L1 / matte terms -> gradient w.r.t. the pre-tanh generator output
   CompositeArgs ca;
   memset(&ca, 0, sizeof(ca));

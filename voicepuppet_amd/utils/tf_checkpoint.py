@@ -364,10 +364,38 @@ class CheckpointReader:
     return a.reshape(e["shape"]).copy()
 
 
+def _read_v1_meta(value):
+  """SavedTensorSliceMeta {tensor=1 repeated SavedSliceMeta {name=1, shape=2 TensorShapeProto, type=3, slice=4}} -> {name: (shape, dtype)}."""
+  meta = {}
+  for fn, wt, v in _fields(value):
+    if fn != 1 or wt != 2:
+      continue
+    name, shape, dtype = None, (), 1
+    for f2, w2, v2 in _fields(v):
+      if f2 == 1 and w2 == 2:
+        name = v2.decode()
+      elif f2 == 2 and w2 == 2:
+        shape = _parse_shape(v2)
+      elif f2 == 3 and w2 == 0:
+        dtype = v2
+    if name is not None:
+      meta[name] = (tuple(shape), dtype)
+  return meta
+
+
 def _read_v1(path):
-  """A V1 checkpoint file: table values are SavedTensorSlices {meta=1, data=2 {name=1, slice=2, data=3 TensorProto}}."""
+  """A V1 checkpoint file: table values are SavedTensorSlices {meta=1, data=2 {name=1, slice=2, data=3 TensorProto}}.
+  TensorSliceWriter fills ONLY the typed *_val field of a slice's TensorProto (tensor_slice_writer.h Fill<T>); shape and dtype
+  of a tensor live in the SavedTensorSliceMeta stored under the empty key.  A TensorProto that does carry dtype / shape (other
+  writers) is honoured."""
   out = {}
-  for key, value in read_table(path, verify=False):
+  records = list(read_table(path, verify=False))
+  meta = {}
+  for key, value in records:
+    for fn, wt, v in _fields(value):
+      if fn == 1 and wt == 2:
+        meta.update(_read_v1_meta(v))
+  for key, value in records:
     for fn, wt, v in _fields(value):
       if fn != 2 or wt != 2:
         continue
@@ -379,7 +407,7 @@ def _read_v1(path):
           tensor = v2
       if name is None or tensor is None:
         continue
-      dtype, shape, content, floats, ints, int64s = 1, (), None, [], [], []
+      dtype, shape, content, floats, ints, int64s = None, None, None, [], [], []
       for f3, w3, v3 in _fields(tensor):
         if f3 == 1 and w3 == 0:
           dtype = v3
@@ -407,6 +435,10 @@ def _read_v1(path):
             int64s.append(np.asarray(vals, np.int64))
           else:
             int64s.append(np.asarray([_signed(v3)], np.int64))
+      if dtype is None:
+        dtype = meta.get(name, ((), 1))[1]
+      if shape is None:
+        shape = meta.get(name, ((), 1))[0]
       if content is not None and dtype in _DTYPES:
         a = np.frombuffer(content, dtype=np.dtype(_DTYPES[dtype]).newbyteorder("<"))
       elif floats:
