@@ -147,6 +147,12 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
  * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile), "overlap" (default 1; 0: the step
  * executor keeps everything on the caller's stream - needed for per-kernel timing).  No counterpart in the reference. */
 int vp_tune(const char* key, int value);
+/* Further keys: "smallp_max_pixels" (largest pixel count per parity class that runs on the few-pixel kernel conv_smallp.hip,
+ * default 256, 0: off), "phase_marks" (1: the step executor records HIP events on the caller's stream at its phase boundaries).
+ * vp_pixrefer_phase_ms: milliseconds between consecutive marks of the last step (synchronises on them): generator forward,
+ * discriminator / VGG forward + losses, generator-loss pass through D and VGG + composite backward (including the host gap between
+ * the forward and the backward call), generator backward stage 0, 1, 2, join of the discriminator-loss pass.  Returns the number written. */
+int vp_pixrefer_phase_ms(vp_pixrefer_t* h, float* ms, int cap);
 
 /* theta -= lr_t * m / (sqrt(v) + eps) with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) (TF formulation) */
 int vp_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, int step_t,

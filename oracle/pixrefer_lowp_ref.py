@@ -166,11 +166,14 @@ def _dspec(ndf):
 
 
 def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64, l1_weight=500.0, gan_weight=1.0, q=round_bf16,
-                     out4_override=None, g_override=None):
+                     out4_override=None, g_override=None, d_override=None):
   """Same contract as pixrefer_ref.forward_backward (inputs in [0,1]); q = IDENT gives the float64 graph.
   out4_override: use this generator output (post-tanh, [N,H,H,4]) for everything downstream of the generator.  The
   generator's own bottleneck (batch-norm over N*1*1 .. N*4*4 values) amplifies single-ulp differences chaotically, so a
-  tight check of the discriminator / VGG / loss / composite backward feeds both sides the SAME generator output."""
+  tight check of the discriminator / VGG / loss / composite backward feeds both sides the SAME generator output.
+  d_override {scope: stored tensor of the 3N discriminator batch}: the same layer-by-layer teacher forcing for the discriminator
+  (errors in D.fwd_err), so that both of its backward passes run on identical activations - one-ulp differences of a stored
+  activation otherwise move the batch-norm backward of this 8-channel test net by several per cent."""
   N = inputs.shape[0]
   inp, fg, tgt = f32(f32(inputs) * 2 - 1), f32(f32(fg_inputs) * 2 - 1), f32(f32(targets) * 2 - 1)
   masks = f32(masks)
@@ -182,7 +185,7 @@ def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64, l1_we
   D = Net(_dspec(ndf), p, 'discriminator', q, groups=3)
   d_in = np.concatenate([np.concatenate([q(inp[..., 3:]), q(fg[..., 3:])], 3), np.concatenate([q(inp[..., :3]), q(fg[..., :3])], 3),
                          np.concatenate([q(inp[..., 3:]), ofg_q], 3)], axis=0)
-  logits = D.forward({'d_inputs': d_in})
+  logits = D.forward({'d_inputs': d_in}, d_override)
   pr = ops.sigmoid(logits)
   p0, p1, pf = pr[:N], pr[N:2 * N], pr[2 * N:]
   predict_real = (p0 + p1) / 2

@@ -110,7 +110,7 @@ def test_adam_update_and_determinism(oracle_step):
   eng.adam_step(3e-4)
   torch.cuda.synchronize()
   after = o["after"]
-  for which in (0, 1):
+  for which, key in ((0, "Gen_grads"), (1, "Discrim_grads")):
     got = eng.get_params(which)
     for name, v in got.items():
       # first Adam step moves every weight by ~lr_t; compare the update, not the value
@@ -119,8 +119,13 @@ def test_adam_update_and_determinism(oracle_step):
       if np.abs(dr).max() == 0:
         assert np.abs(du).max() == 0, name
         continue
-      # sign(g) * lr_t update: elements whose oracle gradient is ~0 may flip sign; compare in L2
-      assert gu.rel_l2(du, dr) < 1e-1, (name, gu.rel_l2(du, dr))
+      # sign(g) * lr_t update: an element whose gradient is smaller than the float32 path's gradient tolerance (5e-3 of the tensor,
+      # see the module docstring) may legitimately take the other sign, and ONE such flip in a 64-element beta is 0.25 in rel-L2;
+      # compare the elements whose oracle gradient is above that noise floor, and all elements loosely
+      gr = np.abs(o["nodes"][key][name])
+      firm = gr > 2e-2 * gr.max()
+      assert gu.rel_l2(du[firm], dr[firm]) < 2e-2, (name, gu.rel_l2(du[firm], dr[firm]))
+      assert gu.rel_l2(du, dr) < 3e-1, (name, gu.rel_l2(du, dr))
   # bit-reproducible: a second engine on the same data gives identical gradients
   eng2 = run_engine(o, "f32")
   assert torch.equal(eng2.grads_g, g1) and torch.equal(eng2.grads_d, d1)
@@ -186,12 +191,17 @@ def test_step_parity_bf16_against_rounding_aware_oracle(oracle_step):
   out4 = eng.tensor("gen_out4").cpu().numpy()
   p64 = {k: v.astype(np.float64) for k, v in o["params"].items()}
   g_dev = {sc: eng.tensor("g/" + sc).float().cpu().numpy() for sc, *_ in ref.generator_spec(o["ngf"])}
+  d_dev = {sc: eng.tensor("d/" + sc).float().cpu().numpy() for sc, *_ in ref.discriminator_spec(o["ndf"])}
   nodes = lowp.forward_backward(p64, *[b.astype(np.float64) for b in o["batch"]], ngf=o["ngf"], ndf=o["ndf"], q=lowp.round_bf16,
-                                out4_override=out4, g_override=g_dev)
+                                out4_override=out4, g_override=g_dev, d_override=d_dev)
   # layer-by-layer forward parity of the generator: each layer recomputed from the device's own previous tensors
   fwd = nodes["G"].fwd_err
   print("\n[bf16 generator forward, per layer from device inputs] worst:", sorted(((v, k) for k, v in fwd.items()), reverse=True)[:4])
   assert max(fwd.values()) < 4e-3, fwd
+  # ... and of the discriminator (its three applications as one batch of 3N)
+  fwd_d = nodes["D"].fwd_err
+  print("[bf16 discriminator forward, per layer from device inputs] worst:", sorted(((v, k) for k, v in fwd_d.items()), reverse=True)[:4])
+  assert max(fwd_d.values()) < 4e-3, fwd_d
   got = eng.losses()
   for k in ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss"):
     assert got[k] == pytest.approx(nodes[k], rel=1e-4), k
@@ -211,8 +221,8 @@ def test_step_parity_bf16_against_rounding_aware_oracle(oracle_step):
   print("\n[bf16 vs rounding-aware oracle] intermediates %s\n worst gradient rel-L2: %s" % (mid, top))
   # residual: f32 accumulation order differs from the oracle's, which flips the bf16 rounding (1 ulp = 0.4 %) of a few
   # per cent of the elements at each of the ~8 backward stages
-  # (d_din of this 8-channel mini net moves between 1.5e-2 and 2.4e-2 with the split-K setting of the discriminator's first layer -
-  # the order of the f32 partial sums decides a few more bf16 roundings; bound 3e-2, the gradient bound below is unchanged)
+  # (before the discriminator was teacher-forced too, d_din of this 8-channel mini net moved between 1.5e-2 and 3.7e-2 with anything
+  # that changes one bf16 rounding upstream - the split-K setting of a layer, the summation order of the generator's bottleneck)
   assert max(mid.values()) < 3e-2, mid
   bad = {k: v for k, v in worst.items() if v > 5e-2}   # measured worst: 3.0e-2 (a bias gradient), typical 1e-2
   assert not bad, bad

@@ -65,6 +65,11 @@ struct IgemmArgs {
   // tap t = r * p_kw + c  ->  (dh, dw) = (p_dhf + r * p_dhs, p_dwf + c * p_dws)
   int patch, p_kw, p_dhf, p_dhs, p_dwf, p_dws;
   void* pool_out;           // patch kernel, 16 x 16-pixel tiles: also write the 2x2 max-pooled output [N][Hg/2][Wg/2][ldY] (null: no)
+  // few-pixel kernel (conv_smallp.hip; patch == 3, plan-time decision: packed rows unpermuted): 32 channels x sp_npt * 16 pixels per tile,
+  // splitk = K splits over blocks, partial = their slabs [split][tile][pixels][32]
+  unsigned* sp_cnt;         // [tiles + channel tiles] arrival counters: zero before the launch, left zero by it
+  unsigned short sp_mask[4];   // per class: taps inside the image for at least one pixel
+  int sp_npt, sp_lcpt;      // MFMA pixel tiles per block tile (1, 2, 4); log2(64-byte K chunks per tap)
 };
 
 // dW[tap][g][d] = sum_{pixels} G~[pixel (+) tap, g] * D~[pixel, d]

@@ -27,6 +27,7 @@
 #include "conv_args.h"
 #include "conv_ops.h"
 #include "igemm_device.h"
+#include "smallp_args.h"
 #include "launch.h"
 #include "vp_common.h"
 
@@ -1951,6 +1952,11 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       return hipGetLastError();
     }
   }
+  if (a.patch == 3) {   // few-pixel layers: conv_smallp.hip (plain epilogue; the fused batch-norm forms are launched by the step executor)
+    ProfScope prof("smallp", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
+                   es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+    return launch_igemm_smallp(a, sizeof(T) == 2, st);
+  }
   if (a.patch) {   // stride-1 convs with the input patch staged once per channel chunk (conv_patch.hip)
     // class name per kernel template: patch2 (parity classes, conv_patch2.hip), patch3 (unrolled 3x3, conv_patch3.hip), patch (generic)
     const char* pk = a.patch == 2 ? "patch2" : (patch3_knob() && patch3_eligible(a, sizeof(T) == 2) ? "patch3" : "patch");
@@ -1994,13 +2000,23 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   return e;
 }
 
+// the few-pixel kernel with a fused batch-norm epilogue (SmallPArgs::mode), launched by the step executor; timed like every other conv launch
+hipError_t launch_smallp_fused(const SmallPArgs& s, int is_bf16, hipStream_t st) {
+  const IgemmArgs& a = s.g;
+  const double Pn = (double)a.N * a.Hg * a.Wg * a.nclass, kreal = (double)a.ntaps * a.cin_real, es = is_bf16 ? 2 : 4;
+  ProfScope prof("smallp", is_bf16, 32, a.sp_npt * 16, 2.0 * Pn * a.Cout * kreal,
+                 es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+  return launch_smallp(s, is_bf16, st);
+}
+
 hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st) {
   return is_bf16 ? launch_igemm_t<bf16>(a, cfg, st) : launch_igemm_t<float>(a, cfg, st);
 }
 
 void igemm_tile(int cfg, int* bc, int* bp) {
-  static const int t[16][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}, {128, 256}, {256, 256}, {64, 256}, {128, 512},
-                               {256, 256}, {128, 512}, {64, 512}, {128, 256}, {64, 256}, {256, 128}};     // 10..15: patch kernel tiles (conv_ops.h patch_tile_hw)
+  static const int t[19][2] = {{128, 128}, {64, 128}, {16, 128}, {128, 32}, {128, 16}, {64, 32}, {128, 256}, {256, 256}, {64, 256}, {128, 512},
+                               {256, 256}, {128, 512}, {64, 512}, {128, 256}, {64, 256}, {256, 128},     // 10..15: patch kernel tiles (conv_ops.h patch_tile_hw)
+                               {32, 16}, {32, 32}, {32, 64}};                                               // 16..18: few-pixel kernel (conv_smallp.hip)
   *bc = t[cfg][0]; *bp = t[cfg][1];
 }
 

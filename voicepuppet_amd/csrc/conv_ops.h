@@ -241,6 +241,62 @@ inline void plan_make_patch2(IgemmPlan& p, int rows, int is_bf16) {
   p.pack.kswap = 1;
 }
 
+// Few-pixel kernel (conv_smallp.hip): layers whose pixel count per parity class is so small that the layer is a stream of weights
+// (the generator's 1x1 .. 16x16 bottleneck).  A plan-time decision: the packed rows are not permuted, the slab / counter sizes differ.
+// c0 / c1: channels of the one or two source tensors.
+inline int& smallp_knob() { static int v = getenv("VP_SMALLP") ? atoi(getenv("VP_SMALLP")) : 256; return v; }   // largest pixel count per class (0: off)
+inline bool plan_smallp_eligible(const IgemmPlan& p, int rows, int is_bf16, int c0, int c1) {
+  const IgemmArgs& a = p.a;
+  const int kc = kc_elems(is_bf16);
+  const long long Pc = (long long)a.N * a.Hg * a.Wg;
+  if (smallp_knob() <= 0 || Pc > smallp_knob() || a.ntaps > 16 || a.nclass > 4) return false;
+  if (rows % 32 || a.Cout != rows || a.ldY % 8) return false;
+  if (a.Cin < kc || (a.Cin & (a.Cin - 1)) || c0 + c1 != a.Cin || c0 % kc || c1 % kc) return false;
+  if ((long long)a.N * a.Hin * a.Win * (c0 > c1 ? c0 : c1) >= (1ll << 30)) return false;       // 32-bit element offsets in the loader
+  return true;
+}
+// counters a smallp plan needs: one per tile + one per channel tile
+inline int smallp_counters(const IgemmArgs& a) {
+  const int PT = a.sp_npt * 16;
+  const int Pc = a.N * a.Hg * a.Wg;
+  return (a.CoutPad / 32) * a.nclass * ((Pc + PT - 1) / PT) + a.CoutPad / 32;
+}
+inline void plan_make_smallp(IgemmPlan& p, int rows, int is_bf16) {
+  IgemmArgs& a = p.a;
+  const int kc = kc_elems(is_bf16);
+  const int Pc = a.N * a.Hg * a.Wg;
+  a.patch = 3;
+  a.sp_npt = Pc <= 16 ? 1 : (Pc <= 32 ? 2 : 4);
+  p.cfg = a.sp_npt == 1 ? 16 : (a.sp_npt == 2 ? 17 : 18);
+  a.sp_lcpt = ilog2(a.Cin / kc);
+  a.CoutPad = round_up(rows, 32);
+  a.rowperm = 0; p.pack.perm = 0; p.pack.kswap = 0;
+  // taps that reach the image for at least one pixel of the class (rows and columns are independent)
+  int minchunks = 1 << 30;
+  for (int cls = 0; cls < a.nclass; ++cls) {
+    unsigned m = 0;
+    for (int t = 0; t < a.ntaps; ++t) {
+      bool okh = false, okw = false;
+      for (int q = 0; q < a.Hg && !okh; ++q) { const int ih = q * a.sh + a.taps[cls].dh[t]; okh = ih >= 0 && ih < a.Hin; }
+      for (int r = 0; r < a.Wg && !okw; ++r) { const int iw = r * a.sw + a.taps[cls].dw[t]; okw = iw >= 0 && iw < a.Win; }
+      if (okh && okw) m |= 1u << t;
+    }
+    a.sp_mask[cls] = (unsigned short)m;
+    const int chunks = __builtin_popcount(m) * (a.Cin / kc);
+    if (chunks < minchunks) minchunks = chunks;
+  }
+  // K splits over blocks: aim at >= 384 blocks, keep >= 2 chunks per wave (4 waves per block share a block's K range)
+  const int PT = a.sp_npt * 16;
+  const int tiles = (a.CoutPad / 32) * a.nclass * ((Pc + PT - 1) / PT);
+  static const int target = getenv("VP_SMALLP_BLOCKS") ? atoi(getenv("VP_SMALLP_BLOCKS")) : 384;
+  int s = (target + tiles - 1) / tiles;
+  if (s > minchunks / 8) s = minchunks / 8;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  a.splitk = s;
+  p.partial_bytes = s > 1 ? (size_t)s * tiles * PT * 32 * sizeof(float) : 0;
+}
+
 // x (PixSrc, total channels g.Cin) -> y [N,Hout,Wout,ldY]
 inline IgemmPlan plan_fwd(const ConvGeomX& g, size_t w_off, int is_bf16) {
   IgemmPlan p;

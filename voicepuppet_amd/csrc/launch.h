@@ -13,6 +13,10 @@ hipError_t launch_igemm_patch(const IgemmArgs& a, int is_bf16, int bc, int bp, h
 bool patch3_eligible(const IgemmArgs& a, int is_bf16);                                                               // conv_patch3.hip
 hipError_t launch_igemm_patch3(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                   // conv_patch3.hip
 hipError_t launch_igemm_patch2(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                   // conv_patch2.hip
+hipError_t launch_igemm_smallp(const IgemmArgs& a, int is_bf16, hipStream_t st);                                   // conv_smallp.hip (plain epilogue)
+struct SmallPArgs;
+hipError_t launch_smallp(const SmallPArgs& s, int is_bf16, hipStream_t st);                                         // conv_smallp.hip (fused batch-norm forms)
+hipError_t launch_smallp_fused(const SmallPArgs& s, int is_bf16, hipStream_t st);                                   // ... with the per-launch profile record (conv_kernels.hip)
 hipError_t launch_igemm_db(const IgemmArgs& b, int is_bf16, int bc, dim3 grid, hipStream_t st);   // conv_db.hip
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
 hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st, const char** variant = nullptr);                                          // wgrad_tr.hip

@@ -57,6 +57,7 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
 extern "C" void vp_overlap_enable(int on);   // plan_pixrefer.hip
 extern "C" void vp_dfork_point(int p);       // plan_pixrefer.hip
 extern "C" void vp_dsplit_enable(int on);    // plan_pixrefer.hip
+extern "C" void vp_phase_marks_enable(int on);   // plan_pixrefer.hip
 
 int vp_tune(const char* key, int value) {
   if (!key) return VP_ERR_ARG;
@@ -72,8 +73,17 @@ int vp_tune(const char* key, int value) {
   if (k == "patch3") { patch3_knob() = value; return VP_OK; }
   if (k == "patch2") { patch2_knob() = value; return VP_OK; }
   if (k == "patch_xcd") { patch_xcd_knob() = value; return VP_OK; }
+  if (k == "smallp_max_pixels") { smallp_knob() = value; return VP_OK; }
+  if (k == "phase_marks") { vp_phase_marks_enable(value); return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
   return VP_ERR_ARG;
+}
+
+// the few-pixel kernel's arrival counters live behind the zero page of the op's workspace, zeroed per call
+static unsigned* smallp_counter_page(char* ws, size_t used, const IgemmArgs& a, hipStream_t st) {
+  unsigned* c = (unsigned*)(ws + align256(used) + 256);
+  (void)hipMemsetAsync(c, 0, (size_t)smallp_counters(a) * sizeof(unsigned), st);
+  return c;
 }
 
 size_t vp_conv_workspace_bytes(const vp_conv_desc* d) {
@@ -84,11 +94,21 @@ size_t vp_conv_workspace_bytes(const vp_conv_desc* d) {
   {
     IgemmPlan p = plan_fwd(g, 0, bf);      // (the patch-kernel plan of the same layer needs no more: same packed block, no split-K slab)
     best = align256(p.pack_elems * es) + p.partial_bytes;
+    if (plan_smallp_eligible(p, g.Cout, bf, d->cin, 0)) {
+      plan_make_smallp(p, g.Cout, bf);
+      const size_t b = align256(p.pack_elems * es) + align256(p.partial_bytes) + 512 + (size_t)smallp_counters(p.a) * sizeof(unsigned);
+      if (b > best) best = b;
+    }
   }
   if ((d->cout & (d->cout - 1)) == 0 && d->cout >= 8) {
     IgemmPlan p = plan_bwd_data(g, 0, 0, d->cin, d->cin, d->cin, bf);
     size_t b = align256(p.pack_elems * es) + p.partial_bytes;
     if (b > best) best = b;
+    if (plan_smallp_eligible(p, d->cin, bf, d->cout, 0)) {
+      plan_make_smallp(p, d->cin, bf);
+      b = align256(p.pack_elems * es) + align256(p.partial_bytes) + 512 + (size_t)smallp_counters(p.a) * sizeof(unsigned);
+      if (b > best) best = b;
+    }
     for (int plain = 0; plain < 2; ++plain) {      // the LDS-DMA weight-gradient kernel (plain operands) tiles and splits differently
       WgradPlan w = plan_wgrad(g, bf, plain != 0);
       if (w.partial_bytes + 512 > best) best = w.partial_bytes + 512;
@@ -105,7 +125,8 @@ int vp_conv_fwd(const vp_conv_desc* d, const void* x, const float* in_scale, con
   const ConvGeomX g = geom_of(d);
   IgemmPlan p = plan_fwd(g, 0, bf);
   // the patch kernel moves plain bytes (LDS-DMA): only inputs that need no deferred affine / activation
-  if (d->in_act == ACT_NONE && !in_scale && plan_patch_eligible(p, g.Cout, bf, true)) plan_make_patch(p, g.Cout, bf);
+  if (d->in_act == ACT_NONE && !in_scale && plan_smallp_eligible(p, g.Cout, bf, d->cin, 0)) plan_make_smallp(p, g.Cout, bf);
+  else if (d->in_act == ACT_NONE && !in_scale && plan_patch_eligible(p, g.Cout, bf, true)) plan_make_patch(p, g.Cout, bf);
   else if (d->in_act == ACT_NONE && !in_scale && plan_patch2_eligible(p, g.Cout, bf, d->cin, 0)) plan_make_patch2(p, g.Cout, bf);
   char* ws = (char*)workspace;
   VP_HIP_CHECK(launch_pack_weights_one(p.pack, w, ws, bf, st));
@@ -115,6 +136,7 @@ int vp_conv_fwd(const vp_conv_desc* d, const void* x, const float* in_scale, con
   a.partial = (float*)(ws + align256(p.pack_elems * es));
   a.Y = y; a.ldY = d->cout; a.bias = bias; a.out_act = d->out_act;
   a.zeros = zero_page(ws, align256(p.pack_elems * es) + p.partial_bytes, st);
+  if (a.patch == 3) a.sp_cnt = smallp_counter_page(ws, align256(p.pack_elems * es) + p.partial_bytes, a, st);
   VP_HIP_CHECK(launch_igemm(a, bf, p.cfg, st));
   return VP_OK;
 }
@@ -126,7 +148,8 @@ int vp_conv_bwd_data(const vp_conv_desc* d, const void* dy, const float* w, void
   hipStream_t st = (hipStream_t)stream;
   const ConvGeomX g = geom_of(d);
   IgemmPlan p = plan_bwd_data(g, 0, 0, d->cin, d->cin, d->cin, bf);
-  if (plan_patch_eligible(p, d->cin, bf, true)) plan_make_patch(p, d->cin, bf);
+  if (plan_smallp_eligible(p, d->cin, bf, d->cout, 0)) plan_make_smallp(p, d->cin, bf);
+  else if (plan_patch_eligible(p, d->cin, bf, true)) plan_make_patch(p, d->cin, bf);
   else if (plan_patch2_eligible(p, d->cin, bf, d->cout, 0)) plan_make_patch2(p, d->cin, bf);
   char* ws = (char*)workspace;
   VP_HIP_CHECK(launch_pack_weights_one(p.pack, w, ws, bf, st));
@@ -136,6 +159,7 @@ int vp_conv_bwd_data(const vp_conv_desc* d, const void* dy, const float* w, void
   a.partial = (float*)(ws + align256(p.pack_elems * es));
   a.Y = dx;
   a.zeros = zero_page(ws, align256(p.pack_elems * es) + p.partial_bytes, st);
+  if (a.patch == 3) a.sp_cnt = smallp_counter_page(ws, align256(p.pack_elems * es) + p.partial_bytes, a, st);
   VP_HIP_CHECK(launch_igemm(a, bf, p.cfg, st));
   return VP_OK;
 }

@@ -20,6 +20,7 @@
 #include "conv_ops.h"
 #include "errors.h"
 #include "launch.h"
+#include "smallp_args.h"
 #include "vp_common.h"
 
 namespace vp {
@@ -61,6 +62,10 @@ struct Tens {
   void* xa[3] = {nullptr, nullptr, nullptr};   // materialised act(bn(y)) per vp::Act (lrelu, relu) for the consumers
   bool need_act[3] = {false, false, false};
   BnBuf bn{};
+  int producer = -1;          // layer that writes this tensor (-1: network input / pool)
+  int n_bwd_consumers = 0;    // layers whose backward-data pass writes into dz
+  int dz_writes = 0;          // ... of which have run in the current backward pass
+  bool bn_bwd_done = false;   // the batch-norm backward of this tensor ran inside the last writer's launch (conv_smallp.hip, SP_BWD_BN)
   size_t elems() const { return (size_t)N * H * W * C; }
 };
 
@@ -86,6 +91,8 @@ struct Layer {
   bool tapgemm = false;
   float* tap_S = nullptr;    // [N,Hin,Win,16] f32
   void* tap_dyS = nullptr;   // [N,Hin,Win,16] T
+  unsigned* sp_cnt_fwd = nullptr;               // few-pixel kernel (conv_smallp.hip): arrival counters of this layer's launches
+  unsigned* sp_cnt_bwd[2] = {nullptr, nullptr};
 };
 
 struct ParamInfo { std::string name; size_t off; int ndim; int64_t shape[4]; };
@@ -102,6 +109,8 @@ struct Net {
   size_t packed_elems = 0;
   std::vector<PackDesc> descs;
   PackDesc* d_descs = nullptr;
+  unsigned* sp_cnt = nullptr;   // arrival counters of the few-pixel launches of this net (zeroed at create, left zero by every launch)
+  size_t sp_cnt_n = 0;
 };
 
 }  // namespace vp
@@ -126,6 +135,10 @@ struct vp_pixrefer {
   hipStream_t side, branch;
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
   bool overlap, forked;
+  // vp_tune("phase_marks", 1): HIP events on the caller's stream at the phase boundaries of a step (vp_pixrefer_phase_ms)
+  hipEvent_t mark[12];
+  int nmark;
+  bool marks_made;
   int dfork_pending;          // vp_pixrefer_backward only: where the generator-loss pass still has to start the discriminator-loss pass on the side stream (0: nowhere)
   void* zeros;
   size_t scratch_bytes;
@@ -185,6 +198,7 @@ static int add_layer(Net& n, const std::string& prefix, const std::string& scope
     add_param(n, base + "batch_normalization/beta", {cout}, &L.beta_off);
   }
   L.out = add_tensor(n, scope, n.batch, L.g.Hout, L.g.Wout, L.g.CoutT, has_bn, false);
+  n.t[L.out].producer = (int)n.l.size();
   n.l.push_back(L);
   return L.out;
 }
@@ -273,7 +287,10 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       L.fwd = plan_fwd(L.g, L.w_off, bf16);
       bool srcs_ok = true;
       for (int s = 0; s < L.nsrc; ++s) srcs_ok = srcs_ok && n.t[L.src[s]].C % (2 * kc_elems(bf16)) == 0;
-      if (plan_wide_eligible(L.fwd, bf16, srcs_ok, true) && !(L.g.Cout < 8)) plan_make_wide(L.fwd, bf16);
+      // the generator's few-pixel bottleneck: conv + K-split combine + batch-norm + activations in one launch (conv_smallp.hip)
+      if (n.groups == 1 && alt_batch == 0 && plan_smallp_eligible(L.fwd, L.g.Cout, bf16, n.t[L.src[0]].C, L.nsrc > 1 ? n.t[L.src[1]].C : 0))
+        plan_make_smallp(L.fwd, L.g.Cout, bf16);
+      else if (plan_wide_eligible(L.fwd, bf16, srcs_ok, true) && !(L.g.Cout < 8)) plan_make_wide(L.fwd, bf16);
       else if (plan_patch_eligible(L.fwd, L.g.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == L.g.Cin)) plan_make_patch(L.fwd, L.g.Cout, bf16);
       else if (plan_patch2_eligible(L.fwd, L.g.Cout, bf16, n.t[L.src[0]].C, L.nsrc > 1 ? n.t[L.src[1]].C : 0)) plan_make_patch2(L.fwd, L.g.Cout, bf16);
     }
@@ -320,7 +337,9 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
             L.bwd[s].pack.perm = L.bwd_alt[s].pack.perm = 0;
           }
         }
-        {
+        if (n.groups == 1 && alt_batch == 0 && !ts.is_input && plan_smallp_eligible(L.bwd[s], rows, bf16, L.g.CoutT, 0)) {
+          plan_make_smallp(L.bwd[s], rows, bf16);
+        } else {
           const bool dy_ok = L.g.CoutT % (2 * kc_elems(bf16)) == 0;
           bool wide = plan_wide_eligible(L.bwd[s], bf16, dy_ok, true);
           if (alt_batch > 0) wide = wide && plan_wide_eligible(L.bwd_alt[s], bf16, dy_ok, true);
@@ -361,6 +380,16 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
   }
   n.packed_elems = pk;
   for (size_t i = 0; i < n.l.size(); ++i) n.l[i].desc1 = i + 1 < n.l.size() ? n.l[i + 1].desc0 : n.descs.size();
+  for (Tens& t : n.t) t.n_bwd_consumers = 0;
+  n.sp_cnt_n = 0;
+  for (Layer& L : n.l) {
+    if (L.fwd.a.patch == 3) n.sp_cnt_n += smallp_counters(L.fwd.a);
+    for (int s = 0; s < L.nsrc && training; ++s) {
+      if (!L.need_bwd[s]) continue;
+      n.t[L.src[s]].n_bwd_consumers++;
+      if (L.bwd[s].a.patch == 3) n.sp_cnt_n += smallp_counters(L.bwd[s].a);
+    }
+  }
 }
 
 // carve device buffers of a net out of the workspace
@@ -387,7 +416,15 @@ static void carve_net(Net& n, Arena& ar, int es, bool training) {
   }
   n.packed = (char*)ar.alloc(n.packed_elems * es);
   n.d_descs = (PackDesc*)ar.alloc(n.descs.size() * sizeof(PackDesc));
-  (void)training;
+  n.sp_cnt = (unsigned*)ar.alloc((n.sp_cnt_n + 1) * sizeof(unsigned));
+  {
+    unsigned* c = n.sp_cnt;
+    for (Layer& L : n.l) {
+      if (L.fwd.a.patch == 3) { L.sp_cnt_fwd = c; c += c ? smallp_counters(L.fwd.a) : 0; }
+      for (int s = 0; s < L.nsrc && training; ++s)
+        if (L.need_bwd[s] && L.bwd[s].a.patch == 3) { L.sp_cnt_bwd[s] = c; c += c ? smallp_counters(L.bwd[s].a) : 0; }
+    }
+  }
 }
 
 static size_t carve_all(vp_pixrefer* h, char* base, size_t cap, std::vector<std::pair<size_t, size_t>>* track = nullptr) {
@@ -564,6 +601,29 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
   a.partial = (float*)scratch_of(h, ss);
   a.zeros = h->zeros;
   if (L.tapgemm) { a.Y = L.tap_S; a.y_f32 = 1; a.ldY = 16; a.bias = nullptr; }
+  if (a.patch == 3) {
+    // few-pixel layer: convolution, K-split combine, batch statistics, affine and the consumers' activations in ONE launch
+    SmallPArgs sp;
+    memset(&sp, 0, sizeof(sp));
+    a.sp_cnt = L.sp_cnt_fwd;
+    sp.g = a;
+    for (int c = 0; c < 4; ++c) sp.tap_mask[c] = a.sp_mask[c];
+    sp.slab = a.partial; sp.cnt = a.sp_cnt; sp.part = bnp_of(h, ss);
+    sp.mode = L.has_bn ? SP_FWD_BN : SP_PLAIN;
+    if (L.has_bn) {
+      sp.gamma = n.params + L.gamma_off; sp.beta = n.params + L.beta_off;
+      sp.aff_a = to.bn.a; sp.aff_b = to.bn.b; sp.mu = to.bn.mu; sp.rstd = to.bn.rstd;
+      sp.out_lrelu = to.need_act[ACT_LRELU] ? to.xa[ACT_LRELU] : nullptr;
+      sp.out_relu = to.need_act[ACT_RELU] ? to.xa[ACT_RELU] : nullptr;
+      sp.eps = 1e-5f;   // pixrefer.py:100
+    }
+    profile_tag((L.scope + ":fwd").c_str());
+    VP_HIP_CHECK(launch_smallp_fused(sp, h->bf16, st));
+    if (!L.has_bn && (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]))
+      VP_HIP_CHECK(launch_act_apply(to.y, nullptr, nullptr, to.C, (n.batch / n.groups) * to.H * to.W, (size_t)to.N * to.H * to.W,
+                                    to.xa[ACT_LRELU], to.xa[ACT_RELU], h->bf16, st));
+    return VP_OK;
+  }
   // batch statistics from the conv epilogue (no re-read of the output) when every pixel tile lies inside one BN group
   bool fused_stats = false;
   int stat_chunks = 0;
@@ -670,6 +730,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       bool& written = gpass ? ts.dz2_written : ts.dz_written;
       a.accumulate = written ? 1 : 0;
       written = true;
+      if (!gpass) ts.dz_writes++;
       // chain rule through the consumer's activation and (for BN tensors) up to the normalised value
       // lrelu'/relu' only depend on the sign of the pre-activation == the sign of the materialised x~
       a.ref = (const char*)ts.xa[L.in_act] + (size_t)sample0 * ts.H * ts.W * ts.C * es;
@@ -678,6 +739,30 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     }
     a.zeros = h->zeros;
     profile_tag((L.scope + (alt ? ":bwdG" : ":bwd")).c_str());
+    if (a.patch == 3 && !alt) {
+      // few-pixel layer: K-split combine in the launch; when this is the last gradient contribution to a batch-normalised tensor, the
+      // batch-norm backward of that tensor (sums, c1 / c2, dgamma / dbeta, dy in place) runs in the same launch
+      SmallPArgs sp;
+      memset(&sp, 0, sizeof(sp));
+      a.sp_cnt = L.sp_cnt_bwd[s];
+      sp.g = a;
+      for (int c = 0; c < 4; ++c) sp.tap_mask[c] = a.sp_mask[c];
+      sp.slab = a.partial; sp.cnt = a.sp_cnt; sp.part = bn_partial;
+      static const bool fuse_bn = !getenv("VP_SMALLP_NO_BNBWD");
+      const bool last = !ts.is_input && !gpass && ts.has_bn && ts.producer >= 0 && ts.dz_writes == ts.n_bwd_consumers && n.groups == 1;
+      if (fuse_bn && last) {
+        const Layer& Lp = n.l[ts.producer];
+        sp.mode = SP_BWD_BN;
+        sp.bn_y = ts.y; sp.bn_mu = ts.bn.mu; sp.bn_rstd = ts.bn.rstd; sp.bn_gamma = n.params + Lp.gamma_off;
+        sp.c1 = ts.bn.c1; sp.c2 = ts.bn.c2;
+        sp.dgamma = n.grads + Lp.gamma_off; sp.dbeta = n.grads + Lp.beta_off; sp.dbias_zero = n.grads + Lp.b_off;
+        ts.bn_bwd_done = true;
+      } else {
+        sp.mode = SP_PLAIN;
+      }
+      VP_HIP_CHECK(launch_smallp_fused(sp, h->bf16, st));
+      continue;
+    }
     VP_HIP_CHECK(launch_igemm(a, h->bf16, alt ? L.bwd_alt[s].cfg : L.bwd[s].cfg, st));
   }
   return VP_OK;
@@ -687,6 +772,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
 static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample0, int nb, int group0, int ng, hipStream_t st,
                       int ss = 0, bool gpass = false) {
   Tens& t = n.t[L.out];
+  if (!gpass && t.bn_bwd_done) { t.bn_bwd_done = false; return VP_OK; }   // done inside the last gradient contribution's launch (conv_smallp.hip)
   BnArgs b;
   memset(&b, 0, sizeof(b));
   b.y = (const char*)t.y + (size_t)sample0 * t.H * t.W * t.C * h->es;
@@ -710,6 +796,29 @@ static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+static bool g_phase_marks = false;   // vp_tune("phase_marks", 0 / 1)
+void vp_phase_marks_enable(int on) { g_phase_marks = on != 0; }
+static void phase_mark(vp_pixrefer* h, hipStream_t st, int idx) {
+  if (!g_phase_marks || idx >= 12) return;
+  if (!h->marks_made) { for (int i = 0; i < 12; ++i) (void)hipEventCreate(&h->mark[i]); h->marks_made = true; }
+  (void)hipEventRecord(h->mark[idx], st);
+  if (idx + 1 > h->nmark) h->nmark = idx + 1;
+}
+// ms between consecutive marks of the last step: [0] generator forward (to the composite), [1] discriminator / VGG forward + losses,
+// [2] generator-loss pass through D and VGG + composite backward, [3] generator backward stage 0, [4] stage 1, [5] stage 2 + joins
+int vp_pixrefer_phase_ms(vp_pixrefer_t* h, float* ms, int cap) {
+  if (!h || !ms) return 0;
+  int n = 0;
+  for (int i = 0; i + 1 < h->nmark && n < cap; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(h->mark[i + 1]) != hipSuccess || hipEventElapsedTime(&t, h->mark[i], h->mark[i + 1]) != hipSuccess) {
+      (void)hipGetLastError();        // (a mark that was never recorded: not an error of the step)
+      break;
+    }
+    ms[n++] = t;
+  }
+  return n;
+}
 static bool g_overlap_on = true;     // vp_tune("overlap", 0 / 1): per-kernel timing (bench.py's profile pass) needs one stream
 void vp_overlap_enable(int on) { g_overlap_on = on != 0; }
 // where vp_pixrefer_backward starts the discriminator-loss pass on the side stream: 0 = at once, 1 = behind the generator-loss pass
@@ -873,6 +982,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
   for (Net* n : {&h->G, &h->D, &h->V}) {
     if (n->descs.empty()) continue;
     VP_HIP_CHECK(hipMemcpyAsync(n->d_descs, n->descs.data(), n->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+    VP_HIP_CHECK(hipMemsetAsync(n->sp_cnt, 0, (n->sp_cnt_n + 1) * sizeof(unsigned), st));
   }
   VP_HIP_CHECK(hipStreamSynchronize(st));   // descs are host vectors owned by the handle; copy is complete
   h->overlap = false; h->forked = false;
@@ -894,6 +1004,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
 
 void vp_pixrefer_destroy(vp_pixrefer_t* h) {
   if (!h) return;
+  if (h->marks_made) for (int i = 0; i < 12; ++i) (void)hipEventDestroy(h->mark[i]);
   if (h->overlap) {
     (void)hipStreamSynchronize(h->side);
     (void)hipEventDestroy(h->ev_fork);
@@ -942,6 +1053,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   memset(&pi, 0, sizeof(pi));
   pi.inputs = inputs; pi.fg_inputs = fg_inputs; pi.gin = h->gin; pi.gfg = h->gfg; pi.din = h->din; pi.vin = h->vin;
   pi.N = N; pi.HW = H * H; pi.train = d.training;
+  phase_mark(h, st, 0);
   VP_HIP_CHECK(launch_pack_inputs(pi, bf, st));
 
   // the real half of the perceptual trunk only needs the packed inputs: side stream, under the generator forward
@@ -985,6 +1097,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   ca.y4 = h->y4; ca.targets = targets; ca.masks = masks; ca.o4 = h->o4; ca.outputs = h->outputs; ca.outputs_fg = h->outputs_fg;
   ca.din = h->din; ca.vin = h->vin; ca.partial = h->comp_partial; ca.N = N; ca.HW = H * H; ca.train = d.training;
   VP_HIP_CHECK(launch_composite_fwd(ca, bf, st));
+  phase_mark(h, st, 1);
   if (!d.training) return VP_OK;
 
   // discriminator on [real1 | real2 | fake] (pixrefer.py:295-306).  It and the fake half of the VGG trunk both hang off the
@@ -1051,6 +1164,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   lf.n_out = (double)N * H * H * 3; lf.n_feat = (double)pa.half; lf.losses = h->losses;
   lf.l1_weight = d.l1_weight; lf.gan_weight = d.gan_weight;
   VP_HIP_CHECK(launch_loss_final(lf, st));
+  phase_mark(h, st, 2);
   return VP_OK;
 }
 
@@ -1096,6 +1210,7 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
   h->dfork_pending = 0;
   if (rc) return rc;
   VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+  phase_mark(h, st, 7);
   return VP_OK;
 }
 
@@ -1268,7 +1383,8 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   ca.targets = h->in_targets; ca.masks = h->in_masks; ca.o4 = h->o4; ca.outputs = h->outputs;
   ca.d_din = h->d_din; ca.d_vin = h->d_vin; ca.dy4 = h->dy4; ca.N = N; ca.HW = H * H; ca.l1_weight = d.l1_weight;
   VP_HIP_CHECK(launch_composite_bwd(ca, bf, st));
-  for (Tens& t : G.t) t.dz_written = false;
+  phase_mark(h, st, 3);
+  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; }
   }
   // (d) generator, last layer first.  Below merged_encoder_2 the two encoder branches are independent again: the foreground
   // branch (encoder_fg_4 .. encoder_fg_1) runs on the branch stream, joined before this call returns control of `st`
@@ -1286,6 +1402,8 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     }
     hipStream_t s2 = fg ? h->branch : st;
     const int ss = fg ? 2 : 0;
+    if (i == i_md5 - 1) phase_mark(h, st, 4);
+    if (i == i_me2 - 1) phase_mark(h, st, 5);
     if (L.has_bn) if ((rc = run_bn_bwd(h, G, L, true, 0, N, 0, 1, s2, ss))) return rc;
     if (wsplit && !fg) {
       // the weight gradient of a layer hangs off the chain (only its data gradient feeds the next layer): branch stream
@@ -1314,6 +1432,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     VP_HIP_CHECK(hipEventRecord(h->ev_bjoin, h->branch));
     VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
   }
+  if (stage < 0 || stage == 2) phase_mark(h, st, 6);
   return VP_OK;
 }
 

@@ -245,6 +245,13 @@ class PixReferEngine:
     self.L.vp_profile_enable(int(on))
     self.L.vp_tune(b"overlap", 0 if on else 1)
 
+  def phase_ms(self):
+    """After vp_tune("phase_marks", 1) and a step on a training plan: milliseconds of the step's phases on the caller's stream
+    (see include/vp_hip.h, vp_pixrefer_phase_ms)."""
+    buf = (ctypes.c_float * 12)()
+    n = self.L.vp_pixrefer_phase_ms(self.h, buf, 12)
+    return [float(buf[i]) for i in range(n)]
+
   def profile_collect(self):
     import json
     n = self.L.vp_profile_collect(None, 0)
