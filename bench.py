@@ -53,6 +53,8 @@ def parse_args(argv=None):
   ap.add_argument("--no-input-pipeline", action="store_true")
   ap.add_argument("--no-bfmnet-train", action="store_true", help="skip the BFMNet training-step sub-record (SURVEY.md 8f-4)")
   ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="vp_tune knob for experiments (repeatable)")
+  ap.add_argument("--grad-dtype", default="auto", choices=["auto", "f32", "bf16"],
+                  help="N > 1: transport type of the gradient all-reduce (f32 master either way); auto = the compute dtype")
   return ap.parse_args(argv)
 
 
@@ -81,10 +83,11 @@ def pmc_traffic(name):
   launch-weighted over the template variants of the class; None when not collected."""
   paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
   if not paths:
-    return None
+    return None, None
   rows = [r for r in json.load(open(paths[-1])) if r.get("class") == name]
   n = sum(r["launches"] for r in rows)
-  return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
+  src = "replayed from the committed rocprofv3 PMC summary profiles/%s (separate --pmc passes of this command; NOT measured in this run)" % os.path.basename(paths[-1])
+  return (sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None), src
 
 
 def synth_batch(n, h, seed, device):
@@ -224,11 +227,15 @@ def bfmnet_train_record(device, with_cpu, steps=30, batch=4, frames=24, nver=357
 
 
 # ---- one measured configuration on this rank -----------------------------------------------------------------------------
-def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group, profile):
+STEP_ROOFLINE_MS_BS32_256 = {"bf16": 2.65, "f32": 33.6}      # mixed per-layer roofline of the whole step (HBM 6.3 TB/s)
+
+
+def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group, profile, grad_dtype="f32"):
   import torch
   import torch.distributed as dist
   from voicepuppet_amd.engine import PixReferEngine
   eng = PixReferEngine(per_gpu, height, 64, 64, dtype=dtype, training=True)
+  eng.grad_transport = grad_dtype
   eng.load_params(eng.random_params(seed=0))   # the reference's initialisers, identical on every rank
   batch = synth_batch(per_gpu, height, 1000 + rank, device)
   lr = 3e-4
@@ -270,8 +277,12 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
     top = recs[0]
     peak = BF16_MFMA_PEAK if dtype == "bf16" else F32_MFMA_PEAK
     ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(top["name"]) if dtype == "bf16" else (None, None)
+    # the whole step against its mixed per-layer roofline, scaled to this rank's batch and image size
+    step_roof_ms = STEP_ROOFLINE_MS_BS32_256[dtype] * per_gpu / 32.0 * (height / 256.0) ** 2
     res["roofline"] = {"kernel": top["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                       "frac": ach / peak, "traffic": pmc_traffic(top["name"]) if dtype == "bf16" else None,
+                       "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                       "step_roofline_ms": step_roof_ms, "step_frac": step_roof_ms / ms,
                        "avg_launch_ms": top["ms"] / top["calls"], "launches_per_step": top["calls"] / psteps,
                        "algorithmic_bytes_per_launch": top["bytes"] / top["calls"],
                        "algorithmic_flops_per_launch": top["flops"] / top["calls"]}
@@ -351,18 +362,32 @@ def main():
     group = dist.group.WORLD
     assert dist.get_world_size() == args.gpus
 
+  grad_dtype = args.dtype if args.grad_dtype == "auto" else args.grad_dtype
+  dist_info = None
+  if world > 1:
+    # proof of the run's shape for the scaling record: ranks, the device each one drives, the collective library
+    mine = {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(local),
+            "pci_bus_id": getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None)}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine, group=group)
+    try:
+      rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+      rccl = None
+    dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl, "ranks": gathered,
+                 "grad_transport": grad_dtype, "gradient_bytes_per_step_per_rank": int((35158852 + 2769601) * (2 if grad_dtype == "bf16" else 4))}
   if args.tune:
     from voicepuppet_amd import _lib
     for kv in args.tune:
       k, v = kv.split("=")
       _lib.check(_lib.lib().vp_tune(k.encode(), int(v)), "vp_tune " + kv)
   main_res = run_config(per_gpu_batch(args, args.scaling, world), args.height, args.dtype, args.steps, args.warmup,
-                        rank, world, device, group, not args.no_profile)
+                        rank, world, device, group, not args.no_profile, grad_dtype)
   other = None
   if world > 1 and not args.no_other_scaling:
     mode = "weak" if args.scaling == "strong" else "strong"
     other = run_config(per_gpu_batch(args, mode, world), args.height, args.dtype, args.steps, args.warmup,
-                       rank, world, device, group, False)
+                       rank, world, device, group, False, grad_dtype)
     other["scaling"] = mode
   f32 = None
   if world == 1 and args.dtype == "bf16" and not args.no_f32:
@@ -389,6 +414,8 @@ def main():
                       "global_batch": n * world, "per_gpu_batch": n, "parallelism": "dp%d" % world},
            "roofline": main_res.get("roofline"), "kernels": main_res.get("kernels"),
            "conv_launches_per_step": main_res.get("conv_launches_per_step"), "step_tflops": main_res["step_tflops"]}
+    if dist_info is not None:
+      out["distributed"] = dist_info
     if other is not None:
       out["other_scaling"] = other
     if f32 is not None:

@@ -106,17 +106,29 @@ int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream);
 int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream);
 /* vp_pixrefer_backward runs the two (independent) halves CONCURRENTLY: the discriminator-loss pass on a HIP stream the handle
  * owns, forked from and joined into `stream` with events (no host blocking; bit-identical results).  The same for a host with
- * work of its own in between: _fork starts the discriminator-loss pass behind everything already enqueued on `stream`, _join
- * makes `stream` wait for it; grads_d is final after the join.  (VP_NO_OVERLAP=1 in the environment at create time: both run
+ * work of its own in between: _fork schedules the discriminator-loss pass (it starts inside stage 0 of the generator backward,
+ * behind the generator-loss pass through the discriminator - or at once with vp_tune("d_backward_fork", 0)), _join makes `stream`
+ * wait for it; grads_d is final after the join, which may come after any stage (the later, the more of the pass is hidden).  (VP_NO_OVERLAP=1 in the environment at create time: both run
  * on `stream`, one after the other.) */
 int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream);
 int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream);
 /* The same pass in vp_pixrefer_backward_g_stages() = 3 consecutive stages (stage < 0: all).  After stage s a contiguous
  * range of the generator gradient arena is final (0: from generator/merged_decoder_5 to the end; 1: from
  * generator/merged_encoder_2 up to merged_decoder_5; 2: the rest), so a data-parallel host can start that bucket's
- * all-reduce while the next stage computes. */
+ * all-reduce while the next stage computes.
+ * STREAM-ORDER CONTRACT for a host that hands an arena range to another stream (a collective): the executor runs parts of a stage
+ * on HIP streams of its own, but before vp_pixrefer_backward_g_stage / vp_pixrefer_backward_d_join return they have made `stream`
+ * wait (hipStreamWaitEvent) for every kernel that writes the range the call completes.  An event recorded on `stream` right after
+ * the call therefore covers the whole range; the collective's stream must wait for THAT event (voicepuppet_amd/parallel.py
+ * GradExchange does) - it must not read the arena on the strength of host-side ordering alone. */
 int vp_pixrefer_backward_g_stages(void);
 int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream);
+/* Data parallel: tf.train.AdamOptimizer + weight re-pack of ONE gradient bucket on `stream`, for a host that has just all-reduced
+ * it there: which = 0 generator (bucket = the stage that completed it), which = 1 discriminator (bucket 0).  `stream` must be
+ * ordered behind that stage (see the contract above).  Bit-identical to vp_adam_tf over the whole arena; after the four buckets of
+ * a step the packed weights are current (the next forward re-packs nothing). */
+int vp_pixrefer_update_bucket(vp_pixrefer_t* h, int which, int bucket, float* m, float* v, int step_t, float lr, float beta1,
+                              float beta2, float eps, void* stream);
 
 /* Named device buffers ("nodes" of pixrefer.py:356-438 and every intermediate):
  *   "Outputs_raw" [N,H,H,3] f32 in [-1,1], "Outputs_FG" [N,H,H,3] f32, "gen_out4" [N,H,H,4] f32,
@@ -153,6 +165,12 @@ int vp_tune(const char* key, int value);
  * discriminator / VGG forward + losses, generator-loss pass through D and VGG + composite backward (including the host gap between
  * the forward and the backward call), generator backward stage 0, 1, 2, join of the discriminator-loss pass.  Returns the number written. */
 int vp_pixrefer_phase_ms(vp_pixrefer_t* h, float* ms, int cap);
+
+/* Data parallel, optional bf16 transport of a gradient bucket (the f32 arena stays the master copy): round n floats to bf16
+ * (nearest even) into a communication buffer; after the bf16 all-reduce (sum) write them back as f32 times `scale` (= 1 / world).
+ * src / dst float pointers 32-byte aligned, the bf16 buffer 16-byte aligned.  No counterpart in the reference (single device). */
+int vp_grad_pack_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+int vp_grad_unpack_bf16(const void* src_bf16, float* dst, size_t n, float scale, void* stream);
 
 /* theta -= lr_t * m / (sqrt(v) + eps) with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) (TF formulation) */
 int vp_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, int step_t,

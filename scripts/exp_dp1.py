@@ -29,10 +29,8 @@ dist.init_process_group("nccl", device_id=dev)
 t = torch.ones(1 << 20, device=dev); dist.all_reduce(t); torch.cuda.synchronize()      # communicator + its streams exist now
 plain = timed(lambda: eng.train_step(*batch, lr=3e-4))
 print("bs%d: step before the process group exists %.3f ms, after %.3f ms" % (n, before, plain))
-noop = timed(lambda: eng.train_step(*batch, lr=3e-4, group=dist.group.WORLD))      # DP schedule, collectives skipped (one rank)
-real = parallel.allreduce_mean
-parallel.allreduce_mean = lambda t, group=None, async_op=False, skip_single=True: real(t, group, async_op, False)
-import voicepuppet_amd.engine as E
-full = timed(lambda: eng.train_step(*batch, lr=3e-4, group=dist.group.WORLD))      # DP schedule with the collectives executed
-print("bs%d: single-GPU step %.3f ms | DP schedule without collectives %.3f ms | DP schedule with one-rank RCCL all-reduces %.3f ms" % (n, plain, noop, full))
+full = timed(lambda: eng.train_step(*batch, lr=3e-4, group=dist.group.WORLD))      # DP schedule, collectives executed on the communication stream
+eng.grad_transport = "bf16"
+half = timed(lambda: eng.train_step(*batch, lr=3e-4, group=dist.group.WORLD))      # ... with bf16 transport (pack + bf16 all-reduce + unpack)
+print("bs%d: single-GPU step %.3f ms | DP schedule with one-rank RCCL all-reduces: f32 %.3f ms, bf16 transport %.3f ms" % (n, plain, full, half))
 dist.destroy_process_group()

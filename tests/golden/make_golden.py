@@ -10,6 +10,9 @@
   full_width.npz     config 1 proper: the generator forward on sample22 at ngf = 64; and three consecutive full G+D steps at
                      ngf = ndf = 64, N = 1 (losses per step, step-1 output, per-tensor gradient norms, post-step parameter sums)
                      (`python tests/golden/make_golden.py full`: ~10 minutes)
+  full_width_n4.npz  the same three steps on a batch of FOUR different samples (every batch-norm has real statistics, the 1x1
+                     bottleneck included), with a strided sample of every step-1 gradient tensor
+                     (`python tests/golden/make_golden.py full_n4`: ~10 minutes)
   frame_pack.npz     input pipeline: uint8 triptych frames + crops -> packed float tensors by the host path (PIL bilinear)
   logmel.npz         log-mel of a seeded 4096-sample chirp+noise, and the 257x80 mel matrix
   bfmnet.npz         BFMNet coefficients for a seeded 5-frame clip (parameters regenerated from the seed)
@@ -138,6 +141,70 @@ def full_width(panels, bg):
   np.savez_compressed(os.path.join(HERE, "full_width.npz"), **d)
 
 
+def grad_sample_index(size, want):
+  """Deterministic strided subsample of a flattened gradient tensor (the full-width tensors hold up to 8.4 M floats each)."""
+  stride = max(1, size // want)
+  return np.arange(0, size, stride)[:want]
+
+
+BOTTLENECK = ("merged_encoder_2", "merged_encoder_3", "merged_encoder_4", "merged_encoder_5",
+              "merged_decoder_5", "merged_decoder_4", "merged_decoder_3", "merged_decoder_2")
+
+
+def full_width_batch(panels, bg, nsamp=4):
+  """the N = 1 fixture leaves the two deepest layers with zero-variance batch statistics and exactly-zero weight
+  gradients (and N = 2 is hardly better: a batch-norm over two values has an analytically vanishing backward pass, so the encoder
+  gradients below it are rounding noise).  This one runs THREE consecutive G+D steps at ngf = ndf = 64 on a batch of FOUR different
+  samples (sample/22.jpg and three mirrored / shifted / re-lit variants), so every batch-norm has real statistics and every layer
+  a real gradient; besides losses, output crops, gradient norms and post-step parameter sums / update norms it keeps a strided
+  SAMPLE of every step-1 gradient tensor (32768 values of the eight bottleneck kernels, 4096 of the others) so the device can be
+  compared element-wise, not only by norm.  The batch is also the 4-per-GPU share of the 8-GPU strong-scaling run."""
+  ngf = ndf = 64
+  seed = 13
+  frame, face3d, matte = [p.astype(np.float64) / 255.0 for p in panels]
+  # four different samples: the original, a mirrored re-lit one, a shifted darker one, an upside-down one with a shrunken matte
+  variants = [(frame, face3d, matte),
+              (frame[:, ::-1] * 0.8 + 0.1, np.roll(face3d[:, ::-1], 7, axis=0), matte[:, ::-1]),
+              (np.roll(frame, 19, axis=1) * 0.6, np.roll(face3d, 19, axis=1) ** 1.5, np.roll(matte, 19, axis=1)),
+              (frame[::-1] * 0.5 + 0.4, face3d[::-1], matte[::-1] * (np.roll(matte[::-1], 11, axis=0) > 0.5))][:nsamp]
+  inputs = np.stack([np.concatenate([face3d, v[1]], axis=-1) for v in variants])
+  fg = np.stack([np.concatenate([frame * matte, v[0] * v[2]], axis=-1) for v in variants])
+  targets, masks = np.stack([v[0] for v in variants]), np.stack([v[2] for v in variants])
+  p = {k: v.astype(np.float64) for k, v in ref.init_params(ngf, ndf, seed=seed, dtype=np.float32).items()}
+  d = {"seed": seed, "ngf": ngf, "inputs": (inputs * 255).round().astype(np.uint8), "fg_inputs": (fg * 255).round().astype(np.uint8),
+       "targets": (targets * 255).round().astype(np.uint8), "masks": (masks * 255).round().astype(np.uint8)}
+  # the device is fed exactly these uint8 / 255 values
+  inputs, fg, targets, masks = [d[k].astype(np.float64) / 255.0 for k in ("inputs", "fg_inputs", "targets", "masks")]
+  st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf, f32_probs=True)
+  keys = ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss")
+  losses, sums, norms2, sat = [], [], [], []
+  names = None
+  for step in range(3):
+    nodes = st.step(inputs, fg, targets, masks)
+    if names is None:
+      names = sorted(nodes["Gen_grads"]) + sorted(nodes["Discrim_grads"])
+      d["grad_names"] = np.array(names)
+      d["Outputs_crop"] = nodes["Outputs"][:, 64:192, 64:192].astype(np.float32)
+      grads = [nodes["Gen_grads" if n.startswith("generator") else "Discrim_grads"][n] for n in names]
+      d["grad_norms"] = np.array([np.linalg.norm(g) for g in grads])
+      samp = []
+      for n, g in zip(names, grads):
+        want = 32768 if (n.endswith("kernel") and any(("/%s/" % b) in n for b in BOTTLENECK)) else 4096
+        samp.append(g.reshape(-1)[grad_sample_index(g.size, want)])
+      d["grad_sample_sizes"] = np.array([len(x) for x in samp])
+      d["grad_samples"] = np.concatenate(samp).astype(np.float32)
+    losses.append([nodes[k] for k in keys])
+    sat.append(int((nodes["Predict_fake"] == 1).sum()))
+    sums.append([st.p[n].sum() for n in names])
+    norms2.append([np.linalg.norm(st.p[n] - p[n]) for n in names])
+    print("full-width N=%d step" % nsamp, step, dict(zip(keys, losses[-1])), flush=True)
+  d["losses"] = np.array(losses)
+  d["saturated_fake_predictions"] = np.array(sat)
+  d["param_sums_after"] = np.array(sums)
+  d["update_norms_after"] = np.array(norms2)
+  np.savez_compressed(os.path.join(HERE, "full_width_n%d.npz" % nsamp), **d)
+
+
 def frame_pack():
   """Input-pipeline fixture: uint8 triptych frames + crops -> the four packed float tensors, computed by the
   host path (PIL bilinear on float planes standing in for cv2.resize, generator.py:956-1019)."""
@@ -220,6 +287,9 @@ if __name__ == "__main__":
     sys.exit(0)
   if sys.argv[1:] == ["full"]:
     full_width(*sample22())
+    sys.exit(0)
+  if sys.argv[1:] == ["full_n4"]:
+    full_width_batch(*sample22(), nsamp=4)
     sys.exit(0)
   if sys.argv[1:] == ["raster"]:
     raster()

@@ -86,3 +86,64 @@ def test_bfmnet_bf16_trunk(b, t, lens):
   assert e[0] < 4e-2 and e[1] < 2e-1 and e[2] < 2e-1, e
   for i, n in enumerate(lens):
     assert np.all(rnn[i, n:] == 0)
+
+
+def test_config3_batch_64_properties():
+  """BASELINE config 3 at its own size (64 clips x 1 s at 16 kHz -> log-mel [64,125,80] -> BFMNet [64,25,64]): the float64 oracle
+  needs minutes for that, so the full size is checked through size-independent properties, anchored on an oracle comparison of
+  three of its clips:
+    * clips are independent: every row of the batch-64 result equals the same clip run in a batch of 4 (different GEMM tiles /
+      grids by batch size: <= 1e-4 rel-L2 through the ~50 float32 layers - measured 2e-5 - not bit-exact), and permuting the batch
+      permutes the result bit for bit;
+    * dynamic_rnn masking: rows past a clip's sequence_length are exactly zero in the recurrent output, and shortening ONE clip's
+      length leaves every other clip's coefficients bit-identical;
+    * rows 0, 31, 63 agree with the float64 oracle run on those three clips alone (1e-3, the parity tolerance above)."""
+  B, T = 64, 25
+  n = ar.pcm_length_for(T)
+  assert n == 16384
+  pcm = synth_pcm(B, n, seed=11)
+  rng = np.random.default_rng(12)
+  ears = (rng.uniform(size=(B, T, 1)) / 100).astype(np.float32)
+  lens = [T] * B
+  lens[5], lens[40] = 17, 3
+  p = ar.init_bfmnet_params(3, dtype=np.float32)
+  lm = LogMel(B, n)
+  mf = lm(torch.tensor(pcm, device="cuda"))
+  assert tuple(mf.shape) == (B, 125, 80) and torch.isfinite(mf).all()
+  eng = BFMNetEngine(B, T)
+  eng.load_params(p)
+  e = torch.tensor(ears, device="cuda")
+  out = eng.forward(e, mf, lens).clone()
+  rnn = eng.tensor("RNNModule").clone()
+  assert tuple(out.shape) == (B, T, 64) and torch.isfinite(out).all()
+  for i, k in enumerate(lens):
+    assert torch.all(rnn[i, k:] == 0)
+  # permutation equivariance, bit for bit (same plan, same kernels)
+  perm = torch.tensor(np.random.default_rng(13).permutation(B), device="cuda")
+  out_p = eng.forward(e[perm].contiguous(), mf[perm].contiguous(), [lens[int(j)] for j in perm.cpu()])
+  assert torch.equal(out_p, out[perm])
+  # shortening one clip touches no other clip
+  lens2 = list(lens)
+  lens2[9] = 11
+  out2 = eng.forward(e, mf, lens2)
+  keep = [i for i in range(B) if i != 9]
+  assert torch.equal(out2[keep], out[keep]) and not torch.equal(out2[9], out[9])
+  # batch independence: groups of 4 clips through a batch-4 plan
+  lm4, eng4 = LogMel(4, n), BFMNetEngine(4, T)
+  eng4.load_params(p)
+  worst = 0.0
+  for g0 in (0, 28, 60):
+    sl = slice(g0, g0 + 4)
+    mf4 = lm4(torch.tensor(pcm[sl], device="cuda"))
+    assert gu.rel_l2(mf4.cpu().numpy(), mf[sl].cpu().numpy()) < 1e-6
+    o4 = eng4.forward(e[sl].contiguous(), mf4, lens[sl])
+    worst = max(worst, gu.rel_l2(o4.cpu().numpy(), out[sl].cpu().numpy()))
+  assert worst < 1e-4, worst
+  # three clips against the float64 oracle
+  idx = [0, 31, 63]
+  mref = ar.extract_mfcc(pcm[idx].astype(np.float64))
+  assert gu.rel_l2(mf[idx].cpu().numpy(), mref) < 1e-4
+  ref = ar.bfmnet_fwd({k: v.astype(np.float64) for k, v in p.items()}, ears[idx].astype(np.float64), mref, [lens[i] for i in idx])
+  err = gu.rel_l2(out[idx].cpu().numpy(), ref["BFMCoeffDecoder"])
+  print("\nconfig 3 at batch 64: batch-4 vs batch-64 rows %.2e, oracle on 3 clips %.2e" % (worst, err))
+  assert err < 1e-3

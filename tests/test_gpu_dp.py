@@ -31,7 +31,7 @@ def _setup(n):
   return params, batch
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, transport="f32"):
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
   dist.init_process_group("gloo", rank=rank, world_size=world)
   torch.cuda.set_device(0)
@@ -42,6 +42,7 @@ def _worker(rank, world, port, out_dir):
   mine = [torch.tensor(b[lo:hi], device="cuda") for b in batch]
   eng = PixReferEngine(hi - lo, 256, NGF, NGF, dtype="f32", training=True)
   eng.load_params(params)
+  eng.grad_transport = transport
   for _ in range(STEPS):
     eng.train_step(*mine, lr=LR, group=dist.group.WORLD)
   torch.cuda.synchronize()
@@ -50,9 +51,13 @@ def _worker(rank, world, port, out_dir):
   dist.destroy_process_group()
 
 
-def test_two_ranks_equal_sequential_microbatches_on_engine_gradients(tmp_path):
+@pytest.mark.parametrize("transport", ["f32", "bf16"])
+def test_two_ranks_equal_sequential_microbatches_on_engine_gradients(tmp_path, transport):
+  """transport = 'bf16' (parallel.GradExchange): every rank rounds its gradients to bf16, the sum is formed in bf16, the mean is
+  written back as f32 - the sequential run does exactly that arithmetic on its two micro-batch gradients, so the equality stays
+  bit for bit (f32 master parameters and Adam state in both)."""
   world = 2
-  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), transport), nprocs=world, join=True)
   from voicepuppet_amd.engine import PixReferEngine
   params, batch = _setup(world)
   eng = PixReferEngine(1, 256, NGF, NGF, dtype="f32", training=True)
@@ -65,8 +70,12 @@ def test_two_ranks_equal_sequential_microbatches_on_engine_gradients(tmp_path):
       eng.backward()
       gs.append(eng.grads_g.clone())
       ds.append(eng.grads_d.clone())
-    eng.grads_g.copy_((gs[0] + gs[1]) / world)
-    eng.grads_d.copy_((ds[0] + ds[1]) / world)
+    if transport == "bf16":
+      eng.grads_g.copy_((gs[0].bfloat16() + gs[1].bfloat16()).float() * (1.0 / world))
+      eng.grads_d.copy_((ds[0].bfloat16() + ds[1].bfloat16()).float() * (1.0 / world))
+    else:
+      eng.grads_g.copy_((gs[0] + gs[1]) / world)
+      eng.grads_d.copy_((ds[0] + ds[1]) / world)
     eng.adam_step(LR)
   torch.cuda.synchronize()
   for r in range(world):

@@ -18,6 +18,14 @@ import gpu_util as gu
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def grad_sample_index(size, want):
+  """The strided subsample tests/golden/make_golden.py keeps of a flattened gradient tensor."""
+  stride = max(1, size // want)
+  return np.arange(0, size, stride)[:want]
+
+
 KEYS = ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss")
 
 
@@ -103,6 +111,89 @@ def test_three_consecutive_full_width_steps(fixture, dtype, tol_pix, tol_loss, t
         % (dtype, pix, worst_loss, worst_norm, worst_upd, worst_sum))
   assert pix < tol_pix and worst_loss < tol_loss and late < tol_late, (pix, worst_loss, late)
   assert worst_norm < tol_norm and worst_upd < tol_upd and worst_sum < tol_upd
+
+
+BOTTLENECK = ("merged_encoder_2", "merged_encoder_3", "merged_encoder_4", "merged_encoder_5",
+              "merged_decoder_5", "merged_decoder_4", "merged_decoder_3", "merged_decoder_2")
+
+
+@pytest.mark.parametrize("dtype,tol_pix,tol_loss,tol_late,tol_grad,tol_grad_deep,tol_upd",
+                         [("f32", 1e-3, 1e-4, 3e-2, 1.5e-2, 1.5e-2, 1e-1), ("bf16", 3e-2, 5e-2, 1e-1, 6e-1, 1.0, 5e-1)])
+def test_three_full_width_steps_on_a_batch_of_four(dtype, tol_pix, tol_loss, tol_late, tol_grad, tol_grad_deep, tol_upd):
+  """tests/golden/full_width_n4.npz (make_golden.py full_n4): FOUR different samples at ngf = ndf = 64 (also the 4-per-GPU share of
+  the 8-GPU strong-scaling run), so the 1x1 bottleneck batch-norm has real statistics and merged_encoder_5 / merged_decoder_5 real
+  gradients (at N = 1 they are exactly zero; at N = 2 a two-value batch-norm has an analytically vanishing backward pass), and the
+  gradients are compared ELEMENT-WISE on the fixture's strided sample of every tensor (32768 values of each of the eight bottleneck
+  kernels), not only by norm.  f32: the north-star tolerances (pixels 1e-3, losses 1e-4); gradient samples 1.5e-2 of a tensor
+  (the float32 forward flips a handful of ReLU / sign() masks the float64 oracle does not, see tests/test_gpu_step.py).
+  bf16: stated, not hidden - pixels 2.2e-3, losses 5.7e-3, gradient NORMS within 6.4e-2 of the oracle's, but element-wise the
+  gradient tensors of the encoder side differ by 0.35-0.75 rel-L2 (merged_encoder_5 worst): every gradient below the bottleneck
+  passes the batch-norm backward of N*1*1 .. N*4*4 values per channel, which subtracts two projections from a bf16-stored tensor
+  (cancellation), and ~0.3 % of the ReLU masks per layer flip against a float64 forward.  Bounds: norms 1e-1, samples 0.6 / 1.0."""
+  d = np.load(os.path.join(G, "full_width_n4.npz"))
+  params = ref.init_params(int(d["ngf"]), int(d["ngf"]), seed=int(d["seed"]), dtype=np.float32)
+  batch = [d[k].astype(np.float32) / 255.0 for k in ("inputs", "fg_inputs", "targets", "masks")]
+  eng = PixReferEngine(4, 256, 64, 64, dtype=dtype, training=True)
+  eng.load_params(params)
+  dev = [torch.tensor(b, device="cuda") for b in batch]
+  names = [str(n) for n in d["grad_names"]]
+  sizes = d["grad_sample_sizes"]
+  offs = np.concatenate([[0], np.cumsum(sizes)])
+  p0 = {}
+  for w in (0, 1):
+    p0.update(eng.get_params(w))
+  late, worst_upd, worst_sum = 0.0, 0.0, 0.0
+  table = []
+  for step in range(3):
+    eng.forward(*dev)
+    eng.backward()
+    torch.cuda.synchronize()
+    got = eng.losses()
+    errs = [abs(got[k] - d["losses"][step, i]) / abs(d["losses"][step, i]) for i, k in enumerate(KEYS)]
+    table.append("step %d: " % step + ", ".join("%s %.2e" % (k, e) for k, e in zip(KEYS, errs)))
+    if step == 0:
+      worst_loss = max(errs)
+      pix = gu.rel_l2(((eng.tensor("Outputs_raw") + 1) / 2).cpu().numpy()[:, 64:192, 64:192], d["Outputs_crop"])
+      grads = dict(eng.get_params(0, src=eng.grads_g), **eng.get_params(1, src=eng.grads_d))
+      per, nerr = {}, {}
+      for j, n in enumerate(names):
+        g = grads[n].astype(np.float64).reshape(-1)
+        r = d["grad_samples"][offs[j]:offs[j + 1]].astype(np.float64)
+        got_s = g[grad_sample_index(g.size, 32768 if len(r) > 4096 else 4096)]
+        assert got_s.shape == r.shape, n
+        if np.all(r == 0):
+          assert np.all(got_s == 0), n      # the bias of a conv in front of a batch-norm: analytically zero
+          continue
+        per[n] = gu.rel_l2(got_s, r)
+        nerr[n] = abs(np.linalg.norm(g) - d["grad_norms"][j]) / d["grad_norms"][j]
+      deep = {n: v for n, v in per.items() if any(("/%s/" % b) in n for b in BOTTLENECK)}
+      rest = {n: v for n, v in per.items() if n not in deep}
+      assert len(deep) >= 24                      # kernel, gamma, beta of eight layers: none of them is degenerate at N = 4
+      top = sorted(((v, n) for n, v in per.items()), reverse=True)[:6]
+    else:
+      late = max(late, max(errs))
+    eng.adam_step(ref.learning_rate(3e-4, 2 * step, 1000, 0.999))
+    torch.cuda.synchronize()
+    now = dict(eng.get_params(0), **eng.get_params(1))
+    for j, n in enumerate(names):
+      upd = np.linalg.norm(now[n].astype(np.float64) - p0[n].astype(np.float64))
+      ref_upd = d["update_norms_after"][step, j]
+      if ref_upd == 0:
+        assert upd == 0, n
+        continue
+      worst_upd = max(worst_upd, abs(upd - ref_upd) / ref_upd)
+      scale = max(abs(d["param_sums_after"][step, j]), np.sqrt(now[n].size) * 0.02)
+      worst_sum = max(worst_sum, abs(now[n].astype(np.float64).sum() - d["param_sums_after"][step, j]) / scale)
+  print("\n" + "\n".join(table))
+  print("[%s] N=4 full width: step-1 pixels %.3e, worst loss %.3e, gradient samples: bottleneck worst %.3e, others worst %.3e, late losses %.3e, "
+        "update norms %.3e, param sums %.3e\n worst tensors: %s" % (dtype, pix, worst_loss, max(deep.values()), max(rest.values()), late, worst_upd,
+                                                                   worst_sum, top))
+  assert pix < tol_pix and worst_loss < tol_loss and late < tol_late, (pix, worst_loss, late)
+  print(" worst gradient norms: %s" % sorted(((v, n) for n, v in nerr.items()), reverse=True)[:6])
+  assert max(nerr.values()) < (5e-3 if dtype == "f32" else 1e-1), sorted(((v, n) for n, v in nerr.items()), reverse=True)[:4]
+  assert max(rest.values()) < tol_grad, sorted(((v, n) for n, v in rest.items()), reverse=True)[:4]
+  assert max(deep.values()) < tol_grad_deep, sorted(((v, n) for n, v in deep.items()), reverse=True)[:4]
+  assert worst_upd < tol_upd and worst_sum < tol_upd
 
 
 def test_config4_per_gpu_workload_properties():

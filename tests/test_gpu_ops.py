@@ -54,6 +54,17 @@ FWD_CASES = [
 ]
 
 
+# Cases whose only purpose is to put a kernel class of the benchmark plans (tests/test_gpu_coverage.py) under the oracle: each is
+# sized so the planner makes the same family / tile decision as for the named layer of the bs-32 / bs-8 / bs-4 plans
+# (patch_min_blocks the case is planned with, case)
+CLASS_CASES = [
+    (384, (0, 8, 256, 256, 32, 128, 4, 2, 1, 0, 0, False)),   # 131072 px x 128 ch, 4x4 stride 2 (layer_2 / encoder_2 fwd at batch 32): igemm_dma 128x256
+    (384, (0, 8, 96, 96, 256, 512, 4, 1, 1, 0, 0, False)),    # 72200 px x 512 ch, K = 4096 (D layer_4 forward): igemm_ws 256x256; its backward-data: patch 256x128
+    (1, (0, 2, 64, 64, 128, 128, 4, 2, 1, 0, 0, False)),      # backward-data of a 128 -> 128 stride-2 conv (layer_3 geometry): patch2 128x256
+    (384, (0, 2, 8, 8, 64, 128, 4, 2, 1, 0, 0, False)),       # 4 x 4 output grid (fewer than 32 K slots per image): the generic wgrad_tr 256x128
+]
+
+
 @pytest.fixture(autouse=True)
 def small_grids_on_the_patch_kernel():
   L = _lib.lib()
@@ -181,6 +192,18 @@ def test_batchnorm_stats_and_backward(pixels, c, dtype):
   assert gu.rel_l2(dyd.float().cpu().numpy(), dyr.reshape(pixels, c)) < TOL[dtype]
   assert gu.rel_l2(outs[4].cpu().numpy(), dgr) < 1e-4
   assert gu.rel_l2(outs[5].cpu().numpy(), dbr) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("minblk,case", CLASS_CASES)
+def test_more_kernel_classes(minblk, case, dtype):
+  """Forward, backward-data and backward-weight parity of the class cases (see CLASS_CASES)."""
+  L = _lib.lib()
+  L.vp_tune(b"patch_min_blocks", minblk)
+  test_conv_fwd(case, dtype)
+  if case[5] >= 8 and (case[5] & (case[5] - 1)) == 0:
+    test_conv_bwd_data(case, dtype)
+    test_conv_bwd_weight(case, dtype)
 
 
 def _profile_classes(fn):

@@ -145,6 +145,7 @@ struct vp_pixrefer {
   int n_comp, n_perc;
   // vp_pixrefer_backward_update: Adam state of the two optimisers + this step's hyper-parameters; active only inside that call
   struct { bool active, d_done; float *m_g, *v_g, *m_d, *v_d; float lr_t_g, lr_t_d, beta1, beta2, eps; } upd;
+  int upd_mask;               // vp_pixrefer_update_bucket: buckets of the current step already updated + re-packed (bits 0-2 generator, 3 discriminator)
   bool params_dirty;
   bool vgg_dirty;             // set by vp_pixrefer_params_changed (a host wrote the arenas), cleared by the next forward; vp_pixrefer_optimizer_stepped leaves it
   const float *in_targets, *in_masks;
@@ -1022,6 +1023,7 @@ int vp_pixrefer_params_changed(vp_pixrefer_t* h) {
   if (!h) return VP_ERR_ARG;
   h->params_dirty = true;
   h->vgg_dirty = true;
+  h->upd_mask = 0;
   return VP_OK;
 }
 
@@ -1247,6 +1249,41 @@ int vp_pixrefer_backward_update(vp_pixrefer_t* h, float* m_g, float* v_g, float*
   return VP_OK;
 }
 
+// Data parallel: the Adam update + weight re-pack of ONE gradient bucket, for a host that has just all-reduced that bucket on `stream`
+// (voicepuppet_amd/parallel.py GradExchange): which = 0 generator, bucket = the backward_g stage that completed it; which = 1
+// discriminator (bucket 0 = the whole arena).  Same kernels on the same values as vp_adam_tf over the whole arena + the re-pack of
+// the next forward, so parameters are bit-identical; once all four buckets of a step are through, the packed weights are current.
+// The caller orders `stream` behind the stage that completed the bucket (the bucket's layers are no longer read by the backward pass).
+int vp_pixrefer_update_bucket(vp_pixrefer_t* h, int which, int bucket, float* m, float* v, int step_t, float lr, float beta1, float beta2,
+                              float eps, void* stream) {
+  if (!h || !h->d.training || !m || !v || step_t < 1 || which < 0 || which > 1 || bucket < 0 || bucket > (which ? 0 : 2)) {
+    set_err("vp_pixrefer_update_bucket: bad argument");
+    return VP_ERR_ARG;
+  }
+  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, step_t)) / (1.0 - pow((double)beta1, step_t)));
+  h->upd.beta1 = beta1; h->upd.beta2 = beta2; h->upd.eps = eps;
+  int rc;
+  if (which == 1) {
+    rc = update_range(h, h->D, m, v, lr_t, 0, h->D.nparams, 0, (int)h->D.l.size() - 1, (hipStream_t)stream);
+    h->upd_mask |= 8;
+  } else {
+    Net& G = h->G;
+    int i_md5 = -1, i_me2 = -1;
+    for (int i = 0; i < (int)G.l.size(); ++i) {
+      if (G.l[i].scope == "merged_decoder_5") i_md5 = i;
+      if (G.l[i].scope == "merged_encoder_2") i_me2 = i;
+    }
+    const int l0 = bucket == 0 ? i_md5 : (bucket == 1 ? i_me2 : 0);
+    const int l1 = bucket == 0 ? (int)G.l.size() - 1 : (bucket == 1 ? i_md5 - 1 : i_me2 - 1);
+    const size_t off0 = G.l[l0].w_off, off1 = l1 + 1 < (int)G.l.size() ? G.l[l1 + 1].w_off : G.nparams;
+    rc = update_range(h, G, m, v, lr_t, off0, off1, l0, l1, (hipStream_t)stream);
+    h->upd_mask |= 1 << bucket;
+  }
+  if (rc) return rc;
+  if (h->upd_mask == 15) { h->upd_mask = 0; h->params_dirty = false; }
+  return VP_OK;
+}
+
 int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d: needs a training plan"); return VP_ERR_STATE; }
   return backward_d_on(h, (hipStream_t)stream, false);
@@ -1260,16 +1297,19 @@ int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   h->forked = h->overlap && g_overlap_on;
   if (!h->forked) return backward_d_on(h, st, false);
-  VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
-  VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  const int rc = backward_d_on(h, h->side, true);
-  if (rc) return rc;
-  VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+  // the pass starts where vp_pixrefer_backward starts it (vp_tune "d_backward_fork", default: inside stage 0 of the generator
+  // backward, behind the generator-loss pass through D and the VGG trunk, i.e. under the generator's own layers); 0: at once
+  h->dfork_pending = g_dfork_point;
+  if (h->dfork_pending == 0) return fork_d(h, st);
   return VP_OK;
 }
 
 int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d_join: needs a training plan"); return VP_ERR_STATE; }
+  if (h->forked && h->dfork_pending) {   // (no stage 0 ran since the fork: start the pass now)
+    const int rc = fork_d(h, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   if (h->forked) VP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0));
   h->forked = false;
   return VP_OK;
@@ -1481,6 +1521,19 @@ int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t s
     return VP_ERR_ARG;
   }
   return VP_ERR_ARG;
+}
+
+// bf16 transport of a gradient bucket: f32 range -> bf16 communication buffer, and back with the 1 / world scale (both need 32-byte
+// aligned pointers: arena offsets of whole variables are, torch allocations are)
+int vp_grad_pack_bf16(const float* src, void* dst_bf16, size_t n, void* stream) {
+  if (!src || !dst_bf16 || n < 1 || ((uintptr_t)src & 31) || ((uintptr_t)dst_bf16 & 15)) { set_err("vp_grad_pack_bf16: bad argument"); return VP_ERR_ARG; }
+  VP_HIP_CHECK(launch_grad_pack_bf16(src, dst_bf16, n, (hipStream_t)stream));
+  return VP_OK;
+}
+int vp_grad_unpack_bf16(const void* src_bf16, float* dst, size_t n, float scale, void* stream) {
+  if (!src_bf16 || !dst || n < 1 || ((uintptr_t)dst & 31) || ((uintptr_t)src_bf16 & 15)) { set_err("vp_grad_unpack_bf16: bad argument"); return VP_ERR_ARG; }
+  VP_HIP_CHECK(launch_grad_unpack_bf16(src_bf16, dst, n, scale, (hipStream_t)stream));
+  return VP_OK;
 }
 
 int vp_adam_tf(float* params, const float* grads, float* m, float* v, size_t n, int step_t,

@@ -819,6 +819,30 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(const AdamArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 transport of a gradient bucket (data parallel, optional): the f32 arena stays the master copy; a bucket is rounded to bf16
+// (nearest even) into a communication buffer, all-reduced as bf16, and written back as f32 times 1 / world.  Halves the bytes on
+// xGMI (152 -> 76 MB per step) at the price of one rounding of every gradient element per rank.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_pack_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n8, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    reinterpret_cast<uint4*>(dst)[i] = Elem<bf16>::pack(f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n8 * 8)) Elem<bf16>::st(dst + n8 * 8 + threadIdx.x, src[n8 * 8 + threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void grad_unpack_bf16_kernel(const bf16* __restrict__ src, float* __restrict__ dst, size_t n8, size_t n, float scale) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float f[8];
+    Elem<bf16>::unpack(reinterpret_cast<const uint4*>(src)[i], f);
+    reinterpret_cast<float4*>(dst)[2 * i] = make_float4(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+    reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n8 * 8)) dst[n8 * 8 + threadIdx.x] = Elem<bf16>::ld(src + n8 * 8 + threadIdx.x) * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
 static inline int nblocks(size_t work, int cap = 2048) {
@@ -994,6 +1018,16 @@ hipError_t launch_relu_bwd(const void* y, void* d, size_t n, int is_bf16, hipStr
   const size_t nvec = n / (is_bf16 ? 8 : 4);
   if (is_bf16) hipLaunchKernelGGL((relu_bwd_kernel<bf16>), dim3(nblocks(nvec)), dim3(256), 0, st, (const bf16*)y, (bf16*)d, nvec);
   else hipLaunchKernelGGL((relu_bwd_kernel<float>), dim3(nblocks(nvec)), dim3(256), 0, st, (const float*)y, (float*)d, nvec);
+  return hipGetLastError();
+}
+
+hipError_t launch_grad_pack_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(grad_pack_bf16_kernel, dim3(nblocks(n / 8 + 1, 4096)), dim3(256), 0, st, src, (bf16*)dst, n / 8, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_grad_unpack_bf16(const void* src, float* dst, size_t n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(grad_unpack_bf16_kernel, dim3(nblocks(n / 8 + 1, 4096)), dim3(256), 0, st, (const bf16*)src, dst, n / 8, n, scale);
   return hipGetLastError();
 }
 

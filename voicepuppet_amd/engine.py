@@ -61,6 +61,8 @@ class PixReferEngine:
     if training:
       self.adam = {"g": [z(counts[0]), z(counts[0])], "d": [z(counts[1]), z(counts[1])]}
     self.t_g = self.t_d = 0
+    self.grad_transport = "f32"          # data parallel: 'bf16' halves the bytes of the gradient all-reduce (parallel.GradExchange)
+    self._exchange = None
     self.fused_update = not os.environ.get("VP_NO_FUSED_UPDATE")      # single-GPU train_step: vp_pixrefer_backward_update (backward + Adam x 2 + re-pack in one call)
     ws = self.L.vp_pixrefer_workspace_bytes(d)
     if ws == 0:
@@ -186,7 +188,6 @@ class PixReferEngine:
     """One iteration of train_pixrefer.py:136-143 on this replica: forward, both backward passes,
     (data parallel: RCCL all-reduce-mean of the two gradient arenas, the discriminator's overlapped
     with the generator backward), Adam(D) then Adam(G)."""
-    from .parallel import allreduce_mean
     self.forward(inputs, fg_inputs, targets, masks)
     if group is None and self.fused_update:
       # both passes AND both Adam updates + weight re-packs in one executor call: every arena range is updated as soon as its
@@ -200,18 +201,29 @@ class PixReferEngine:
     if group is None:
       self.backward()          # both passes, the discriminator-loss pass on the executor's side stream
     else:
-      # the discriminator-loss pass runs on the side stream under stage 0 of the generator backward; its bucket and the first
-      # two generator buckets travel while later stages still compute
+      # data parallel: every bucket is all-reduced on the communication stream as soon as its stage has run, and its Adam update +
+      # weight re-pack follow right behind the collective on that stream - under the stages that still compute
+      from .parallel import GradExchange
+      ex = self._exchange
+      if ex is None or ex.group is not group or ex.transport != self.grad_transport:
+        ex = self._exchange = GradExchange(group, self.grad_transport)
+      self.t_d += 1
+      self.t_g += 1
+      (m_g, v_g), (m_d, v_d) = self.adam["g"], self.adam["d"]
+
+      def update(which, bucket):
+        m, v, t = (m_d, v_d, self.t_d) if which else (m_g, v_g, self.t_g)
+        return lambda sp: _lib.check(self.L.vp_pixrefer_update_bucket(self.h, which, bucket, _ptr(m), _ptr(v), t, lr, beta1, 0.999, 1e-8, sp),
+                                     "vp_pixrefer_update_bucket")
       _lib.check(self.L.vp_pixrefer_backward_d_fork(self.h, _stream()), "vp_pixrefer_backward_d_fork")
-      works = []
       for stage, (lo, hi) in enumerate(self.grad_buckets_g()):
         self.backward_g_stage(stage)
-        if stage == 0:
-          _lib.check(self.L.vp_pixrefer_backward_d_join(self.h, _stream()), "vp_pixrefer_backward_d_join")
-          works.append(allreduce_mean(self.grads_d, group, async_op=True))
-        works.append(allreduce_mean(self.grads_g[lo:hi], group, async_op=True))
-      for w in works:
-        w.wait()
+        ex.start(self.grads_g[lo:hi], then=update(0, stage))
+      # the discriminator-loss pass ran on the side stream under the generator's stages; its (small) bucket goes last
+      _lib.check(self.L.vp_pixrefer_backward_d_join(self.h, _stream()), "vp_pixrefer_backward_d_join")
+      ex.start(self.grads_d, then=update(1, 0))       # (an event on this stream covers the joined pass: include/vp_hip.h)
+      ex.finish()
+      return
     self.adam_step(lr, beta1)
 
   def adam_step(self, lr, beta1=0.5, beta2=0.999, eps=1e-8):
