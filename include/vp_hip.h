@@ -366,6 +366,17 @@ int vp_adam_tf_clipped(float* params, float* grads, float* m, float* v, size_t n
                        float beta2, float eps, void* stream);
 int vp_moving_update(float* moving, const float* batch, const float* factor, size_t n, float decay, void* stream);
 
+/* ---- cv2.resize(uint8, INTER_LINEAR) + paste: the last step of render_face (voicepuppet/pixrefer/infer_bfmvid.py:110-121) ----
+ * OpenCV's fixed-point bilinear (11-bit coefficients, the two-pass rounding of resize.cpp: see csrc/resize.hip), byte for byte;
+ * optionally behind cv2.cvtColor(BGR2RGB).  src [frames][src_h][src_w][3] uint8 is resized to dst_h x dst_w and written into
+ * canvas [frames][canvas_h][canvas_w][3] at (y0, x0); canvas pixels outside the pasted rectangle are not touched (the caller zeroes
+ * the canvas, as np.zeros does in the reference).  workspace: vp_resize_paste_workspace_bytes(dst_h, dst_w) device bytes.
+ * vp_resize_linear_table: the coefficient tables alone (host arrays of dst_size entries), for host callers and tests. */
+size_t vp_resize_paste_workspace_bytes(int dst_h, int dst_w);
+int vp_resize_paste_u8(const unsigned char* src, int frames, int src_h, int src_w, int dst_h, int dst_w, int swap_rb,
+                       unsigned char* canvas, int canvas_h, int canvas_w, int y0, int x0, void* workspace, void* stream);
+int vp_resize_linear_table(int src_size, int dst_size, int rows, int* ofs, short* a0, short* a1, int* row1);
+
 #ifdef __cplusplus
 }
 #endif

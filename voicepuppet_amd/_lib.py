@@ -68,6 +68,10 @@ _SIGNATURES = {
     "vp_grad_unpack_bf16": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_float, _P]),
     "vp_pixrefer_update_bucket": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                  ctypes.c_float, _P]),
+    "vp_resize_paste_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "vp_resize_paste_u8": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_resize_linear_table": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     "vp_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "vp_tune": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "vp_pixrefer_pack_frames": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P]),

@@ -69,22 +69,19 @@ def angle_sequence(frames, start=(0.0, 0.0, 0.0), shift=0.005):
 
 
 def render_faces(renderer, center_x, center_y, ratio, bfm_coeff_seq, img_shape, transform_params):
-  """render_face (infer_bfmvid.py:79-122) for every frame of the clip: one device pass for reconstruction + rasterisation,
-  then the reference's per-frame channel swap / resize / paste on the host (PIL bilinear standing in for cv2.resize)."""
-  from PIL import Image
+  """render_face (infer_bfmvid.py:79-122) for every frame of the clip: one device pass for reconstruction + rasterisation, then the
+  reference's channel swap / cv2.resize / paste for all frames in one more launch (csrc/resize.hip: OpenCV's fixed-point bilinear,
+  byte for byte; voicepuppet_amd/utils/cv_resize.py)."""
+  from voicepuppet_amd.utils.cv_resize import resize_paste_u8
   ratio = ratio * transform_params[2]
   tx = -int((transform_params[3] / ratio))
   ty = -int((transform_params[4] / ratio))
   T = bfm_coeff_seq.shape[0]
-  images, _ = renderer(bfm_coeff_seq.astype(np.float32), angle_sequence(T))
-  images = images.cpu().numpy()[..., ::-1]                                       # cv2.cvtColor(BGR2RGB), :110
-  side = int(round(224 / ratio))
-  out = np.zeros((T,) + tuple(img_shape), np.uint8)
-  for i in range(T):
-    face = np.asarray(Image.fromarray(np.ascontiguousarray(images[i])).resize((side, side), Image.BILINEAR))
-    cx, cy = face.shape[1] // 2, face.shape[0] // 2
-    out[i, center_y - cy - ty:center_y - cy + face.shape[0] - ty, center_x - cx - tx:center_x - cx + face.shape[1] - tx, :] = face
-  return out
+  images, _ = renderer(bfm_coeff_seq.astype(np.float32), angle_sequence(T))      # [T, 224, 224, 3] uint8 on the device, rasteriser order
+  side = int(round(images.shape[1] / ratio))
+  cx, cy = side // 2, side // 2
+  out = resize_paste_u8(images, side, side, (img_shape[0], img_shape[1]), center_y - cy - ty, center_x - cx - tx, swap_rb=True)   # :110-121
+  return out.cpu().numpy()
 
 
 def main(argv=None):
