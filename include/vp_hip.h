@@ -366,6 +366,34 @@ int vp_adam_tf_clipped(float* params, float* grads, float* m, float* v, size_t n
                        float beta2, float eps, void* stream);
 int vp_moving_update(float* moving, const float* batch, const float* factor, size_t n, float decay, void* stream);
 
+/* ---- plain float32 matrix products on the repo's own MFMA kernels (the BFMNet training step is made of them: bfmnet.py:215-323) ----
+ * Row-major, leading dimensions in floats.  vp_mm_fwd_f32: y[P,N] = x[P,K] . w[K,N] (+ bias[N]); w_transposed: w is stored [N,K].
+ * vp_mm_bwd_data_f32: dx[P,K] (+)= dy[P,N] . w[K,N]^T.  vp_mm_bwd_weight_f32: dw[k_real,N] = (x[P,K]^T . dy[P,N])[:k_real].
+ * The contraction dimension of the first two (K resp. N) is walked in chunks of 16 floats: K % 16 == 0, and dy carries
+ * lddy >= round_up(N, 16) columns with zeros beyond N.  workspace: vp_mm_workspace_bytes(P, K, N) device bytes (the packed
+ * copy of w, split-K slabs) whose FIRST 256 BYTES ARE ZERO on entry; the calls never write them.  float32 products and
+ * accumulation (v_mfma_f32_16x16x4_f32). */
+size_t vp_mm_workspace_bytes(int P, int K, int N);
+int vp_mm_fwd_f32(const float* x, int ldx, const float* w, int ldw, int w_transposed, const float* bias, float* y, int ldy,
+                  int P, int K, int N, void* workspace, void* stream);
+int vp_mm_bwd_data_f32(const float* dy, int lddy, const float* w, int ldw, int w_transposed, float* dx, int lddx, int accumulate,
+                       int P, int K, int N, void* workspace, void* stream);
+int vp_mm_bwd_weight_f32(const float* x, int ldx, const float* dy, int lddy, float* dw, int P, int K, int k_real, int N,
+                         void* workspace, void* stream);
+/* The same two weight-consuming products on weights packed AHEAD of time (a training step re-packs every matrix once, in one
+ * launch, instead of once per product).  dir: 0 = the layout of vp_mm_fwd_f32, 1 = of vp_mm_bwd_data_f32; the layout follows from
+ * (P, K, N, dir) alone.  vp_mm_pack_desc fills one host descriptor (vp_mm_pack_desc_bytes() bytes) of a matrix at master + w_off
+ * floats whose packed block goes to packed + dst_off floats (blocks of vp_mm_packed_bytes); vp_mm_pack_table packs n of them from
+ * a DEVICE copy of the descriptor array. */
+size_t vp_mm_packed_bytes(int P, int K, int N, int dir);
+size_t vp_mm_pack_desc_bytes(void);
+int vp_mm_pack_desc(size_t w_off, int ldw, int w_transposed, int P, int K, int N, int dir, size_t dst_off, void* desc);
+int vp_mm_pack_table(const void* device_descs, int n, const float* master, void* packed, void* stream);
+int vp_mm_fwd_f32_packed(const float* x, int ldx, const void* packed_w, const float* bias, float* y, int ldy, int P, int K, int N,
+                         void* workspace, void* stream);
+int vp_mm_bwd_data_f32_packed(const float* dy, int lddy, const void* packed_w, float* dx, int lddx, int accumulate, int P, int K, int N,
+                              void* workspace, void* stream);
+
 /* ---- cv2.resize(uint8, INTER_LINEAR) + paste: the last step of render_face (voicepuppet/pixrefer/infer_bfmvid.py:110-121) ----
  * OpenCV's fixed-point bilinear (11-bit coefficients, the two-pass rounding of resize.cpp: see csrc/resize.hip), byte for byte;
  * optionally behind cv2.cvtColor(BGR2RGB).  src [frames][src_h][src_w][3] uint8 is resized to dst_h x dst_w and written into

@@ -72,6 +72,17 @@ _SIGNATURES = {
     "vp_resize_paste_u8": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "vp_resize_linear_table": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
+    "vp_mm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vp_mm_fwd_f32": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_mm_bwd_data_f32": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, _P, _P]),
+    "vp_mm_bwd_weight_f32": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_mm_packed_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vp_mm_pack_desc_bytes": (ctypes.c_size_t, []),
+    "vp_mm_pack_desc": (ctypes.c_int, [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, _P]),
+    "vp_mm_pack_table": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P]),
+    "vp_mm_fwd_f32_packed": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_mm_bwd_data_f32_packed": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "vp_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "vp_tune": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "vp_pixrefer_pack_frames": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P]),

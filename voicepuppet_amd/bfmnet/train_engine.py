@@ -3,8 +3,10 @@
 One `train_step` = training-mode forward (batch-statistics batch_norm, dropout masks), the vertex-space loss of add_cost_function
 plus the l2 regulariser, the full backward pass, clip_by_global_norm and one tf.train.AdamOptimizer update, plus the moving-average
 update of every batch_norm.  Division of labour: everything that is a plain matrix product (1x1 convolutions and dense layers on
-[pixels, channels] matrices, the GRU's input / recurrent weight gradients, the [B*T, 64] x [64, 3n] face-shape products) is a
-rocBLAS GEMM through torch.mm; everything else - batch-norm statistics and backward, activations and dropout, the depthwise 7x3
+[pixels, channels] matrices, the GRU's input / recurrent weight gradients, the [B*T, 64] x [64, 3n] face-shape products) goes
+through vp_mm_fwd_f32 / vp_mm_bwd_data_f32 / vp_mm_bwd_weight_f32 (csrc/mm_api.hip: the repo's own float32-MFMA implicit-GEMM and
+weight-gradient kernels, the same ones the PixReferNet float32 path runs on; no vendor GEMM library); everything else -
+batch-norm statistics and backward, activations and dropout, the depthwise 7x3
 convolution with its two gradients, SAME max-pools, the im2col of the stem, the GRU recurrence forward and backward through time, the
 loss with its gradient, the sums of squares, Adam - is a hand-written HIP kernel of libvp_hip.so (csrc/bfm_train.hip,
 audio_kernels.hip, pointwise.hip).  No CPU fallback: the constructor raises without a GPU.
@@ -56,31 +58,13 @@ def regularised(name):
   return "MfccNet" in name and (name.endswith("/kernel") or name.endswith("depthwise_weights"))
 
 
-TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning", "gfx950_batch4_batch32.csv")
-
-
-def use_tuned_gemms(path=TUNED_GEMMS):
-  """The step's ~170 f32 GEMMs are skinny (K = 32 ... 256 against 10^4 ... 10^5 rows) and rocBLAS's default heuristic picks solutions
-  that run at a third of the f32 MFMA peak; PyTorch's TunableOp looks each shape up in a results file (rocBLAS / hipBLASLt solution per
-  shape, searched once on an MI355X by scripts/tune_bfmnet_gemms.sh for the 24-frame clips at batch 4 and 32: 9.4 -> 7.9 ms and
-  31.8 -> 23.1 ms per step).  Shapes that are not in the file, or a file written for another ROCm build (its validator lines do not
-  match), fall back to the default solutions.  Process-wide: TunableOp is a torch global."""
-  if os.environ.get("VP_NO_TUNED_GEMMS") or not os.path.exists(path):
-    return False
-  tun = torch.cuda.tunable
-  tun.enable(True)
-  tun.tuning_enable(False)
-  return bool(tun.read_file(path))
-
-
 class BFMNetTrainEngine:
-  def __init__(self, batch, frames, model, lr=1e-4, max_grad_norm=50.0, num_mel_bins=80, tuned_gemms=True):
+  def __init__(self, batch, frames, model, lr=1e-4, max_grad_norm=50.0, num_mel_bins=80):
     """model: dict with exBase [3n,64] and vmask [3n] (the mouth-weighted vertex mask of bfmnet.py:131-134); idBase / meanshape cancel in
     every term of the loss (both face shapes share the identity coefficients) and are not needed on the device."""
     if not torch.cuda.is_available():
       raise RuntimeError("BFMNetTrainEngine needs an MI355X (no CPU fallback)")
     self.L = _lib.lib()
-    self.tuned_gemms = use_tuned_gemms() if tuned_gemms else False
     self.B, self.T, self.W0 = batch, frames, num_mel_bins
     self.lr, self.clip = lr, max_grad_norm
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -119,26 +103,9 @@ class BFMNetTrainEngine:
     self.J = self.exbase.shape[0]
     self.ears_scale = torch.tensor([-2.0, -2.0, -2.0, -4.0], device=dev)
     self._ws = {}
+    self._gdpad = None
+    self._pk, self._pk_pending, self._pk_ready, self._pk_arena, self._packed = {}, {}, False, (None, 0), None
     self._graphs = {}
-
-  def tune_gemms(self, ears, mfccs, bfm_coeffs, seq_len, path, max_ms_per_shape=20):
-    """Search the GEMM solutions for THIS batch / clip length (one gradient-only step with TunableOp's tuning on, a few minutes) and
-    write them to `path` in TunableOp's format; later engines pick them up with use_tuned_gemms(path)."""
-    tun = torch.cuda.tunable
-    tun.enable(True)
-    tun.set_max_tuning_duration(max_ms_per_shape)
-    tun.tuning_enable(True)
-    try:
-      self.train_step(ears, mfccs, bfm_coeffs, seq_len, apply=False)
-      torch.cuda.synchronize()
-    finally:
-      tun.tuning_enable(False)
-    with open(path, "w") as f:                                                     # TunableOp's own CSV layout
-      for k, v in tun.get_validators():
-        f.write("Validator,%s,%s\n" % (k, v))
-      for row in tun.get_results():
-        f.write(",".join(str(x) for x in row) + "\n")
-    return path
 
   # ---- parameters -----------------------------------------------------------------------------------------------------------
   def load_params(self, params):
@@ -228,6 +195,113 @@ class BFMNetTrainEngine:
     _lib.check(self.L.vp_maxpool_hw_bwd(_ptr(x2d), _ptr(dy2d), _ptr(dx), self.B, H, W, C, k[0], k[1], s[0], s[1], _stream()), "vp_maxpool_hw_bwd")
     return dx
 
+  # ---- matrix products: the repo's own float32 MFMA kernels behind vp_mm_* (include/vp_hip.h), no vendor GEMM library --------------------
+  def _mm_ws(self, P, K, N):
+    """One workspace for every product of the step (they run back to back on one stream); its first 256 bytes are the kernels' zero page
+    (include/vp_hip.h): allocated zeroed, never written."""
+    need = self.L.vp_mm_workspace_bytes(int(P), int(K), int(N))
+    w = self._ws.get("mm")
+    if w is None or w.numel() < need:
+      if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("the matrix-product workspace must exist before a graph capture (run one eager step first)")
+      w = self._ws["mm"] = torch.zeros(int(need), dtype=torch.uint8, device=self.dev)
+    return w
+
+  # Weight matrices are packed into the kernels' chunk-major layout AHEAD of the products: the first (eager) step registers every
+  # (matrix, direction, shape) it multiplies with; from then on ONE launch at the top of a step packs all arena matrices from the
+  # freshly updated parameters (vp_mm_pack_table), constant matrices (exBase) were packed once, and the products read the packed blocks.
+  def _packed_for(self, w, w_t, P, K, N, direction):
+    """-> device pointer of the packed block of `w` for this product, or None while the table does not hold it yet."""
+    a0, esz = self.arena.data_ptr(), 4
+    in_arena = a0 <= w.data_ptr() < a0 + self.arena.numel() * esz
+    if not in_arena and w.data_ptr() != self.exbase.data_ptr():
+      return None                                      # a temporary (the zero-padded stem kernel): packed per product
+    key = ((w.data_ptr() - a0) // esz if in_arena else -w.data_ptr(), w.stride(0), bool(w_t), int(P), int(K), int(N), direction)
+    hit = self._pk.get(key)
+    if hit is not None:
+      return hit
+    if not self._pk_ready and key not in self._pk_pending:
+      self._pk_pending[key] = (w if not in_arena else None)
+    return None
+
+  def _build_pack_table(self):
+    L = self.L
+    dsz = int(L.vp_mm_pack_desc_bytes())
+    groups = {"arena": [], "const": []}
+    for key, wconst in self._pk_pending.items():
+      groups["const" if wconst is not None else "arena"].append((key, wconst))
+    total = sum(int(L.vp_mm_packed_bytes(k[3], k[4], k[5], k[6])) for k in self._pk_pending)
+    self._packed = torch.zeros(max(total, 256), dtype=torch.uint8, device=self.dev)
+    off = 0
+    for name, items in groups.items():
+      host = ctypes.create_string_buffer(dsz * max(len(items), 1))
+      for i, (key, wconst) in enumerate(items):
+        w_off, ldw, w_t, P, K, N, direction = key
+        src = 0 if wconst is not None else w_off
+        # one table per master pointer: a constant matrix is its own master (offset 0)
+        _lib.check(L.vp_mm_pack_desc(src, ldw, 1 if w_t else 0, P, K, N, direction, off // 4, ctypes.byref(host, i * dsz)), "vp_mm_pack_desc")
+        self._pk[key] = ctypes.c_void_p(self._packed.data_ptr() + off)
+        off += int(L.vp_mm_packed_bytes(P, K, N, direction))
+      dev = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.dev)
+      if name == "arena":
+        self._pk_arena = (dev, len(items))
+      else:
+        # constants: pack now, once (each against its own base pointer: one launch per matrix)
+        for i, (key, wconst) in enumerate(items):
+          one = dev[i * dsz:(i + 1) * dsz].clone()
+          _lib.check(L.vp_mm_pack_table(_ptr(one), 1, _ptr(wconst), _ptr(self._packed), _stream()), "vp_mm_pack_table")
+          self._keep_const = getattr(self, "_keep_const", []) + [one]
+    self._pk_pending = {}
+    self._pk_ready = True
+
+  def _pack_weights(self):
+    """One launch: every arena matrix of the step, both layouts, from the current parameters."""
+    if self._pk_ready and self._pk_arena[1] > 0:
+      dev, n = self._pk_arena
+      _lib.check(self.L.vp_mm_pack_table(_ptr(dev), n, _ptr(self.arena), _ptr(self._packed), _stream()), "vp_mm_pack_table")
+
+  def _mm(self, x, w, bias=None, w_t=False, out=None):
+    """x [P, K] . w [K, N] (+ bias) -> [P, N];  w_t: w is stored [N, K].  Row strides are taken from the tensors."""
+    P, K = x.shape
+    N = w.shape[0] if w_t else w.shape[1]
+    assert x.stride(1) == 1 and w.stride(1) == 1 and K % 16 == 0, (x.shape, w.shape)
+    y = out if out is not None else torch.empty(P, N, dtype=torch.float32, device=self.dev)
+    pk = self._packed_for(w, w_t, P, K, N, 0)
+    if pk is not None:
+      _lib.check(self.L.vp_mm_fwd_f32_packed(_ptr(x), x.stride(0), pk, _ptr(bias), _ptr(y), y.stride(0), P, K, N, _ptr(self._mm_ws(P, K, N)), _stream()),
+                 "vp_mm_fwd_f32_packed")
+    else:
+      _lib.check(self.L.vp_mm_fwd_f32(_ptr(x), x.stride(0), _ptr(w), w.stride(0), 1 if w_t else 0, _ptr(bias), _ptr(y), y.stride(0), P, K, N,
+                                      _ptr(self._mm_ws(P, K, N)), _stream()), "vp_mm_fwd_f32")
+    return y
+
+  def _mm_dx(self, dy, w, w_t=False, out=None, accumulate=False, n=None):
+    """dy [P, N] . w [K, N]^T -> [P, K] (optionally added to `out`);  w_t: w is stored [N, K];  n: real columns of dy when it is
+    stored with zero padding up to a multiple of 16."""
+    P = dy.shape[0]
+    N = int(n) if n is not None else dy.shape[1]
+    K = w.shape[1] if w_t else w.shape[0]
+    assert dy.stride(1) == 1 and w.stride(1) == 1 and dy.stride(0) >= -(-N // 16) * 16, (dy.shape, dy.stride(), N)
+    dx = out if out is not None else torch.empty(P, K, dtype=torch.float32, device=self.dev)
+    pk = self._packed_for(w, w_t, P, K, N, 1)
+    if pk is not None:
+      _lib.check(self.L.vp_mm_bwd_data_f32_packed(_ptr(dy), dy.stride(0), pk, _ptr(dx), dx.stride(0), 1 if accumulate else 0, P, K, N,
+                                                  _ptr(self._mm_ws(P, K, N)), _stream()), "vp_mm_bwd_data_f32_packed")
+    else:
+      _lib.check(self.L.vp_mm_bwd_data_f32(_ptr(dy), dy.stride(0), _ptr(w), w.stride(0), 1 if w_t else 0, _ptr(dx), dx.stride(0), 1 if accumulate else 0,
+                                           P, K, N, _ptr(self._mm_ws(P, K, N)), _stream()), "vp_mm_bwd_data_f32")
+    return dx
+
+  def _mm_dw(self, x, dy, out, k_real=None):
+    """x [P, K]^T . dy [P, N] -> out [k_real, N] (contiguous; k_real < K: x carries zero padding columns, the stem)"""
+    P, K = x.shape
+    N = dy.shape[1]
+    kr = K if k_real is None else int(k_real)
+    assert x.stride(1) == 1 and dy.stride(1) == 1 and out.is_contiguous() and out.numel() == kr * N, (x.shape, dy.shape, out.shape)
+    _lib.check(self.L.vp_mm_bwd_weight_f32(_ptr(x), x.stride(0), _ptr(dy), dy.stride(0), _ptr(out), P, K, kr, N, _ptr(self._mm_ws(P, K, N)), _stream()),
+               "vp_mm_bwd_weight_f32")
+    return out
+
   def _sumsq(self, x):
     n = self.L.vp_sumsq_partials(x.numel())
     part = torch.empty(n, dtype=torch.float64, device=self.dev)
@@ -236,8 +310,8 @@ class BFMNetTrainEngine:
 
   # ---- conv + batch-norm + activation, forward / backward -----------------------------------------------------------------------
   def _cba_fwd(self, x, kernel, bn_scope, act, tape):
-    """x [P, cin] @ kernel [cin, cout] -> batch_norm -> act.  tape gets what the backward needs."""
-    y = torch.mm(x, kernel)
+    """x [P, cin] . kernel [cin, cout] -> batch_norm -> act.  tape gets what the backward needs."""
+    y = self._mm(x, kernel)
     mean, rstd, shift = self._bn_fwd(y, bn_scope)
     a = self._act(y, rstd, shift, act)
     tape.append(("cba", x, kernel, y, mean, rstd, shift, act, bn_scope))
@@ -321,6 +395,7 @@ class BFMNetTrainEngine:
     masks = masks or {}
     mk = lambda k, c: (masks[k].reshape(B * T, c).contiguous() if masks.get(k) is not None else None)
     tape = []
+    self._pack_weights()
     # stem: 9x5 stride (1,2) as im2col + GEMM
     Wo = (W + 1) // 2
     col = torch.empty(B * H * Wo, 48, dtype=torch.float32, device=self.dev)
@@ -359,15 +434,15 @@ class BFMNetTrainEngine:
     tape.append(("pool", feat, H, W, (5, 3), (5, 3)))
 
     def dense(x, wname, bname, act, mask):
-      z = torch.addmm(p[bname], x, p[wname])
+      z = self._mm(x, p[wname], p[bname])
       y = z if (act == ACT_NONE and mask is None) else self._act(z, None, None, act, mask)
       tape.append(("dense", x, wname, bname, y, act, mask))
       return y
     e = dense(enc_in, "mfcc_encoder/dense/kernel", "mfcc_encoder/dense/bias", ACT_LRELU, mk("enc", 256))
     c1 = dense(e, "rnn_module/dense/kernel", "rnn_module/dense/bias", ACT_LRELU, None)
     wg, wc = p[GRU + "gates/kernel"], p[GRU + "candidate/kernel"]
-    xg = torch.addmm(p[GRU + "gates/bias"], c1, wg[:256])
-    xc = torch.addmm(p[GRU + "candidate/bias"], c1, wc[:256])
+    xg = self._mm(c1, wg[:256], p[GRU + "gates/bias"])
+    xc = self._mm(c1, wc[:256], p[GRU + "candidate/bias"])
     whg, whc = wg[256:].contiguous(), wc[256:].contiguous()
     rnn, sr, su, scand, shp = (torch.empty(B * T, 256, dtype=torch.float32, device=self.dev) for _ in range(5))
     _lib.check(L.vp_gru_train_fwd(_ptr(xg), _ptr(xc), _ptr(whg), _ptr(whc), _ptr(seq), _ptr(rnn), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), B, T,
@@ -389,9 +464,9 @@ class BFMNetTrainEngine:
     def dense_bwd(dy):
       _, x, wname, bname, y, act, mask = tape.pop()
       dz = dy if (act == ACT_NONE and mask is None) else self._act_bwd(dy, y, act, mask)
-      torch.mm(x.t(), dz, out=g[wname])
+      self._mm_dw(x, dz, g[wname])
       torch.sum(dz, 0, out=g[bname])
-      return torch.mm(dz, p[wname].t())
+      return self._mm_dx(dz, p[wname])
     d = dense_bwd(do)
     d = dense_bwd(d)
     d = dense_bwd(d)                                                                 # d loss / d rnn_m
@@ -400,13 +475,14 @@ class BFMNetTrainEngine:
     dag, dac = torch.empty(B * T, 512, dtype=torch.float32, device=self.dev), torch.empty(B * T, 256, dtype=torch.float32, device=self.dev)
     _lib.check(L.vp_gru_train_bwd(_ptr(d.contiguous()), _ptr(whg), _ptr(whc), _ptr(seq), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), _ptr(dag), _ptr(dac),
                                   B, T, _stream()), "vp_gru_train_bwd")
-    torch.mm(c1.t(), dag, out=g[GRU + "gates/kernel"][:256])
-    torch.mm(shp.t(), dag, out=g[GRU + "gates/kernel"][256:])
+    self._mm_dw(c1, dag, g[GRU + "gates/kernel"][:256])
+    self._mm_dw(shp, dag, g[GRU + "gates/kernel"][256:])
     torch.sum(dag, 0, out=g[GRU + "gates/bias"])
-    torch.mm(c1.t(), dac, out=g[GRU + "candidate/kernel"][:256])
-    torch.mm((sr * shp).t(), dac, out=g[GRU + "candidate/kernel"][256:])
+    self._mm_dw(c1, dac, g[GRU + "candidate/kernel"][:256])
+    self._mm_dw(sr * shp, dac, g[GRU + "candidate/kernel"][256:])
     torch.sum(dac, 0, out=g[GRU + "candidate/bias"])
-    d = torch.mm(dag, wg[:256].t()) + torch.mm(dac, wc[:256].t())                      # d loss / d c1
+    d = self._mm_dx(dag, wg[:256])
+    self._mm_dx(dac, wc[:256], out=d, accumulate=True)                               # d loss / d c1
     d = dense_bwd(d)
     d = dense_bwd(d)                                                                 # d loss / d enc_in  [B*T, 256]
 
@@ -415,10 +491,10 @@ class BFMNetTrainEngine:
       _, x, kernel, y, mean, rstd, shift, act, scope = tape.pop()
       dy = self._bn_act_bwd(da, y, mean, rstd, shift, act, scope)
       if x.shape[1] == 48:                                                           # stem: no input gradient
-        g[PREFIX + "block0_0/conv2d/conv2d/kernel"].view(45, 32).copy_(torch.mm(x.t(), dy)[:45])
+        self._mm_dw(x, dy, g[PREFIX + "block0_0/conv2d/conv2d/kernel"].view(45, 32), k_real=45)
         return None
-      torch.mm(x.t(), dy, out=self._grad2d(kernel))
-      return torch.mm(dy, kernel.t())
+      self._mm_dw(x, dy, self._grad2d(kernel))
+      return self._mm_dx(dy, kernel)
     while tape:
       kind = tape[-1][0]
       if kind == "pool":
@@ -455,19 +531,27 @@ class BFMNetTrainEngine:
     else:
       gn = torch.sqrt(ss)
       self.grads.mul_((self.clip / torch.clamp(gn, min=self.clip)).to(torch.float32))
+    if self._pk_pending and not torch.cuda.is_current_stream_capturing():
+      self._build_pack_table()                                                       # after the first eager step: the products are known
     return torch.stack([loss, loss_data, torch.sqrt(ss)])
 
   def _vertex_loss(self, o, bfm_coeffs, seq):
     """add_cost_function (bfmnet.py:229-271): both face shapes share the identity coefficients, so their difference is
     exBase . (ex_true - ex_pred).  o [B*T,64] -> (data loss as a float64 device scalar, d loss / d o [B*T,64])."""
     B, T, L = self.B, self.T, self.L
-    delta = bfm_coeffs.reshape(B * T, -1)[:, 80:144] - o
-    D = torch.mm(delta, self.exbase.t())                                             # [B*T, 3n]
+    J = self.J
+    delta = (bfm_coeffs.reshape(B * T, -1)[:, 80:144] - o).contiguous()
+    D = self._mm(delta, self.exbase, w_t=True)                                       # delta . exBase^T  [B*T, 3n] (exBase is stored [3n, 64])
     gD = torch.empty_like(D)
-    npart = L.vp_vertex_loss_partials(B, self.J)
+    npart = L.vp_vertex_loss_partials(B, J)
     part = torch.empty(npart, dtype=torch.float64, device=self.dev)
-    _lib.check(L.vp_bfm_vertex_loss(_ptr(D), _ptr(self.vmask), _ptr(seq), B, T, self.J, _ptr(gD), _ptr(part), _stream()), "vp_bfm_vertex_loss")
-    return part.sum(), -torch.mm(gD, self.exbase)
+    _lib.check(L.vp_bfm_vertex_loss(_ptr(D), _ptr(self.vmask), _ptr(seq), B, T, J, _ptr(gD), _ptr(part), _stream()), "vp_bfm_vertex_loss")
+    # gD . exBase contracts over the 3n vertex coordinates (not a multiple of the kernels' 16-float K chunk): a zero-padded copy
+    gp = self._gdpad
+    if gp is None or gp.shape[0] != B * T:
+      gp = self._gdpad = torch.zeros(B * T, -(-J // 16) * 16, dtype=torch.float32, device=self.dev)
+    gp[:, :J].copy_(gD)
+    return part.sum(), -self._mm_dx(gp, self.exbase, w_t=True, n=J)
 
   def regulariser(self):
     reg = torch.zeros((), dtype=torch.float64, device=self.dev)

@@ -77,7 +77,8 @@ struct IgemmArgs {
 //   deconv: G = dY (co),          D = layer input    -> HWOI kernel gradient
 struct WgradArgs {
   PixSrc g;
-  int Gc, log2Gc;           // padded channels of the gathered operand (power of two)
+  int Gc, log2Gc;           // padded channels of the gathered operand (power of two; any count with one tap: log2Gc = 30)
+  int gc_mask;              // Gc - 1 (or all-ones with one tap): row m of the gradient = (tap = m >> log2Gc, channel = m & gc_mask)
   int Hgin, Wgin;           // spatial size of the gathered tensor
   PixSrc d;
   int Dc;                   // channels of the dense operand

@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(WC * WP * 64) void wgrad_kernel(const WgradArgs a) 
   WgTask<T> task;
   {
     int ch, tap = 0;
-    if (isA) { const int m = m_base + cg * E; tap = m >> a.log2Gc; ch = m & (a.Gc - 1); task.ok = tap < a.ntaps; }
+    if (isA) { const int m = m_base + cg * E; tap = m >> a.log2Gc; ch = m & a.gc_mask; task.ok = m < a.ntaps * a.Gc; }   // (1 tap: log2Gc = 30, any channel count)
     else { ch = d_base + cg * E; task.ok = ch < a.Dc; }
     task.ok = task.ok && active;
     int tdh = 0, tdw = 0;
@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(WC * WP * 64) void wgrad_kernel(const WgradArgs a) 
         if (d >= a.Dreal) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int m = m0 + e, tap = m >> a.log2Gc, gc = m & (a.Gc - 1);
+          const int m = m0 + e, tap = m >> a.log2Gc, gc = m & a.gc_mask;
           if (tap < a.ntaps && gc < a.Greal) {
             float* o = a.dW + ((size_t)tap * a.Greal + gc) * a.Dreal + d;
             *o = acc[tc][tp][e] + (a.accumulate ? *o : 0.f);

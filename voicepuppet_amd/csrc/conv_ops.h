@@ -413,6 +413,8 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
     a.Hb = g.Hin; a.Wb = g.Win; a.s = 2;
   }
   a.log2Gc = ilog2(a.Gc);
+  a.gc_mask = a.Gc - 1;
+  if (a.ntaps == 1) { a.log2Gc = 30; a.gc_mask = 0x3fffffff; }   // 1x1: rows are channels, any count (BFMNet's 192 .. 1536-wide layers)
   p.cfg = (a.Dc % 128 == 0) ? 0 : (a.Dc % 64 == 0 ? 1 : 2);
   {
     // 256-row tiles (half the operand bytes per MAC; one 8-wave block per CU) where the M and N extents allow; bf16 only

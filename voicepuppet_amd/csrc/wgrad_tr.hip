@@ -111,7 +111,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradAr
     const int idx = (wave + NW * j) * 64 + lane;          // slot index inside the A stage
     const int p = idx / PA, c = (idx % PA) ^ tr_swz(p);
     const int m = m_base + c * 8;
-    const int tap = m >> a.log2Gc, ch = m & (a.Gc - 1);
+    const int tap = m >> a.log2Gc, ch = m & a.gc_mask;
     int tdh = 0, tdw = 0;
 #pragma unroll
     for (int t = 0; t < 16; ++t) if (t == tap) { tdh = a.taps.dh[t]; tdw = a.taps.dw[t]; }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradAr
         if (d >= a.Dreal) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int m = m0 + e, tap = m >> a.log2Gc, gc = m & (a.Gc - 1);
+          const int m = m0 + e, tap = m >> a.log2Gc, gc = m & a.gc_mask;
           if (tap < a.ntaps && gc < a.Greal) {
             float* o = a.dW + ((size_t)tap * a.Greal + gc) * a.Dreal + d;
             *o = acc[tc][tp][e] + (a.accumulate ? *o : 0.f);
