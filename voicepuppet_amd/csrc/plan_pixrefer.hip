@@ -134,6 +134,7 @@ struct vp_pixrefer {
   double* bn_partial3;
   hipStream_t side, branch;
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
+  hipEvent_t ev_upd_b, ev_upd_m;   // fused update: a generator bucket's weight gradients (branch stream) / data gradients (caller's stream) are done
   bool overlap, forked;
   // vp_tune("phase_marks", 1): HIP events on the caller's stream at the phase boundaries of a step (vp_pixrefer_phase_ms)
   hipEvent_t mark[12];
@@ -997,6 +998,8 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch, hipStreamNonBlocking));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bfork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bjoin, hipEventDisableTiming));
+    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_upd_b, hipEventDisableTiming));
+    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_upd_m, hipEventDisableTiming));
     h->overlap = true;
   }
   *out = h;
@@ -1014,6 +1017,8 @@ void vp_pixrefer_destroy(vp_pixrefer_t* h) {
     (void)hipStreamSynchronize(h->branch);
     (void)hipEventDestroy(h->ev_bfork);
     (void)hipEventDestroy(h->ev_bjoin);
+    (void)hipEventDestroy(h->ev_upd_b);
+    (void)hipEventDestroy(h->ev_upd_m);
     (void)hipStreamDestroy(h->branch);
   }
   delete h;
@@ -1460,12 +1465,25 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
       const int l0 = i, l1 = i == i_md5 ? (int)G.l.size() - 1 : (i == i_me2 ? i_md5 - 1 : i_me2 - 1);
       const size_t off0 = G.l[l0].w_off, off1 = l1 + 1 < (int)G.l.size() ? G.l[l1 + 1].w_off : G.nparams;
       hipStream_t su = st;
-      if (h->overlap && g_overlap_on) {
+      static const bool upd_on_side = !getenv("VP_UPDATE_ON_BRANCH");
+      const bool on_side = upd_on_side && h->overlap && g_overlap_on && h->dfork_pending == 0 && g_dfork_point >= 0;
+      if (h->overlap && g_overlap_on && on_side) {
+        // the (HBM-bound) optimiser + re-pack of the bucket go to the SIDE stream, behind the discriminator-loss pass that runs there:
+        // on the branch stream they sat between the weight gradients of the layers still to come and delayed the end of the step.
+        // The bucket is final when its weight gradients (branch stream) and its data gradients (this stream: they read the packed
+        // weights the re-pack overwrites) are done; vp_pixrefer_backward's closing wait on ev_join covers the updates.
+        VP_HIP_CHECK(hipEventRecord(h->ev_upd_b, h->branch));
+        VP_HIP_CHECK(hipEventRecord(h->ev_upd_m, st));
+        VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_upd_b, 0));
+        VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_upd_m, 0));
+        su = h->side;
+      } else if (h->overlap && g_overlap_on) {
         VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
         VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
         su = h->branch; forked = true;
       }
       if ((rc = update_range(h, G, h->upd.m_g, h->upd.v_g, h->upd.lr_t_g, off0, off1, l0, l1, su))) return rc;
+      if (su == h->side) VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
     }
   }
   if (forked) {
