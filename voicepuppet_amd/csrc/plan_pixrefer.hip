@@ -65,6 +65,7 @@ struct Tens {
   int producer = -1;          // layer that writes this tensor (-1: network input / pool)
   int n_bwd_consumers = 0;    // layers whose backward-data pass writes into dz
   int dz_writes = 0;          // ... of which have run in the current backward pass
+  bool dz_on_branch = false;  // the first gradient contribution of the pass was issued on the branch stream
   bool bn_bwd_done = false;   // the batch-norm backward of this tensor ran inside the last writer's launch (conv_smallp.hip, SP_BWD_BN)
   size_t elems() const { return (size_t)N * H * W * C; }
 };
@@ -134,6 +135,7 @@ struct vp_pixrefer {
   double* bn_partial3;
   hipStream_t side, branch;
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
+  hipEvent_t ev_skip;              // generator backward: the skip-connection data gradients issued on the branch stream so far are done
   hipEvent_t ev_upd_b, ev_upd_m;   // fused update: a generator bucket's weight gradients (branch stream) / data gradients (caller's stream) are done
   bool overlap, forked;
   // vp_tune("phase_marks", 1): HIP events on the caller's stream at the phase boundaries of a step (vp_pixrefer_phase_ms)
@@ -676,8 +678,9 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
 // sample0/nb/group0/ng select a sub-batch (discriminator G-loss pass: the fake group only).
 // ss: scratch set of the stream the call runs on; gpass: generator-loss pass through the discriminator (dz2 buffers)
 static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool want_dw, bool alt,
-                         int sample0, int nb, int group0, hipStream_t st, int ss = 0, bool gpass = false, int parts = 3) {
-  // parts: bit 0 = weight / bias gradients, bit 1 = data gradients (so a host can put the two on different streams)
+                         int sample0, int nb, int group0, hipStream_t st, int ss = 0, bool gpass = false, int parts = 7) {
+  // parts: bit 0 = weight / bias gradients, bit 1 = data gradient of source 0, bit 2 = data gradient of source 1 (so a host can put
+  // them on different streams: only source 0's gradient - the decoder chain - is on the critical path of the generator backward)
   const int es = h->es;
   if (!(parts & 1)) want_dw = false;
   char* scratch = scratch_of(h, ss);
@@ -717,7 +720,8 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
     }
   }
-  for (int s = 0; s < L.nsrc && (parts & 2); ++s) {
+  for (int s = 0; s < L.nsrc; ++s) {
+    if (!(parts & (2 << s))) continue;
     if (!L.need_bwd[s]) continue;
     Tens& ts = n.t[L.src[s]];
     IgemmArgs a = alt ? L.bwd_alt[s].a : L.bwd[s].a;
@@ -732,7 +736,13 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       bool& written = gpass ? ts.dz2_written : ts.dz_written;
       a.accumulate = written ? 1 : 0;
       written = true;
-      if (!gpass) ts.dz_writes++;
+      if (!gpass) {
+        ts.dz_writes++;
+        // a gradient contribution issued on the branch stream (a decoder's skip-connection source) must have landed before another
+        // stream accumulates into the same tensor
+        if (a.accumulate && ts.dz_on_branch && ss != 2) VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_skip, 0));
+        if (!a.accumulate) ts.dz_on_branch = ss == 2;
+      }
       // chain rule through the consumer's activation and (for BN tensors) up to the normalised value
       // lrelu'/relu' only depend on the sign of the pre-activation == the sign of the materialised x~
       a.ref = (const char*)ts.xa[L.in_act] + (size_t)sample0 * ts.H * ts.W * ts.C * es;
@@ -998,6 +1008,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch, hipStreamNonBlocking));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bfork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bjoin, hipEventDisableTiming));
+    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_skip, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_upd_b, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_upd_m, hipEventDisableTiming));
     h->overlap = true;
@@ -1017,6 +1028,7 @@ void vp_pixrefer_destroy(vp_pixrefer_t* h) {
     (void)hipStreamSynchronize(h->branch);
     (void)hipEventDestroy(h->ev_bfork);
     (void)hipEventDestroy(h->ev_bjoin);
+    (void)hipEventDestroy(h->ev_skip);
     (void)hipEventDestroy(h->ev_upd_b);
     (void)hipEventDestroy(h->ev_upd_m);
     (void)hipStreamDestroy(h->branch);
@@ -1429,7 +1441,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   ca.d_din = h->d_din; ca.d_vin = h->d_vin; ca.dy4 = h->dy4; ca.N = N; ca.HW = H * H; ca.l1_weight = d.l1_weight;
   VP_HIP_CHECK(launch_composite_bwd(ca, bf, st));
   phase_mark(h, st, 3);
-  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; }
+  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; t.dz_on_branch = false; }
   }
   // (d) generator, last layer first.  Below merged_encoder_2 the two encoder branches are independent again: the foreground
   // branch (encoder_fg_4 .. encoder_fg_1) runs on the branch stream, joined before this call returns control of `st`
@@ -1455,8 +1467,14 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
       VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
       VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
       forked = true;
-      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, h->branch, 2, false, 1))) return rc;
-      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st, 0, false, 2))) return rc;
+      // ... and so does the data gradient of a SECOND source (a decoder's skip connection, merged_encoder_2's foreground input): it is
+      // first needed when the backward pass reaches the encoder that produced the tensor
+      // (opt-in: measured +0.02 .. 0.05 ms at batch 4 / 8 / 32 - the branch stream, not this one, ends the step)
+      static const bool skip_on_branch = getenv("VP_SKIP_ON_BRANCH") != nullptr;
+      const int bparts = (skip_on_branch && L.nsrc > 1) ? 1 | 4 : 1;
+      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, h->branch, 2, false, bparts))) return rc;
+      if (bparts & 4) VP_HIP_CHECK(hipEventRecord(h->ev_skip, h->branch));
+      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st, 0, false, 6 & ~bparts))) return rc;
     } else {
       if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, s2, ss))) return rc;
     }
