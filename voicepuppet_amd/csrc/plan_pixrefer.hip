@@ -1501,7 +1501,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
         su = h->branch; forked = true;
       }
       if ((rc = update_range(h, G, h->upd.m_g, h->upd.v_g, h->upd.lr_t_g, off0, off1, l0, l1, su))) return rc;
-      if (su == h->side) VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+      if (h->overlap && g_overlap_on && on_side) VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
     }
   }
   if (forked) {
