@@ -2,7 +2,7 @@
 """Host enqueue time vs GPU time of one G+D step: is a small-batch step bound by the host issuing launches?
 usage: host_time.py [batch ...]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from bench import synth_batch

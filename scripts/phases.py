@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Phase times of the G+D step (HIP events on the main stream, no profiler): usage phases.py [batch ...]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bench import synth_batch

@@ -60,7 +60,7 @@ inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
 }
 
 inline int pick_igemm_splitk(int blocks, int nchunk) {
-  // round-2 sweep (scripts/exp_sk.sh): target 128 / cap 8 / at least 4 chunks per split: 8.79 vs 8.97 ms at batch 32, 2.84 vs 3.00 ms at
+  // round-2 sweep (scripts/ab.sh with VP_SPLITK_TARGET / _MAX / _MINCHUNK): target 128 / cap 8 / at least 4 chunks per split: 8.79 vs 8.97 ms at batch 32, 2.84 vs 3.00 ms at
   // batch 4 against the round-1 setting 512 / 32 / 2 - the slab reduce and the short blocks cost more than the idle CUs
   static const int target = getenv("VP_SPLITK_TARGET") ? atoi(getenv("VP_SPLITK_TARGET")) : 128;   // resident blocks aimed at
   static const int cap = getenv("VP_SPLITK_MAX") ? atoi(getenv("VP_SPLITK_MAX")) : 8;
