@@ -165,6 +165,9 @@ int vp_tune(const char* key, int value);
  * discriminator / VGG forward + losses, generator-loss pass through D and VGG + composite backward (including the host gap between
  * the forward and the backward call), generator backward stage 0, 1, 2, join of the discriminator-loss pass.  Returns the number written. */
 int vp_pixrefer_phase_ms(vp_pixrefer_t* h, float* ms, int cap);
+/* "phase_marks" = 2 adds a mark in front of every generator layer (forward: mark 8 + layer, backward on the caller's stream:
+ * 32 + layer, layers in TF scope order); vp_pixrefer_mark_ms: milliseconds between two marks of the last step, -1 if not recorded. */
+float vp_pixrefer_mark_ms(vp_pixrefer_t* h, int from, int to);
 
 /* Data parallel, optional bf16 transport of a gradient bucket (the f32 arena stays the master copy): round n floats to bf16
  * (nearest even) into a communication buffer; after the bf16 all-reduce (sum) write them back as f32 times `scale` (= 1 / world).

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "vp_mm_pack_table": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P]),
     "vp_mm_fwd_f32_packed": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "vp_mm_bwd_data_f32_packed": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_pixrefer_mark_ms": (ctypes.c_float, [_P, ctypes.c_int, ctypes.c_int]),
     "vp_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "vp_tune": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "vp_pixrefer_pack_frames": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P]),

@@ -139,7 +139,7 @@ struct vp_pixrefer {
   hipEvent_t ev_upd_b, ev_upd_m;   // fused update: a generator bucket's weight gradients (branch stream) / data gradients (caller's stream) are done
   bool overlap, forked;
   // vp_tune("phase_marks", 1): HIP events on the caller's stream at the phase boundaries of a step (vp_pixrefer_phase_ms)
-  hipEvent_t mark[12];
+  hipEvent_t mark[64];
   int nmark;
   bool marks_made;
   int dfork_pending;          // vp_pixrefer_backward only: where the generator-loss pass still has to start the discriminator-loss pass on the side stream (0: nowhere)
@@ -808,20 +808,28 @@ static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-static bool g_phase_marks = false;   // vp_tune("phase_marks", 0 / 1)
-void vp_phase_marks_enable(int on) { g_phase_marks = on != 0; }
+static bool g_phase_marks = false;   // vp_tune("phase_marks", 0 / 1 / 2): 2 = also one mark in front of every generator layer
+static bool g_phase_detail = false;
+void vp_phase_marks_enable(int on) { g_phase_marks = on != 0; g_phase_detail = on > 1; }
 static void phase_mark(vp_pixrefer* h, hipStream_t st, int idx) {
-  if (!g_phase_marks || idx >= 12) return;
-  if (!h->marks_made) { for (int i = 0; i < 12; ++i) (void)hipEventCreate(&h->mark[i]); h->marks_made = true; }
+  if (!g_phase_marks || idx >= 64) return;
+  if (!h->marks_made) { for (int i = 0; i < 64; ++i) (void)hipEventCreate(&h->mark[i]); h->marks_made = true; }
   (void)hipEventRecord(h->mark[idx], st);
   if (idx + 1 > h->nmark) h->nmark = idx + 1;
 }
 // ms between consecutive marks of the last step: [0] generator forward (to the composite), [1] discriminator / VGG forward + losses,
 // [2] generator-loss pass through D and VGG + composite backward, [3] generator backward stage 0, [4] stage 1, [5] stage 2 + joins
+// ms from mark `from` to mark `to` of the last step (-1: one of them was not recorded)
+float vp_pixrefer_mark_ms(vp_pixrefer_t* h, int from, int to) {
+  if (!h || !h->marks_made || from < 0 || to < 0 || from >= 64 || to >= 64) return -1.f;
+  float t = -1.f;
+  if (hipEventSynchronize(h->mark[to]) != hipSuccess || hipEventElapsedTime(&t, h->mark[from], h->mark[to]) != hipSuccess) { (void)hipGetLastError(); return -1.f; }
+  return t;
+}
 int vp_pixrefer_phase_ms(vp_pixrefer_t* h, float* ms, int cap) {
   if (!h || !ms) return 0;
   int n = 0;
-  for (int i = 0; i + 1 < h->nmark && n < cap; ++i) {
+  for (int i = 0; i + 1 < (h->nmark < 8 ? h->nmark : 8) && n < cap; ++i) {
     float t = 0.f;
     if (hipEventSynchronize(h->mark[i + 1]) != hipSuccess || hipEventElapsedTime(&t, h->mark[i], h->mark[i + 1]) != hipSuccess) {
       (void)hipGetLastError();        // (a mark that was never recorded: not an error of the step)
@@ -1019,7 +1027,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
 
 void vp_pixrefer_destroy(vp_pixrefer_t* h) {
   if (!h) return;
-  if (h->marks_made) for (int i = 0; i < 12; ++i) (void)hipEventDestroy(h->mark[i]);
+  if (h->marks_made) for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->mark[i]);
   if (h->overlap) {
     (void)hipStreamSynchronize(h->side);
     (void)hipEventDestroy(h->ev_fork);
@@ -1108,6 +1116,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   for (Layer& L : h->G.l) {
     if (split_enc && L.scope.rfind("encoder_fg_", 0) == 0) continue;
     if (split_enc && L.scope == "merged_encoder_2") VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
+    if (g_phase_detail) phase_mark(h, st, 8 + (int)(&L - &h->G.l[0]));          // per-layer marks: [8 + layer] = before the layer's forward
     if ((rc = run_layer_fwd(h, h->G, L, st))) return rc;
   }
 
@@ -1461,6 +1470,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     const int ss = fg ? 2 : 0;
     if (i == i_md5 - 1) phase_mark(h, st, 4);
     if (i == i_me2 - 1) phase_mark(h, st, 5);
+    if (g_phase_detail && !fg) phase_mark(h, st, 32 + i);                         // [32 + layer] = before the layer's backward on `st`
     if (L.has_bn) if ((rc = run_bn_bwd(h, G, L, true, 0, N, 0, 1, s2, ss))) return rc;
     if (wsplit && !fg) {
       // the weight gradient of a layer hangs off the chain (only its data gradient feeds the next layer): branch stream
