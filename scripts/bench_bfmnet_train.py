@@ -1,4 +1,4 @@
-"""ms per BFMNet training step on one MI355X: `python scripts/bench_bfmnet_train.py [steps] [batch] [nver] [eager|graph]`.
+"""ms per BFMNet training step on one MI355X: `python scripts/bench_bfmnet_train.py [steps] [batch] [nver] [eager|graph|auto]`.
 Synthetic clips of 24 frames (the generator's slice length), a random stand-in face model of `nver` vertices (35709 = BFM_model_front),
 dropout on, loss fetched every step as train_bfmnet.py does.  Prints one JSON line."""
 import json
@@ -30,7 +30,9 @@ def main():
   mfccs = torch.randn(B, 5 * T, 80, device=dev)
   coeff = torch.randn(B, T, 257, device=dev) * 0.5
   seq = torch.full((B,), T, dtype=torch.int32, device=dev)
-  if mode == "graph":
+  if mode == "auto":
+    step = lambda: eng.train_step_auto(ears, mfccs, coeff, seq, 0.25)
+  elif mode == "graph":
     step = lambda: eng.train_step_graphed(ears, mfccs, coeff, seq, 0.25)
   else:
     step = lambda: eng.train_step(ears, mfccs, coeff, seq, masks=eng.draw_masks(0.25))

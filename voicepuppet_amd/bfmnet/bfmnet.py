@@ -253,8 +253,8 @@ class BFMNet(ModelBuilder):
       apply = 'Train_op' in names
       if any(n in names for n in ('Train_op', 'Loss', 'Grads', 'BFMCoeffDecoder')):
         eng.lr = lr
-        if apply:    # the whole step replays from a hipGraph (dropout draws included)
-          aux = eng.train_step_graphed(t(vals['Ears']), t(vals['Mfccs']), t(vals['BFM_coeff_seq']), seq, self.drop_rate)
+        if apply:    # small batches: the whole step replays from a hipGraph (dropout draws included); large ones: eager on two streams
+          aux = eng.train_step_auto(t(vals['Ears']), t(vals['Mfccs']), t(vals['BFM_coeff_seq']), seq, self.drop_rate)
           self.global_step += 1
         else:
           aux = eng.train_step(t(vals['Ears']), t(vals['Mfccs']), t(vals['BFM_coeff_seq']), seq, masks=eng.draw_masks(self.drop_rate), apply=False)

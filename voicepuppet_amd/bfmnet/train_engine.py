@@ -106,6 +106,9 @@ class BFMNetTrainEngine:
     self._gdpad = None
     self._pk, self._pk_pending, self._pk_ready, self._pk_arena, self._packed = {}, {}, False, (None, 0), None
     self._graphs = {}
+    # weight gradients (1x1 / depthwise / dense / GRU) run on a second stream beside the data-gradient chain (VP_F4_NO_SIDE=1: one stream)
+    self._side = None if os.environ.get("VP_F4_NO_SIDE") else torch.cuda.Stream()
+    self._hold, self._mmkey = [], "mm"
 
   # ---- parameters -----------------------------------------------------------------------------------------------------------
   def load_params(self, params):
@@ -197,15 +200,36 @@ class BFMNetTrainEngine:
 
   # ---- matrix products: the repo's own float32 MFMA kernels behind vp_mm_* (include/vp_hip.h), no vendor GEMM library --------------------
   def _mm_ws(self, P, K, N):
-    """One workspace for every product of the step (they run back to back on one stream); its first 256 bytes are the kernels' zero page
-    (include/vp_hip.h): allocated zeroed, never written."""
+    """One workspace per stream for every product of the step (they run back to back on that stream); its first 256 bytes are the
+    kernels' zero page (include/vp_hip.h): allocated zeroed, never written."""
     need = self.L.vp_mm_workspace_bytes(int(P), int(K), int(N))
-    w = self._ws.get("mm")
+    w = self._ws.get(self._mmkey)
     if w is None or w.numel() < need:
       if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("the matrix-product workspace must exist before a graph capture (run one eager step first)")
-      w = self._ws["mm"] = torch.zeros(int(need), dtype=torch.uint8, device=self.dev)
+      w = self._ws[self._mmkey] = torch.zeros(int(need), dtype=torch.uint8, device=self.dev)
     return w
+
+  def _fork(self, fn, *keep):
+    """Run fn() - weight-gradient launches, nothing the data-gradient chain waits for - on the side stream, ordered behind everything
+    enqueued on the current stream so far.  The tensors it reads are held until _join(): the caching allocator must not hand their memory
+    to a later allocation of the main stream while the side stream still reads it (also inside a graph capture's private pool)."""
+    if self._side is None or torch.cuda.is_current_stream_capturing():
+      fn()            # (a captured graph replays one stream: hipGraph branches measured slower than the chain, 8.97 vs 8.49 ms at batch 4)
+      return
+    self._side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(self._side):
+      self._mmkey = "mm_side"
+      try:
+        fn()
+      finally:
+        self._mmkey = "mm"
+    self._hold.extend(keep)
+
+  def _join(self):
+    if self._side is not None:
+      torch.cuda.current_stream().wait_stream(self._side)
+    self._hold = []
 
   # Weight matrices are packed into the kernels' chunk-major layout AHEAD of the products: the first (eager) step registers every
   # (matrix, direction, shape) it multiplies with; from then on ONE launch at the top of a step packs all arena matrices from the
@@ -365,6 +389,14 @@ class BFMNetTrainEngine:
     loss, loss_data, gn = res.tolist()
     return {"loss": loss, "loss_data": loss_data, "global_norm": gn}
 
+  def train_step_auto(self, ears, mfccs, bfm_coeffs, seq_len, drop_rate=0.25, inner_rate=0.25):
+    """The faster of the two schedules for this batch size: up to 8 clips the step is a chain of launch-latency-bound kernels and the
+    hipGraph replay wins (8.5 vs 9.2 ms eager at batch 4); above that the eager step with the weight gradients on the second stream
+    does (24.3 vs 26.3 ms at batch 32: the graph replays one stream)."""
+    if self.B <= 8 or self._side is None:
+      return self.train_step_graphed(ears, mfccs, bfm_coeffs, seq_len, drop_rate, inner_rate)
+    return self.train_step(ears, mfccs, bfm_coeffs, seq_len, masks=self.draw_masks(drop_rate, inner_rate))
+
   def _advance(self):
     self.step_t += 1
     self.lr_t.fill_(self.lr * math.sqrt(1 - 0.999 ** self.step_t) / (1 - 0.9 ** self.step_t))
@@ -464,8 +496,10 @@ class BFMNetTrainEngine:
     def dense_bwd(dy):
       _, x, wname, bname, y, act, mask = tape.pop()
       dz = dy if (act == ACT_NONE and mask is None) else self._act_bwd(dy, y, act, mask)
-      self._mm_dw(x, dz, g[wname])
-      torch.sum(dz, 0, out=g[bname])
+      def wg(x=x, dz=dz, wname=wname, bname=bname):
+        self._mm_dw(x, dz, g[wname])
+        torch.sum(dz, 0, out=g[bname])
+      self._fork(wg, x, dz)
       return self._mm_dx(dz, p[wname])
     d = dense_bwd(do)
     d = dense_bwd(d)
@@ -475,12 +509,15 @@ class BFMNetTrainEngine:
     dag, dac = torch.empty(B * T, 512, dtype=torch.float32, device=self.dev), torch.empty(B * T, 256, dtype=torch.float32, device=self.dev)
     _lib.check(L.vp_gru_train_bwd(_ptr(d.contiguous()), _ptr(whg), _ptr(whc), _ptr(seq), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), _ptr(dag), _ptr(dac),
                                   B, T, _stream()), "vp_gru_train_bwd")
-    self._mm_dw(c1, dag, g[GRU + "gates/kernel"][:256])
-    self._mm_dw(shp, dag, g[GRU + "gates/kernel"][256:])
-    torch.sum(dag, 0, out=g[GRU + "gates/bias"])
-    self._mm_dw(c1, dac, g[GRU + "candidate/kernel"][:256])
-    self._mm_dw(sr * shp, dac, g[GRU + "candidate/kernel"][256:])
-    torch.sum(dac, 0, out=g[GRU + "candidate/bias"])
+    srh = sr * shp
+    def gru_wg():
+      self._mm_dw(c1, dag, g[GRU + "gates/kernel"][:256])
+      self._mm_dw(shp, dag, g[GRU + "gates/kernel"][256:])
+      torch.sum(dag, 0, out=g[GRU + "gates/bias"])
+      self._mm_dw(c1, dac, g[GRU + "candidate/kernel"][:256])
+      self._mm_dw(srh, dac, g[GRU + "candidate/kernel"][256:])
+      torch.sum(dac, 0, out=g[GRU + "candidate/bias"])
+    self._fork(gru_wg, c1, shp, srh, dag, dac)
     d = self._mm_dx(dag, wg[:256])
     self._mm_dx(dac, wc[:256], out=d, accumulate=True)                               # d loss / d c1
     d = dense_bwd(d)
@@ -491,9 +528,10 @@ class BFMNetTrainEngine:
       _, x, kernel, y, mean, rstd, shift, act, scope = tape.pop()
       dy = self._bn_act_bwd(da, y, mean, rstd, shift, act, scope)
       if x.shape[1] == 48:                                                           # stem: no input gradient
-        self._mm_dw(x, dy, g[PREFIX + "block0_0/conv2d/conv2d/kernel"].view(45, 32), k_real=45)
+        self._fork(lambda: self._mm_dw(x, dy, g[PREFIX + "block0_0/conv2d/conv2d/kernel"].view(45, 32), k_real=45), x, dy)
         return None
-      self._mm_dw(x, dy, self._grad2d(kernel))
+      gk = self._grad2d(kernel)
+      self._fork(lambda: self._mm_dw(x, dy, gk), x, dy)
       return self._mm_dx(dy, kernel)
     while tape:
       kind = tape[-1][0]
@@ -508,7 +546,8 @@ class BFMNetTrainEngine:
         dad = cba_bwd(dsum)                                                          # projection conv
         _, a_in, wd, yd, mean, rstd, shift, b, h_, w_ = tape.pop()
         dyd = self._bn_act_bwd(dad, yd, mean, rstd, shift, ACT_RELU6, b + "/depthwise_conv2d")
-        self._dw_wgrad(a_in, dyd, h_, w_, g[b + "/depthwise_conv2d/SeparableConv2d/depthwise_weights"])
+        gdw = g[b + "/depthwise_conv2d/SeparableConv2d/depthwise_weights"]
+        self._fork(lambda a_in=a_in, dyd=dyd, h_=h_, w_=w_, gdw=gdw: self._dw_wgrad(a_in, dyd, h_, w_, gdw), a_in, dyd)
         da = self._dw(dyd, wd.flip(0).contiguous(), h_, w_)
         d = cba_bwd(da)                                                              # expansion conv
         d.add_(dsc)
@@ -517,6 +556,7 @@ class BFMNetTrainEngine:
       else:
         raise AssertionError(kind)
 
+    self._join()                                                                     # every weight gradient is in the arena
     # ---- regulariser, clip_by_global_norm, Adam, moving averages ------------------------------------------------------------------------
     part = torch.empty(L.vp_sumsq_partials(self.ntrain), dtype=torch.float64, device=self.dev)
     _lib.check(L.vp_l2_regulariser(_ptr(self.arena), _ptr(self.l2mask), _ptr(self.grads), self.ntrain, L2_SCALE, _ptr(part), _stream()), "vp_l2_regulariser")
