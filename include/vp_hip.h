@@ -250,6 +250,12 @@ void vp_bfmnet_destroy(vp_bfmnet_t* h);
 int vp_bfmnet_params_changed(vp_bfmnet_t* h);
 /* ears [B,T,1], mfccs [B,5T,80], seq_len [B] (int32) -> BFMCoeffDecoder [B,T,64]; all device pointers */
 int vp_bfmnet_forward(vp_bfmnet_t* h, const float* ears, const float* mfccs, const int* seq_len, float* out, void* stream);
+/* Opt-in: the reference's BFMCoeffDecoder applies tf.nn.dropout(keep_prob = 0.75) behind both hidden dense layers unconditionally,
+ * i.e. also at inference (voicepuppet/bfmnet/bfmnet.py:114,116: that class's drop_rate is never zeroed).  The default forward omits
+ * both (deterministic: the expectation of the reference's output).  With masks set - mask0 [B*T,128], mask1 [B*T,64], device f32,
+ * entries 0 or 1 / keep_prob, owned by the caller until cleared with NULLs - every following forward multiplies the two hidden
+ * activations by them: one SAMPLE of the reference's inference output for that draw. */
+int vp_bfmnet_set_decoder_dropout(vp_bfmnet_t* h, const float* mask0, const float* mask1);
 /* "MfccEncoder" [B,T,256], "RNNModule" [B,T,256] of the last forward */
 int vp_bfmnet_tensor(vp_bfmnet_t* h, const char* name, void** ptr, int64_t shape[4]);
 

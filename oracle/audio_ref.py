@@ -237,8 +237,11 @@ def gru_seq(x, seq_len, wg, bg, wc, bc):
   return out
 
 
-def bfmnet_fwd(p, ears, mfccs, seq_len):
-  """BFMNet.build_inference_op (bfmnet.py:325-333): ears [B,T,1], mfccs [B,5T,80] -> [B,T,64]."""
+def bfmnet_fwd(p, ears, mfccs, seq_len, decoder_masks=None):
+  """BFMNet.build_inference_op (bfmnet.py:325-333): ears [B,T,1], mfccs [B,5T,80] -> [B,T,64].
+  decoder_masks: None = deterministic (both tf.nn.dropout of BFMCoeffDecoder.build_network, bfmnet.py:114,116, omitted: DESIGN.md
+  section 4); (m0 [B,T,128], m1 [B,T,64]) with entries 0 or 1 / keep_prob = one draw of those two dropouts, which the reference
+  applies at inference too."""
   B = mfccs.shape[0]
   feat = mfccnet_fwd(p, mfccs[..., None])
   enc = maxpool_same(feat, (5, 3), (5, 3)).reshape(B, -1, 256)                      # bfmnet.py:35-36
@@ -247,7 +250,11 @@ def bfmnet_fwd(p, ears, mfccs, seq_len):
   g = 'rnn_module/rnn/multi_rnn_cell/cell_0/gru_cell/'
   rnn = gru_seq(c1, seq_len, p[g + 'gates/kernel'], p[g + 'gates/bias'], p[g + 'candidate/kernel'], p[g + 'candidate/bias'])
   d = leaky_relu(rnn @ p['bfm_coeff_decoder/dense/kernel'] + p['bfm_coeff_decoder/dense/bias'])
+  if decoder_masks is not None:
+    d = d * decoder_masks[0]                                                         # bfmnet.py:114
   d = leaky_relu(d @ p['bfm_coeff_decoder/dense_1/kernel'] + p['bfm_coeff_decoder/dense_1/bias'])
+  if decoder_masks is not None:
+    d = d * decoder_masks[1]                                                         # bfmnet.py:116
   out = d @ p['bfm_coeff_decoder/dense_2/kernel'] + p['bfm_coeff_decoder/dense_2/bias']
   e = ears * np.array([-2.0, -2.0, -2.0, -4.0])                                      # bfmnet.py:209
   out = out.copy()

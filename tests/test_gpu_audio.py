@@ -63,6 +63,36 @@ def test_bfmnet_parity(b, t, lens):
 
 
 @pytest.mark.gpu
+def test_bfmnet_reference_decoder_dropout_is_an_opt_in():
+  """The reference's BFMCoeffDecoder drops 25 % of both hidden activations also at inference (bfmnet.py:114,116).  Default: omitted
+  (deterministic).  With one explicit draw of the two masks the device equals the oracle run with the same masks; clearing the masks
+  restores the deterministic output bit for bit."""
+  b, t, lens = 2, 6, [6, 4]
+  p = ar.init_bfmnet_params(3, dtype=np.float32)
+  rng = np.random.default_rng(4)
+  pcm = synth_pcm(b, ar.pcm_length_for(t), seed=5)
+  mfcc = ar.extract_mfcc(pcm.astype(np.float64)).astype(np.float32)
+  ears = (rng.uniform(size=(b, t, 1)) / 100).astype(np.float32)
+  eng = BFMNetEngine(b, t)
+  eng.load_params(p)
+  e_d, m_d = torch.tensor(ears, device="cuda"), torch.tensor(mfcc, device="cuda")
+  plain = eng.forward(e_d, m_d, lens).cpu().numpy()
+  g = torch.Generator(device="cuda").manual_seed(11)
+  m0, m1 = eng.draw_decoder_dropout(0.25, generator=g)
+  u = np.unique(m0.cpu().numpy())
+  assert len(u) == 2 and u[0] == 0 and abs(u[1] - 1 / 0.75) < 1e-6 and 0.6 < float((m0 > 0).float().mean()) < 0.9
+  dropped = eng.forward(e_d, m_d, lens).cpu().numpy()
+  p64 = {k: v.astype(np.float64) for k, v in p.items()}
+  ref = ar.bfmnet_fwd(p64, ears.astype(np.float64), mfcc.astype(np.float64), lens,
+                      decoder_masks=(m0.cpu().numpy().astype(np.float64), m1.cpu().numpy().astype(np.float64)))
+  ref_plain = ar.bfmnet_fwd(p64, ears.astype(np.float64), mfcc.astype(np.float64), lens)
+  assert gu.rel_l2(dropped, ref["BFMCoeffDecoder"]) < 1e-3
+  assert gu.rel_l2(ref["BFMCoeffDecoder"], ref_plain["BFMCoeffDecoder"]) > 5e-2      # the draw matters
+  eng.set_decoder_dropout(None, None)
+  assert np.array_equal(eng.forward(e_d, m_d, lens).cpu().numpy(), plain)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("b,t,lens", [(2, 6, [6, 4]), (3, 25, [25, 25, 17])])
 def test_bfmnet_bf16_trunk(b, t, lens):
   """trunk_dtype = bf16 (opt-in throughput mode, 2x the f32 path): the 6x-expanded tensors and every 1x1-conv operand of MfccNet

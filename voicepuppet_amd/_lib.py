@@ -111,6 +111,7 @@ _SIGNATURES = {
     "vp_bfmnet_destroy": (None, [_P]),
     "vp_bfmnet_params_changed": (ctypes.c_int, [_P]),
     "vp_bfmnet_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
+    "vp_bfmnet_set_decoder_dropout": (ctypes.c_int, [_P, _P, _P]),
     "vp_bfmnet_tensor": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     "vp_maxpool2x2_fwd": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "vp_maxpool2x2_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),

@@ -99,6 +99,30 @@ class BFMNetEngine:
     host = self.params.cpu().numpy()
     return {name: host[off:off + int(np.prod(shape))].reshape(shape).copy() for name, off, shape in self.manifest}
 
+  def set_decoder_dropout(self, mask0=None, mask1=None):
+    """Opt-in (include/vp_hip.h, vp_bfmnet_set_decoder_dropout): masks [B,T,128] / [B,T,64] with entries 0 or 1 / keep_prob multiply the
+    decoder's two hidden activations in every following forward - the reference's unconditional tf.nn.dropout (bfmnet.py:114,116);
+    None clears them (the deterministic default)."""
+    B, T = self.desc.batch, self.desc.frames
+    keep = []
+    for m, c in ((mask0, 128), (mask1, 64)):
+      if m is not None:
+        m = m.to(self.params.device, torch.float32).contiguous()
+        assert m.numel() == B * T * c, (tuple(m.shape), (B, T, c))
+      keep.append(m)
+    self._drop_masks = keep              # the executor keeps the raw pointers: the tensors must outlive the forwards
+    _lib.check(self.L.vp_bfmnet_set_decoder_dropout(self.h, _ptr(keep[0]), _ptr(keep[1])), "vp_bfmnet_set_decoder_dropout")
+
+  def draw_decoder_dropout(self, rate=0.25, generator=None):
+    """One draw of the two masks as tf.nn.dropout(keep_prob = 1 - rate) makes them (from torch's device generator, not TensorFlow's
+    stream) and set_decoder_dropout with them."""
+    B, T = self.desc.batch, self.desc.frames
+    keep = 1.0 - rate
+    mk = lambda c: (torch.rand(B, T, c, device=self.params.device, generator=generator) < keep).to(torch.float32) / keep
+    m0, m1 = mk(128), mk(64)
+    self.set_decoder_dropout(m0, m1)
+    return m0, m1
+
   def forward(self, ears, mfccs, seq_len):
     B, T = self.desc.batch, self.desc.frames
     ears, mfccs = ears.contiguous(), mfccs.contiguous()

@@ -76,6 +76,9 @@ class BFMNet(ModelBuilder):
     self.decay_rate = params.training['decay_rate']
     self.drop_rate = params.training.get('drop_rate', 0.25)
     self.synthetic = (params.get('amd') or {}).get('synthetic_data', 'auto')
+    # opt-in (params.yml: amd: {reference_decoder_dropout: true}): the reference's BFMCoeffDecoder keeps its two tf.nn.dropout at
+    # inference (bfmnet.py:114,116); off = the deterministic expectation
+    self.reference_decoder_dropout = bool((params.get('amd') or {}).get('reference_decoder_dropout', False))
     for k, want in (('thinresnet_output_channels', 256), ('encode_embedding_size', 256), ('rnn_hidden_size', 256),
                     ('rnn_layers', 1), ('bfm_coeff_size', 64)):
       if getattr(params, k) != want:
@@ -264,6 +267,8 @@ class BFMNet(ModelBuilder):
       eng = self.engine if which == 'infer' else self._eval_engine
       if which == 'eval':
         eng.load_params(self.train_engine.get_params())     # the eval graph shares the variables being trained (AUTO_REUSE)
+      if which == 'infer' and self.reference_decoder_dropout:
+        eng.draw_decoder_dropout(0.25)                      # a fresh draw per run, as a TF session would make
       coeff = eng.forward(t(vals['Ears']), t(vals['Mfccs']), seq)
       if 'Loss' in names:
         aux['loss'] = self.train_engine.eval_loss(coeff, t(vals['BFM_coeff_seq']), seq)

@@ -13,4 +13,5 @@ hipError_t launch_maxpool_same(const void* x, void* y, int in_bf16, int out_bf16
 hipError_t launch_fold_bn(const float* w, const float* beta, const float* mean, const float* var, float eps, size_t n, int C, float* wf, float* bf, hipStream_t st);
 hipError_t launch_gru_seq(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, int B, int T, hipStream_t st);
 hipError_t launch_add_ears(float* out, const float* ears, int n, hipStream_t st);
+hipError_t launch_mul_inplace(float* x, const float* m, size_t n, hipStream_t st);
 }  // namespace vp

@@ -245,6 +245,12 @@ __global__ __launch_bounds__(256) void gru_seq_kernel(const float* __restrict__ 
 }
 
 // out[b,t,16:20] += ears[b,t] * {-2,-2,-2,-4}     (bfmnet.py:117,209)
+// x *= m, element-wise (the opt-in decoder dropout masks of BFMNet inference: 0 or 1 / keep_prob)
+__global__ void mul_inplace_kernel(float* __restrict__ x, const float* __restrict__ m, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= m[i];
+}
+
 __global__ void add_ears_kernel(float* __restrict__ out, const float* __restrict__ ears, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -305,6 +311,10 @@ hipError_t launch_fold_bn(const float* w, const float* beta, const float* mean, 
 }
 hipError_t launch_gru_seq(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, int B, int T, hipStream_t st) {
   hipLaunchKernelGGL(gru_seq_kernel, dim3(B), dim3(256), 0, st, xg, xc, whg, whc, seq_len, out, T);
+  return hipGetLastError();
+}
+hipError_t launch_mul_inplace(float* x, const float* m, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(mul_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, m, n);
   return hipGetLastError();
 }
 hipError_t launch_add_ears(float* out, const float* ears, int n, hipStream_t st) {

@@ -265,6 +265,7 @@ struct vp_bfmnet {
   void* zeros;
   bool dirty;
   int T5, Wm[6];
+  const float *drop0, *drop1;   // opt-in: the reference's unconditional decoder dropout (bfmnet.py:114,116) as explicit masks
 };
 
 namespace {
@@ -472,9 +473,17 @@ int vp_bfmnet_forward(vp_bfmnet_t* h, const float* ears, const float* mfccs, con
   if ((rc = run_gemm(h, m.g_xc, h->c1, h->xc, ACT_NONE, 0, st))) return rc;
   VP_HIP_CHECK(launch_gru_seq(h->xg, h->xc, h->params + m.gk + (size_t)256 * 512, h->params + m.ck + (size_t)256 * 256, seq_len, h->rnn, B, T, st));
   if ((rc = run_gemm(h, m.g_d0, h->rnn, h->dd0, ACT_LEAKY, 0, st))) return rc;
+  if (h->drop0) VP_HIP_CHECK(launch_mul_inplace(h->dd0, h->drop0, (size_t)B * T * 128, st));
   if ((rc = run_gemm(h, m.g_d1, h->dd0, h->dd1, ACT_LEAKY, 0, st))) return rc;
+  if (h->drop1) VP_HIP_CHECK(launch_mul_inplace(h->dd1, h->drop1, (size_t)B * T * 64, st));
   if ((rc = run_gemm(h, m.g_d2, h->dd1, out, ACT_NONE, 0, st))) return rc;
   VP_HIP_CHECK(launch_add_ears(out, ears, B * T, st));
+  return VP_OK;
+}
+
+int vp_bfmnet_set_decoder_dropout(vp_bfmnet_t* h, const float* mask0, const float* mask1) {
+  if (!h) { set_err("vp_bfmnet_set_decoder_dropout: null handle"); return VP_ERR_ARG; }
+  h->drop0 = mask0; h->drop1 = mask1;
   return VP_OK;
 }
 
