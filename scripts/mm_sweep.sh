@@ -1,5 +1,8 @@
-cd $GRAFT_REPO_ROOT
-for s in "" "VP_SPLITK_TARGET=256 VP_SPLITK_MAX=16" "VP_SPLITK_TARGET=256 VP_SPLITK_MAX=16 VP_SPLITK_MINCHUNK=8" "VP_SPLITK_TARGET=192 VP_SPLITK_MAX=12" "VP_SPLITK_TARGET=512 VP_SPLITK_MAX=32 VP_SPLITK_MINCHUNK=8"; do
-  echo "== $s"
-  env $s python scripts/mm_bench.py 4 2>/dev/null | awk '{print $1,$3,$5,$7,$8,$12,$13,$17,$18}' 
+#!/bin/bash
+# per-product timing of the float32 matrix products under experiment settings: bash scripts/mm_sweep.sh BATCH "ENV..." ["ENV..." ...]
+cd "${GRAFT_REPO_ROOT:-.}"
+b=${1:-4}; shift
+for s in "$@"; do
+  echo "== batch $b [$s]"
+  env $s python scripts/mm_bench.py $b 10 2>/dev/null | awk '{ if ($1 == "batch") print; else print $1,$3,$5,$7,$8,$12,$13,$17,$18 }'
 done

@@ -65,6 +65,7 @@ struct IgemmArgs {
   // tap t = r * p_kw + c  ->  (dh, dw) = (p_dhf + r * p_dhs, p_dwf + c * p_dws)
   int patch, p_kw, p_dhf, p_dhs, p_dwf, p_dws;
   void* pool_out;           // patch kernel, 16 x 16-pixel tiles: also write the 2x2 max-pooled output [N][Hg/2][Wg/2][ldY] (null: no)
+  int pool_only;            // with pool_out: write ONLY the pooled output (nobody reads the full-resolution tensor: the real half of the VGG trunk)
   // few-pixel kernel (conv_smallp.hip; patch == 3, plan-time decision: packed rows unpermuted): 32 channels x sp_npt * 16 pixels per tile,
   // splitk = K splits over blocks, partial = their slabs [split][tile][pixels][32]
   unsigned* sp_cnt;         // [tiles + channel tiles] arrival counters: zero before the launch, left zero by it

@@ -194,6 +194,9 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
         bsum += x; bsq = fmaf(x, x, bsq);
       }
     }
+    bool store_y = true;
+    if constexpr (pix_has_pool<PixFn>::value) store_y = !(a.pool_out != nullptr && a.pool_only);
+    if (store_y)
     for (int idx = tid; idx < RP * CG; idx += NT) {
       const int p = idx / CG, cgp = idx - p * CG;
       const long long ot = otab[p];

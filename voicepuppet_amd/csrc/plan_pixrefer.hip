@@ -574,9 +574,10 @@ static bool plan_can_pool(const IgemmPlan& p) {
 }
 
 // forward of one half of the batch of a plain conv layer (VGG: no batch-norm, activation in the epilogue): half 0 / 1
-static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStream_t st, void* pool_out = nullptr) {
+static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStream_t st, void* pool_out = nullptr, bool pool_only = false) {
   IgemmArgs a = L.fwd_half.a;
   a.pool_out = pool_out;
+  a.pool_only = pool_out && pool_only ? 1 : 0;
   const int nb = a.N;
   fill_src(n, L, a.x, nb, half * nb, 0, h->es);
   a.Wp = n.packed + L.pk_fwd_half * h->es;
@@ -1094,7 +1095,9 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
       Layer& L = Vs.l[i];
       const bool pooled = L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2";
       const bool fuse = pooled && plan_can_pool(L.fwd_half);
-      if ((rc = run_layer_fwd_half(h, Vs, L, 0, h->side, fuse ? Vs.t[L.out + 1].y : nullptr))) return rc;
+      // the real half has no backward pass: of conv1_2 / conv2_2 only the pooled image is ever read, the full-resolution store is skipped
+      static const bool pool_only = !getenv("VP_NO_POOL_ONLY");
+      if ((rc = run_layer_fwd_half(h, Vs, L, 0, h->side, fuse ? Vs.t[L.out + 1].y : nullptr, pool_only))) return rc;
       if (pooled && !fuse) {
         const Tens& ti = Vs.t[L.out];
         Tens& tp = Vs.t[L.out + 1];
