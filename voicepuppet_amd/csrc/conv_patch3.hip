@@ -42,10 +42,14 @@ struct Patch3TilePix {
   }
 };
 
-template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC>
+// NSTW: stages of the weight ring = NSTW - 1 steps of weights in flight.  A step of a 64-row tile is 8 MFMAs per wave, far shorter than
+// the 1-1.5 us an LDS-DMA takes to land under load: with 3 stages the loop ran at the DMA latency (0.7 us per step whatever the tile),
+// with 6 the weights of five steps are in flight.  18 steps per trip: NSTW divides 18, stage indices stay compile-time.
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC, int NSTW = 3>
 __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
-  constexpr int NW = 8, NT = 512, NSTW = 3;
+  constexpr int NW = 8, NT = 512, LA = NSTW - 1;
+  static_assert(18 % NSTW == 0 && NSTW >= 3, "ring stages");
   static_assert(WC * WP == NW, "eight waves");
   constexpr int BC = WC * TC * 16, BP = TH * TW;
   static_assert(BP == WP * TP * 16, "pixel blocks of the tile = pixel blocks of the waves");
@@ -56,11 +60,11 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   constexpr int PW = TW + 2, PH = TH + 2, NPATCH = PW * PH;
   constexpr int PPAD = (NPATCH + 127) / 128 * 128;                   // patch pixels, padded to whole DMA rounds of the 8 waves
   constexpr int JP = PPAD / 128;                                     // patch DMA instructions per wave and chunk
-  static_assert(JP <= 7, "one patch DMA per tap step, none in the last two");
+  static_assert(JP + LA <= 9, "one patch DMA per tap step, none in the last LA steps of a chunk");
   constexpr int PBUFB = PPAD * 64;                                   // bytes of one patch buffer
   constexpr int WSTB = 4 * BC * 16;                                  // bytes of one weight stage
   constexpr int WBASE = 2 * PBUFB;
-  static_assert(PBUFB + 2 * PW * 64 + 64 < 65536 && 2 * WSTB + 7 * 1024 + 16 < 65536, "read offsets are DS immediates");
+  static_assert(PBUFB + 2 * PW * 64 + 64 < 65536 && (NSTW - 1) * WSTB + 7 * 1024 + 16 < 65536, "read offsets are DS immediates");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -150,31 +154,34 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
 #pragma unroll
     for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // prologue: the whole first patch, then the weights of the first two steps
+  // prologue: the whole first patch, then the weights of the first LA steps
 #pragma unroll
   for (int j = 0; j < JP; ++j) issue_p(0, 0, j);
-  issue_w(0, 0, 0);
-  issue_w(1, 0, 1);
+#pragma unroll
+  for (int d = 0; d < LA; ++d) issue_w(d % 9, d / 9, d % NSTW);
 
   // One trip = 2 chunks x 9 patch positions.  Step U = 9 * cc + u (cc: chunk of the pair = patch buffer, u: patch position);
-  // ring stage U % 3.  In DMA order behind the weights of step U: [patch piece issued at U-2], weights of U+1, [patch piece of U-1]
-  // - a piece is issued at the steps with u < JP, always (behind the last chunk it fetches bytes nobody reads, into the idle buffer)
+  // ring stage U % NSTW.  In DMA order behind the weights of step U (issued at step U - LA): the patch piece of step U - LA, then per
+  // later step its weights and its patch piece - a piece is issued at the steps with u < JP, always (behind the last chunk it
+  // fetches bytes nobody reads, into the idle buffer)
   for (int c = 0; c < nchunkc; c += 2) {
     const bool last_pair = c + 2 >= nchunkc;
     auto step = [&](auto uc) {
       constexpr int U = decltype(uc)::value;
-      constexpr int cc = U / 9, u = U % 9, pr = u / 3, pc = u % 3, stage = U % 3;
-      constexpr int um1 = (U + 17) % 18 % 9, um2 = (U + 16) % 18 % 9;            // patch positions of the two previous steps
-      constexpr int NV = JA + (um1 < JP ? 1 : 0) + (um2 < JP ? 1 : 0);
-      if (U == 17 && last_pair) wait_vm<NV - JA>();                            // (no weights of a next step behind the last one)
+      constexpr int cc = U / 9, u = U % 9, pr = u / 3, pc = u % 3, stage = U % NSTW;
+      // DMAs issued behind the weights of this step: the patch pieces of the LA previous steps, the weights of the LA - 1 next ones
+      constexpr int NPIECE = [] { int n = 0; for (int k = 1; k <= LA; ++k) n += ((U + 18 - k) % 18 % 9) < JP ? 1 : 0; return n; }();
+      constexpr int NV = (LA - 1) * JA + NPIECE;
+      constexpr int WLAST = (17 - U < LA - 1 ? 17 - U : LA - 1);                 // behind the last pair no weights of a next trip follow
+      if (U + LA - 1 > 17 && last_pair) wait_vm<WLAST * JA + NPIECE>();
       else wait_vm<NV>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // weights two steps ahead (ring stage (U + 2) % 3, last read in step U - 1)
+      // weights LA steps ahead (ring stage (U + LA) % NSTW, last read in step U - 1)
       {
-        constexpr int U2 = (U + 2) % 18;
-        if (U < 16) issue_w(U2 % 9, c + U2 / 9, (U + 2) % 3);
-        else if (!last_pair) issue_w(U2 % 9, c + 2, (U + 2) % 3);
+        constexpr int UL = (U + LA) % 18;
+        if (U + LA < 18) issue_w(UL % 9, c + UL / 9, (U + LA) % NSTW);
+        else if (!last_pair) issue_w(UL % 9, c + 2 + UL / 9, (U + LA) % NSTW);
       }
       if constexpr (u < JP) issue_p(c + cc + 1, 1 - cc, u);
       // eight weight blocks per wave: two read batches of four (16 fragment registers instead of 32); the 64-accumulator tile at
@@ -201,18 +208,18 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, Patch3TilePix<TW>{a, n, y0, x0}, c_base, blkA0, blkB0, acc, smem, bt, 0);
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int OCC>
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int OCC, int NSTW = 3>
 static hipError_t launch_patch3_t(const IgemmArgs& b, hipStream_t st) {
   constexpr int BC = WC * TC * 16, BP = TH * TW;
   constexpr int PPAD = ((TH + 2) * (TW + 2) + 127) / 128 * 128;
-  constexpr int RINGB = 3 * 4 * BC * 16 + 2 * PPAD * 64;
+  constexpr int RINGB = NSTW * 4 * BC * 16 + 2 * PPAD * 64;
   constexpr int NPE = epi_passes(BC, BP, WP, RINGB);
   size_t sm = RINGB;
   const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
   if (se > sm) sm = se;
   const int tiles = b.N * ((b.Hg + TH - 1) / TH) * ((b.Wg + TW - 1) / TW);
   dim3 grid(tiles, b.CoutPad / BC, 1);
-  auto kern = b.bn_part ? igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC> : igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC>;
+  auto kern = b.bn_part ? igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC, NSTW> : igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC, NSTW>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(kern, grid, dim3(512), sm, st, b);
   return hipGetLastError();
@@ -232,9 +239,15 @@ hipError_t launch_igemm_patch3(const IgemmArgs& a, int is_bf16, int bc, int bp, 
   b.xcd_remap = patch_xcd_knob();
 #define VP_PATCH3_GO(WC, WP, TC, TP, TH, TW, OCC) \
   (is_bf16 ? launch_patch3_t<bf16, WC, WP, TC, TP, TH, TW, OCC>(b, st) : launch_patch3_t<float, WC, WP, TC, TP, TH, TW, OCC>(b, st))
+#define VP_PATCH3_GO6(WC, WP, TC, TP, TH, TW, OCC) \
+  (is_bf16 ? launch_patch3_t<bf16, WC, WP, TC, TP, TH, TW, OCC, 6>(b, st) : launch_patch3_t<float, WC, WP, TC, TP, TH, TW, OCC, 6>(b, st))
+  // 64-row tiles of 16 x 16 pixels: six weight stages (73 KB of LDS, still two blocks per CU); VP_PATCH3_RING=3: the three-stage form
+  static const int ring = getenv("VP_PATCH3_RING") ? atoi(getenv("VP_PATCH3_RING")) : 6;
   if (bc == 256) return bp == 128 ? VP_PATCH3_GO(2, 4, 8, 2, 8, 16, 4) : VP_PATCH3_GO(2, 4, 8, 4, 16, 16, 2);
   if (bc == 128) return bp == 512 ? VP_PATCH3_GO(1, 8, 8, 4, 16, 32, 2) : VP_PATCH3_GO(2, 4, 4, 4, 16, 16, 4);
-  return bp == 512 ? VP_PATCH3_GO(1, 8, 4, 4, 16, 32, 2) : VP_PATCH3_GO(2, 4, 2, 4, 16, 16, 4);
+  if (bp == 512) return VP_PATCH3_GO(1, 8, 4, 4, 16, 32, 2);
+  return ring == 6 ? VP_PATCH3_GO6(2, 4, 2, 4, 16, 16, 4) : VP_PATCH3_GO(2, 4, 2, 4, 16, 16, 4);
+#undef VP_PATCH3_GO6
 #undef VP_PATCH3_GO
 }
 
