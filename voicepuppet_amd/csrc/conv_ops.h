@@ -94,6 +94,13 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   const int P = a.N * a.Hg * a.Wg;
   a.Kpad = round_up(a.ntaps * a.Cin, kc_elems(is_bf16));
   p.cfg = pick_igemm_cfg(rows, P, a.Kpad);
+  // float32 matrix products (one tap: BFMNet's 1x1 convolutions, the DFT): a 128x128 block is 4x the MFMA time of a bf16 one, so a grid
+  // of 257-511 blocks costs two full rounds of the 256 CUs.  64x128 tiles (two resident per CU, half the time each) quantise finer:
+  // rounds x rows 3 x 64 against 2 x 128 for 300 blocks (scripts/mm_bench.py: 19200 x 1152 x 256 forward 140 -> 109 us)
+  if (!is_bf16 && a.ntaps == 1 && p.cfg == 0 && !getenv("VP_NO_F32_TILE_RULE")) {
+    const long long b128 = (long long)((P + 127) / 128) * (rows / 128), b64 = 2 * b128;
+    if (((b64 + 255) / 256) * 64 < ((b128 + 255) / 256) * 128) p.cfg = 1;
+  }
   int bc, bp;
   igemm_tile(p.cfg, &bc, &bp);
   a.CoutPad = round_up(rows, bc);
