@@ -130,6 +130,26 @@ def test_graphed_step_equals_eager_step():
   assert len(losses) == 3 and all(np.isfinite(l) for l in losses)
 
 
+def test_two_stream_step_equals_one_stream_step(monkeypatch):
+  """The eager step runs its weight gradients on a second stream (train_engine._fork); with VP_F4_NO_SIDE=1 everything stays on one.
+  Same kernels on the same values: gradients and updated parameters are bit-identical over three steps."""
+  B, T, seq = 3, 5, [5, 2, 4]
+  p, mf, ears, coeff, model, masks = _case(B, T, seq, 120, 7, True)
+  dev = lambda a: torch.tensor(a, device="cuda")
+  outs = []
+  for one_stream in (False, True):
+    if one_stream:
+      monkeypatch.setenv("VP_F4_NO_SIDE", "1")
+    eng = BFMNetTrainEngine(B, T, model)
+    assert (eng._side is None) == one_stream
+    eng.load_params(p)
+    for _ in range(3):
+      eng.train_step(dev(ears), dev(mf), dev(coeff), seq, {k: dev(v) for k, v in masks.items()})
+    torch.cuda.synchronize()
+    outs.append((eng.grads.clone(), eng.arena.clone()))
+  assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("P,K,N", [(96, 256, 512), (3840, 192, 1152), (1000, 48, 32), (7, 1536, 256), (96, 64, 1007)])
 def test_matrix_products_against_numpy(P, K, N):
   """vp_mm_fwd_f32 / vp_mm_bwd_data_f32 / vp_mm_bwd_weight_f32 (csrc/mm_api.hip: the repo's own float32-MFMA kernels - no vendor GEMM
