@@ -101,14 +101,16 @@ def test_maxpool_hw_same(k, s, shape):
 
 def test_gru_seq():
   L = _lib.lib()
-  B, T, I, H = 3, 7, 64, 256
+  B, T, I, H = 4, 7, 64, 256
   rng = np.random.default_rng(5)
   f = lambda *sh: np.float32(rng.normal(0, 0.08, size=sh)).astype(np.float64)
   x, wg, bg, wc, bc = f(B, T, I) * 10, f(I + H, 2 * H), f(2 * H) + 1.0, f(I + H, H), f(H)
-  seq = np.array([7, 4, 1], np.int32)
+  seq = np.array([7, 4, 1, 0], np.int32)                        # ragged, down to an empty sequence (dynamic_rnn: all-zero outputs)
   want = ar.gru_seq(x, seq, wg, bg, wc, bc)
   xg, xc = x @ wg[:I] + bg, x @ wc[:I] + bc                       # the input halves of the two kernels are plain GEMMs (vp_conv_fwd 1x1)
   out = torch.full((B, T, H), float("nan"), device="cuda")
   xgd, xcd, whg, whc, sq = dev(xg), dev(xc), dev(wg[I:]), dev(wc[I:]), torch.tensor(seq, device="cuda")
   _lib.check(L.vp_gru_seq(P(xgd), P(xcd), P(whg), P(whc), P(sq), P(out), B, T, gu.stream()))
   assert gu.rel_l2(out.cpu().numpy(), want) < 1e-5
+  got = out.cpu().numpy()
+  assert np.all(got[3] == 0) and np.all(got[2, 1:] == 0) and np.all(want[3] == 0)
