@@ -2048,6 +2048,10 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
   const double Pn = (double)a.N * a.Hb * a.Wb;
   ProfScope prof("wgrad", sizeof(T) == 2, pbm, pbn, 2.0 * Pn * a.ntaps * a.Greal * a.Dreal,
                  sizeof(T) * ((double)a.N * a.Hgin * a.Wgin * a.Greal + Pn * a.Dreal) + 4.0 * a.ntaps * a.Greal * a.Dreal, st);
+  if (sizeof(T) == 4 && wgrad_mm_eligible(a, cfg)) {               // one-tap float32 products: transpose-free LDS-DMA kernel (wgrad_mm.hip)
+    g_prof_family = "wgrad_mm";
+    e = launch_wgrad_mm(a, cfg, st);
+  } else
   switch (cfg) {
     case 0: e = launch_wgrad_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 rows x 128 cols
     case 1: e = launch_wgrad_cfg<T, 2, 2, 4, 2>(a, st); break;   // 128 rows x  64 cols
