@@ -341,7 +341,9 @@ int vp_bfm_reconstruct(const vp_bfm_model* m, const float* coeff, const double* 
  *   vp_dwconv7x3_wgrad       its weight gradient [21][c]
  *   vp_maxpool_hw_bwd        backward of vp_maxpool_hw (first maximum of a window, as TF's MaxPoolGrad)
  *   vp_stem_im2col           the 9x5 stride-(1,2) stem as a [pixels, 48] matrix (GEMM operand for forward and weight gradient)
- *   vp_gru_train_fwd / _bwd  GRUCell recurrence with saved gates, and backward through time to the gate / candidate pre-activations
+ *   vp_gru_train_fwd / _bwd  GRUCell recurrence with saved gates, and backward through time to the gate / candidate pre-activations.
+ *                            whg [256][512] / whc [256][256]: the recurrent halves of the two kernels (row = h unit).  _bwd takes them
+ *                            TRANSPOSED (whg_t [512][256], whc_t [256][256]): its products with the kernels' rows then read coalesced columns
  *   vp_bfm_vertex_loss       add_cost_function on D = face_shape(true) - face_shape(pred): loss partials (f64) and dLoss/dD
  *   vp_sumsq                 sum of squares partials (f64): global-norm clipping
  *   vp_l2_regulariser        tf.losses.get_regularization_loss() over the flat arena: gradient contribution + value partials
@@ -364,7 +366,7 @@ int vp_maxpool_hw_bwd(const float* x, const float* dy, float* dx, int b, int h, 
 int vp_stem_im2col(const float* x, float* col, int b, int h, int w, void* stream);
 int vp_gru_train_fwd(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, float* r, float* u, float* c,
                      float* hprev, int b, int t, void* stream);
-int vp_gru_train_bwd(const float* dout, const float* whg, const float* whc, const int* seq_len, const float* r, const float* u, const float* c,
+int vp_gru_train_bwd(const float* dout, const float* whg_t, const float* whc_t, const int* seq_len, const float* r, const float* u, const float* c,
                      const float* hprev, float* dag, float* dac, int b, int t, void* stream);
 int vp_vertex_loss_partials(int b, int j);
 int vp_bfm_vertex_loss(const float* d, const float* vmask, const int* seq_len, int b, int t, int j, float* gd, double* partial, void* stream);

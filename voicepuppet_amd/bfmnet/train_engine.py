@@ -507,7 +507,8 @@ class BFMNetTrainEngine:
     if mr is not None:
       d = d * mr
     dag, dac = torch.empty(B * T, 512, dtype=torch.float32, device=self.dev), torch.empty(B * T, 256, dtype=torch.float32, device=self.dev)
-    _lib.check(L.vp_gru_train_bwd(_ptr(d.contiguous()), _ptr(whg), _ptr(whc), _ptr(seq), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), _ptr(dag), _ptr(dac),
+    whg_t, whc_t = wg[256:].t().contiguous(), wc[256:].t().contiguous()             # the backward kernel reads the recurrent kernels transposed
+    _lib.check(L.vp_gru_train_bwd(_ptr(d.contiguous()), _ptr(whg_t), _ptr(whc_t), _ptr(seq), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), _ptr(dag), _ptr(dac),
                                   B, T, _stream()), "vp_gru_train_bwd")
     srh = sr * shp
     def gru_wg():

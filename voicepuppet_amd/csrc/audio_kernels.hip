@@ -4,6 +4,7 @@
 // f32-MFMA implicit-GEMM kernel of conv_kernels.hip.
 // Reference: generator/generator.py:60-80, voicepuppet/bfmnet/tinynet.py:7-212, bfmnet.py:20-122.
 #include "audio_args.h"
+#include "gru_device.h"
 #include "vp_common.h"
 
 namespace vp {
@@ -210,47 +211,15 @@ __global__ __launch_bounds__(256) void fold_bn_kernel(const float* __restrict__ 
   }
 }
 
-// tf.contrib.rnn.GRUCell over T steps (dynamic_rnn semantics), one block per sequence, H = 256 = blockDim.
-//   xg [B,T,2H] = x.Wg[:H] + bg,  xc [B,T,H] = x.Wc[:H] + bc  (precomputed GEMMs);  whg [H][2H], whc [H][H]
-__global__ __launch_bounds__(256) void gru_seq_kernel(const float* __restrict__ xg, const float* __restrict__ xc, const float* __restrict__ whg,
-                                                      const float* __restrict__ whc, const int* __restrict__ seq_len, float* __restrict__ out,
-                                                      int T) {
-  constexpr int H = 256;
-  __shared__ float h[H], rh[H];
-  const int b = blockIdx.x, j = threadIdx.x;
-  const int len = seq_len[b];
-  h[j] = 0.f;
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const float* g = xg + ((size_t)b * T + t) * 2 * H;
-    float ar = g[j], au = g[H + j];
-    for (int k = 0; k < H; ++k) {
-      const float hk = h[k];
-      ar = fmaf(hk, whg[(size_t)k * 2 * H + j], ar);
-      au = fmaf(hk, whg[(size_t)k * 2 * H + H + j], au);
-    }
-    const float r = 1.f / (1.f + expf(-ar)), u = 1.f / (1.f + expf(-au));
-    const float hj = h[j];
-    rh[j] = r * hj;
-    __syncthreads();
-    float ac = xc[((size_t)b * T + t) * H + j];
-    for (int k = 0; k < H; ++k) ac = fmaf(rh[k], whc[(size_t)k * H + j], ac);
-    const float hn = u * hj + (1.f - u) * tanhf(ac);
-    const bool live = t < len;
-    out[((size_t)b * T + t) * H + j] = live ? hn : 0.f;
-    __syncthreads();
-    h[j] = live ? hn : hj;
-    __syncthreads();
-  }
-}
+// tf.contrib.rnn.GRUCell over T steps (dynamic_rnn semantics): gru_device.h (gru_fwd_kernel<false>), one 1024-thread block per sequence
 
-// out[b,t,16:20] += ears[b,t] * {-2,-2,-2,-4}     (bfmnet.py:117,209)
 // x *= m, element-wise (the opt-in decoder dropout masks of BFMNet inference: 0 or 1 / keep_prob)
 __global__ void mul_inplace_kernel(float* __restrict__ x, const float* __restrict__ m, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= m[i];
 }
 
+// out[b,t,16:20] += ears[b,t] * {-2,-2,-2,-4}     (bfmnet.py:117,209)
 __global__ void add_ears_kernel(float* __restrict__ out, const float* __restrict__ ears, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -310,7 +279,8 @@ hipError_t launch_fold_bn(const float* w, const float* beta, const float* mean, 
   return hipGetLastError();
 }
 hipError_t launch_gru_seq(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, int B, int T, hipStream_t st) {
-  hipLaunchKernelGGL(gru_seq_kernel, dim3(B), dim3(256), 0, st, xg, xc, whg, whc, seq_len, out, T);
+  hipLaunchKernelGGL(gru_fwd_kernel<false>, dim3(B), dim3(1024), 0, st, xg, xc, whg, whc, seq_len, out, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, T);
   return hipGetLastError();
 }
 hipError_t launch_mul_inplace(float* x, const float* m, size_t n, hipStream_t st) {

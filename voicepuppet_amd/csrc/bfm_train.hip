@@ -11,6 +11,7 @@
 
 #include "audio_args.h"
 #include "errors.h"
+#include "gru_device.h"
 #include "vp_common.h"
 
 namespace vp {
@@ -354,72 +355,10 @@ __global__ __launch_bounds__(256) void im2col_9x5_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// GRU (tf.contrib.rnn.GRUCell under dynamic_rnn, 256 units), training form.  One block per sequence, thread j = unit j.
+// GRU (tf.contrib.rnn.GRUCell under dynamic_rnn, 256 units), training form: gru_device.h (gru_fwd_kernel<true>, gru_bwd_kernel).
 //   forward : saves r, u, c and h_prev per step (what the backward needs); out = h past-the-end zero, state frozen
 //   backward: d_ag [B,T,512] (gate pre-activations), d_ac [B,T,256] (candidate pre-activation) from d_out; the weight / input
 //             gradients are GEMMs over these (train_engine.py)
-// whg [256][512], whc [256][256]: recurrent halves of the kernels (row = h unit)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gru_train_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ xc, const float* __restrict__ whg,
-                                                            const float* __restrict__ whc, const int* __restrict__ seq_len, float* __restrict__ out,
-                                                            float* __restrict__ sr, float* __restrict__ su, float* __restrict__ sc, float* __restrict__ shp,
-                                                            int T) {
-  __shared__ float h[256], rh[256];
-  const int b = blockIdx.x, j = threadIdx.x, n = seq_len[b];
-  h[j] = 0.f;
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const size_t o = (size_t)b * T + t;
-    if (t >= n) { out[o * 256 + j] = 0.f; sr[o * 256 + j] = 0.f; su[o * 256 + j] = 0.f; sc[o * 256 + j] = 0.f; shp[o * 256 + j] = h[j]; continue; }
-    float ar = xg[o * 512 + j], au = xg[o * 512 + 256 + j];
-    for (int k = 0; k < 256; ++k) { const float hk = h[k]; ar = fmaf(hk, whg[(size_t)k * 512 + j], ar); au = fmaf(hk, whg[(size_t)k * 512 + 256 + j], au); }
-    const float r = 1.f / (1.f + expf(-ar)), u = 1.f / (1.f + expf(-au));
-    rh[j] = r * h[j];
-    __syncthreads();
-    float ac = xc[o * 256 + j];
-    for (int k = 0; k < 256; ++k) ac = fmaf(rh[k], whc[(size_t)k * 256 + j], ac);
-    const float c = tanhf(ac);
-    const float hp = h[j];
-    const float hn = u * hp + (1.f - u) * c;
-    sr[o * 256 + j] = r; su[o * 256 + j] = u; sc[o * 256 + j] = c; shp[o * 256 + j] = hp;
-    out[o * 256 + j] = hn;
-    __syncthreads();
-    h[j] = hn;
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(256) void gru_train_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ whg, const float* __restrict__ whc,
-                                                            const int* __restrict__ seq_len, const float* __restrict__ sr, const float* __restrict__ su,
-                                                            const float* __restrict__ sc, const float* __restrict__ shp, float* __restrict__ dag,
-                                                            float* __restrict__ dac, int T) {
-  __shared__ float s_dag[512], s_dac[256];
-  const int b = blockIdx.x, j = threadIdx.x, n = seq_len[b];
-  float dh = 0.f;                                    // d loss / d h_t carried backwards (unit j)
-  for (int t = T - 1; t >= 0; --t) {
-    const size_t o = (size_t)b * T + t;
-    if (t >= n) { dag[o * 512 + j] = 0.f; dag[o * 512 + 256 + j] = 0.f; dac[o * 256 + j] = 0.f; continue; }   // frozen state: dh passes through
-    const float r = sr[o * 256 + j], u = su[o * 256 + j], c = sc[o * 256 + j], hp = shp[o * 256 + j];
-    const float g = dout[o * 256 + j] + dh;
-    const float d_u = g * (hp - c), d_c = g * (1.f - u);
-    float dhp = g * u;
-    const float d_ac = d_c * (1.f - c * c);
-    s_dac[j] = d_ac;
-    __syncthreads();
-    float d_rh = 0.f;                                // d / d (r * h_prev)[j] = sum_m whc[j][m] * d_ac[m]
-    for (int m = 0; m < 256; ++m) d_rh = fmaf(whc[(size_t)j * 256 + m], s_dac[m], d_rh);
-    const float d_r = d_rh * hp;
-    dhp = fmaf(d_rh, r, dhp);
-    const float d_ar = d_r * r * (1.f - r), d_au = d_u * u * (1.f - u);
-    s_dag[j] = d_ar; s_dag[256 + j] = d_au;
-    __syncthreads();
-    for (int m = 0; m < 512; ++m) dhp = fmaf(whg[(size_t)j * 512 + m], s_dag[m], dhp);
-    dag[o * 512 + j] = d_ar; dag[o * 512 + 256 + j] = d_au; dac[o * 256 + j] = d_ac;
-    dh = dhp;
-    __syncthreads();
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // vertex-space loss (bfmnet.py:215-262) on D[b,t,j] = face_shape(true) - face_shape(pred) (a GEMM of the expression difference):
 //   loss = (1/B) sum_b [ sum_t fm[b,t] sum_j |D[b,t,j]| vm[j]  +  sum_{t<T-1} vd[b,t] sum_j |D[b,t+1,j] - D[b,t,j]| vm[j] ]
@@ -659,15 +598,15 @@ int vp_stem_im2col(const float* x, float* col, int b, int h, int w, void* stream
 int vp_gru_train_fwd(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, float* r, float* u, float* c,
                      float* hprev, int b, int t, void* stream) {
   if (!xg || !xc || !whg || !whc || !seq_len || !out || !r || !u || !c || !hprev || b < 1 || t < 1) { set_err("vp_gru_train_fwd: bad argument"); return VP_ERR_ARG; }
-  hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, xg, xc, whg, whc, seq_len, out, r, u, c, hprev, t);
+  hipLaunchKernelGGL(gru_fwd_kernel<true>, dim3(b), dim3(1024), 0, (hipStream_t)stream, xg, xc, whg, whc, seq_len, out, r, u, c, hprev, t);
   VP_HIP_CHECK(hipGetLastError());
   return VP_OK;
 }
 
-int vp_gru_train_bwd(const float* dout, const float* whg, const float* whc, const int* seq_len, const float* r, const float* u, const float* c,
+int vp_gru_train_bwd(const float* dout, const float* whg_t, const float* whc_t, const int* seq_len, const float* r, const float* u, const float* c,
                      const float* hprev, float* dag, float* dac, int b, int t, void* stream) {
-  if (!dout || !whg || !whc || !seq_len || !r || !u || !c || !hprev || !dag || !dac || b < 1 || t < 1) { set_err("vp_gru_train_bwd: bad argument"); return VP_ERR_ARG; }
-  hipLaunchKernelGGL(gru_train_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, dout, whg, whc, seq_len, r, u, c, hprev, dag, dac, t);
+  if (!dout || !whg_t || !whc_t || !seq_len || !r || !u || !c || !hprev || !dag || !dac || b < 1 || t < 1) { set_err("vp_gru_train_bwd: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, dout, whg_t, whc_t, seq_len, r, u, c, hprev, dag, dac, t);
   VP_HIP_CHECK(hipGetLastError());
   return VP_OK;
 }
