@@ -358,8 +358,13 @@ int vp_bn_train_bwd(const float* x, const float* dz, size_t pixels, int c, const
 int vp_bn_act_train_bwd(const float* x, const float* da, size_t pixels, int c, const float* mean, const float* rstd, const float* shift, int act,
                         float* dx, float* dbeta, void* workspace, void* stream);
 int vp_affine_act_fwd(const float* x, const float* scale, const float* shift, const float* mask, size_t pixels, int c, int act, float* y, void* stream);
+/* the same pass + the residual branch: y = act(scale * x + shift) * mask + add */
+int vp_affine_act_add_fwd(const float* x, const float* scale, const float* shift, const float* mask, const float* add, size_t pixels, int c, int act,
+                          float* y, void* stream);
 int vp_act_bwd(const float* dy, const float* ya, const float* mask, size_t n, int act, float* dx, void* stream);
 int vp_dwconv7x3_raw(const float* x, const float* w, float* y, int b, int h, int wd, int c, void* stream);
+/* backward-data of vp_dwconv7x3_raw: dy convolved with the taps of w reversed (no flipped copy of w is needed) */
+int vp_dwconv7x3_bwd_data(const float* dy, const float* w, float* dx, int b, int h, int wd, int c, void* stream);
 size_t vp_dwconv7x3_wgrad_workspace_bytes(int b, int h, int wd, int c);
 int vp_dwconv7x3_wgrad(const float* x, const float* dy, float* dw, int b, int h, int wd, int c, void* workspace, void* stream);
 int vp_maxpool_hw_bwd(const float* x, const float* dy, float* dx, int b, int h, int w, int c, int kh, int kw, int sh, int sw, void* stream);

@@ -130,8 +130,10 @@ _SIGNATURES = {
     "vp_bn_train_fwd": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.c_int, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "vp_bn_train_bwd": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
     "vp_affine_act_fwd": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_affine_act_add_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P, _P]),
     "vp_act_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_int, _P, _P]),
     "vp_dwconv7x3_raw": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "vp_dwconv7x3_bwd_data": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "vp_dwconv7x3_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "vp_bn_act_train_bwd": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int, _P, _P, _P, ctypes.c_int, _P, _P, _P, _P]),
     "vp_l2_regulariser": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_float, _P, _P]),

@@ -163,10 +163,14 @@ class BFMNetTrainEngine:
                                           _ptr(self.g[scope + "/BatchNorm/beta"]), _ptr(ws), _stream()), "vp_bn_act_train_bwd")
     return dx
 
-  def _act(self, x, scale, shift, act, mask=None):
+  def _act(self, x, scale, shift, act, mask=None, add=None):
+    """act(scale * x + shift) * mask (+ add: the residual branch of a block, fused into the same pass)"""
     P, C = x.shape
     y = torch.empty_like(x)
-    _lib.check(self.L.vp_affine_act_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(mask), P, C, act, _ptr(y), _stream()), "vp_affine_act_fwd")
+    if add is not None:
+      _lib.check(self.L.vp_affine_act_add_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(mask), _ptr(add), P, C, act, _ptr(y), _stream()), "vp_affine_act_add_fwd")
+    else:
+      _lib.check(self.L.vp_affine_act_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(mask), P, C, act, _ptr(y), _stream()), "vp_affine_act_fwd")
     return y
 
   def _act_bwd(self, dy, ya, act, mask=None):
@@ -174,10 +178,12 @@ class BFMNetTrainEngine:
     _lib.check(self.L.vp_act_bwd(_ptr(dy), _ptr(ya), _ptr(mask), dy.numel(), act, _ptr(dx), _stream()), "vp_act_bwd")
     return dx
 
-  def _dw(self, x2d, w21, H, W):
+  def _dw(self, x2d, w21, H, W, backward=False):
+    """depthwise 7x3; backward=True: the data gradient (the same taps walked in reverse)"""
     C = x2d.shape[1]
     y = torch.empty_like(x2d)
-    _lib.check(self.L.vp_dwconv7x3_raw(_ptr(x2d), _ptr(w21), _ptr(y), self.B, H, W, C, _stream()), "vp_dwconv7x3_raw")
+    fn = self.L.vp_dwconv7x3_bwd_data if backward else self.L.vp_dwconv7x3_raw
+    _lib.check(fn(_ptr(x2d), _ptr(w21), _ptr(y), self.B, H, W, C, _stream()), "vp_dwconv7x3")
     return y
 
   def _dw_wgrad(self, x2d, dy2d, H, W, out):
@@ -333,11 +339,11 @@ class BFMNetTrainEngine:
     return part.sum()
 
   # ---- conv + batch-norm + activation, forward / backward -----------------------------------------------------------------------
-  def _cba_fwd(self, x, kernel, bn_scope, act, tape):
-    """x [P, cin] . kernel [cin, cout] -> batch_norm -> act.  tape gets what the backward needs."""
+  def _cba_fwd(self, x, kernel, bn_scope, act, tape, add=None):
+    """x [P, cin] . kernel [cin, cout] -> batch_norm -> act (+ add).  tape gets what the backward needs."""
     y = self._mm(x, kernel)
     mean, rstd, shift = self._bn_fwd(y, bn_scope)
-    a = self._act(y, rstd, shift, act)
+    a = self._act(y, rstd, shift, act, add=add)
     tape.append(("cba", x, kernel, y, mean, rstd, shift, act, bn_scope))
     return a
 
@@ -447,14 +453,16 @@ class BFMNetTrainEngine:
       mean, rstd, shift = self._bn_fwd(yd, b + "/depthwise_conv2d")
       ad = self._act(yd, rstd, shift, ACT_RELU6)
       tape.append(("dw", a, wd, yd, mean, rstd, shift, b, H, W))
-      out = self._cba_fwd(ad, p[b + "/projection_1x1_conv2d/conv2d/kernel"].reshape(cin * exp, cout), b + "/projection_1x1_conv2d", ACT_NONE, tape)
+      # the block's sum out + shortcut rides on the last normalisation pass (the shortcut conv of a widening block runs after the
+      # projection conv: the reference's creation order of the variables, and the order the tape is unwound in)
+      pk, ps = p[b + "/projection_1x1_conv2d/conv2d/kernel"].reshape(cin * exp, cout), b + "/projection_1x1_conv2d"
       if cout != cin:
-        sc = self._cba_fwd(inp, p[b + "/1x1_conv2d/conv2d/kernel"].reshape(cin, cout), b + "/1x1_conv2d", ACT_NONE, tape)
+        out = self._cba_fwd(ad, pk, ps, ACT_NONE, tape)
+        net = self._cba_fwd(inp, p[b + "/1x1_conv2d/conv2d/kernel"].reshape(cin, cout), b + "/1x1_conv2d", ACT_NONE, tape, add=out)
         tape.append(("add_sc",))
-        net = out + sc
       else:
+        net = self._cba_fwd(ad, pk, ps, ACT_NONE, tape, add=inp)
         tape.append(("add_id",))
-        net = out + inp
       if pool:
         pooled, Ho, Wn = self._pool(net, H, W, (2, 2), (1, 2))
         tape.append(("pool", net, H, W, (2, 2), (1, 2)))
@@ -524,8 +532,8 @@ class BFMNetTrainEngine:
     d = dense_bwd(d)
     d = dense_bwd(d)                                                                 # d loss / d enc_in  [B*T, 256]
 
-    def cba_bwd(da, wgrad=True):
-      """-> d loss / d x (None for the stem)"""
+    def cba_bwd(da, into=None):
+      """-> d loss / d x (None for the stem); into: a gradient of the same tensor the result is ADDED to, in place (the shortcut's)"""
       _, x, kernel, y, mean, rstd, shift, act, scope = tape.pop()
       dy = self._bn_act_bwd(da, y, mean, rstd, shift, act, scope)
       if x.shape[1] == 48:                                                           # stem: no input gradient
@@ -533,6 +541,8 @@ class BFMNetTrainEngine:
         return None
       gk = self._grad2d(kernel)
       self._fork(lambda: self._mm_dw(x, dy, gk), x, dy)
+      if into is not None:
+        return self._mm_dx(dy, kernel, out=into, accumulate=True)
       return self._mm_dx(dy, kernel)
     while tape:
       kind = tape[-1][0]
@@ -549,9 +559,8 @@ class BFMNetTrainEngine:
         dyd = self._bn_act_bwd(dad, yd, mean, rstd, shift, ACT_RELU6, b + "/depthwise_conv2d")
         gdw = g[b + "/depthwise_conv2d/SeparableConv2d/depthwise_weights"]
         self._fork(lambda a_in=a_in, dyd=dyd, h_=h_, w_=w_, gdw=gdw: self._dw_wgrad(a_in, dyd, h_, w_, gdw), a_in, dyd)
-        da = self._dw(dyd, wd.flip(0).contiguous(), h_, w_)
-        d = cba_bwd(da)                                                              # expansion conv
-        d.add_(dsc)
+        da = self._dw(dyd, wd, h_, w_, backward=True)
+        d = cba_bwd(da, into=dsc)                                                    # expansion conv, added to the shortcut's gradient
       elif kind == "cba":                                                            # block8_0 (1x1) or the stem
         d = cba_bwd(d)
       else:

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv7x3_kernel(const T* __restrict__ x, const float* __restrict__ w /*[21][C]*/,
                                                         const float* __restrict__ bias, T* __restrict__ y, int B, int H, int W, int C, int HS,
-                                                        int nseg) {
+                                                        int nseg, int rev) {
   constexpr int PF = 3;
   const int cq = C >> 2;
   const size_t total = (size_t)B * nseg * W * cq;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void dwconv7x3_kernel(const T* __restrict__ x,
     const int hs = h0 + HS <= H ? HS : H - h0;         // output rows of this segment
     float4 wv[21];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (size_t)k * C + c4);
+    for (int k = 0; k < 21; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (size_t)(rev ? 20 - k : k) * C + c4);   // rev: backward-data = the taps reversed
     // bias == nullptr: the raw convolution (training forward / backward-data, bfm_train.hip): no bias, no relu6
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[7];
@@ -249,7 +249,7 @@ hipError_t launch_conv_first(const float* x, const float* w, const float* bias, 
   else hipLaunchKernelGGL((conv_first_kernel<float>), grid, dim3(256), 45 * Cout * sizeof(float), st, x, w, bias, (float*)y, B, H, W, Wo, Cout, pt, pl);
   return hipGetLastError();
 }
-hipError_t launch_dwconv7x3(const void* x, const float* w, const float* bias, void* y, int is_bf16, int B, int H, int W, int C, hipStream_t st) {
+hipError_t launch_dwconv7x3(const void* x, const float* w, const float* bias, void* y, int is_bf16, int B, int H, int W, int C, hipStream_t st, int rev) {
   // row segments per column: enough threads to fill the chip (>= ~128k), at least 8 rows each; a segment of HS rows reads HS + 6
   const size_t cols = (size_t)B * W * (C / 4);
   int nseg = (int)((131072 + cols - 1) / cols);
@@ -259,8 +259,8 @@ hipError_t launch_dwconv7x3(const void* x, const float* w, const float* bias, vo
   const int hs = (H + nseg - 1) / nseg;
   nseg = (H + hs - 1) / hs;
   const dim3 grid(nblk(cols * nseg, 8192));
-  if (is_bf16) hipLaunchKernelGGL((dwconv7x3_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, hs, nseg);
-  else hipLaunchKernelGGL((dwconv7x3_kernel<float>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C, hs, nseg);
+  if (is_bf16) hipLaunchKernelGGL((dwconv7x3_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, hs, nseg, rev);
+  else hipLaunchKernelGGL((dwconv7x3_kernel<float>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C, hs, nseg, rev);
   return hipGetLastError();
 }
 hipError_t launch_maxpool_same(const void* x, void* y, int in_bf16, int out_bf16, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, hipStream_t st) {

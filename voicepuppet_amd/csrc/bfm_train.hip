@@ -178,7 +178,8 @@ __device__ __forceinline__ float act_d(int act, float y) {
 
 // y = act(scale[c] * x + shift[c]) * mask   (scale / shift / mask optional)
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const float* __restrict__ mask, size_t P, int C, int act, float* __restrict__ y) {
+                                                         const float* __restrict__ mask, const float* __restrict__ add, size_t P, int C, int act,
+                                                         float* __restrict__ y) {
   const int cq = C >> 2;
   const size_t total = P * cq;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     }
     v.x = act_f(act, v.x); v.y = act_f(act, v.y); v.z = act_f(act, v.z); v.w = act_f(act, v.w);
     if (mask) { const float4 m = *reinterpret_cast<const float4*>(mask + i * 4); v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
+    if (add) { const float4 r = *reinterpret_cast<const float4*>(add + i * 4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }   // residual branch
     *reinterpret_cast<float4*>(y + i * 4) = v;
   }
 }
@@ -523,7 +525,17 @@ int vp_bn_train_bwd(const float* x, const float* dz, size_t pixels, int c, const
 // y = act(scale[c] * x + shift[c]) * mask   (scale / shift and mask may be null); act: 0 none, 1 leaky-relu(0.2), 2 relu, 5 relu6
 int vp_affine_act_fwd(const float* x, const float* scale, const float* shift, const float* mask, size_t pixels, int c, int act, float* y, void* stream) {
   if (!x || !y || (scale && !shift) || pixels < 1 || c < 4 || c % 4) { set_err("vp_affine_act_fwd: bad argument"); return VP_ERR_ARG; }
-  hipLaunchKernelGGL(affine_act_kernel, dim3(tblk(pixels * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, scale, shift, mask, pixels, c, act, y);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(tblk(pixels * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, scale, shift, mask, (const float*)nullptr, pixels, c,
+                     act, y);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// y = act(scale[c] * x + shift[c]) * mask + add: the same pass with the residual branch of an inverted-residual block added (add [pixels, c])
+int vp_affine_act_add_fwd(const float* x, const float* scale, const float* shift, const float* mask, const float* add, size_t pixels, int c, int act,
+                          float* y, void* stream) {
+  if (!x || !y || !add || (scale && !shift) || pixels < 1 || c < 4 || c % 4) { set_err("vp_affine_act_add_fwd: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(affine_act_kernel, dim3(tblk(pixels * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, scale, shift, mask, add, pixels, c, act, y);
   VP_HIP_CHECK(hipGetLastError());
   return VP_OK;
 }
@@ -540,6 +552,13 @@ int vp_act_bwd(const float* dy, const float* ya, const float* mask, size_t n, in
 int vp_dwconv7x3_raw(const float* x, const float* w, float* y, int b, int h, int wd, int c, void* stream) {
   if (!x || !w || !y || b < 1 || h < 1 || wd < 1 || c < 4 || c % 4) { set_err("vp_dwconv7x3_raw: bad argument"); return VP_ERR_ARG; }
   VP_HIP_CHECK(launch_dwconv7x3(x, w, nullptr, y, 0, b, h, wd, c, (hipStream_t)stream));
+  return VP_OK;
+}
+
+// backward-data of the same convolution: dx = dy convolved with the taps reversed (the kernel indexes them backwards, no flipped copy)
+int vp_dwconv7x3_bwd_data(const float* dy, const float* w, float* dx, int b, int h, int wd, int c, void* stream) {
+  if (!dy || !w || !dx || b < 1 || h < 1 || wd < 1 || c < 4 || c % 4) { set_err("vp_dwconv7x3_bwd_data: bad argument"); return VP_ERR_ARG; }
+  VP_HIP_CHECK(launch_dwconv7x3(dy, w, nullptr, dx, 0, b, h, wd, c, (hipStream_t)stream, 1));
   return VP_OK;
 }
 
