@@ -29,7 +29,11 @@ template <int IMM> __device__ __forceinline__ float lds_rd32(int addr) {
   return r;
 }
 
-template <int TP>
+// TAPS: the k x k form.  Row m of the gradient is (tap, channel); a 16-byte piece (4 channels) lies in one tap, so a DMA lane has ONE
+// tap offset (dh, dw) for the whole launch.  K walks the padded grid [N][2^lh][2^lw] (shifts, no divisions); per stage a lane forms the
+// gathered pixel (q * s + dh, r * s + dw) of its row, out-of-image / out-of-grid rows read zeros.  A tile's channels lie in ONE source
+// tensor of a virtual concat (checked on the host), chosen per block.
+template <int TP, bool TAPS>
 __global__ __launch_bounds__(256) void wgrad_mm_kernel(const WgradArgs a) {
   constexpr int BM = 128, BN = 2 * TP * 16;          // rows (channels of x) x columns (channels of dy) of the tile
   constexpr int TC = 4;                              // 2 x 2 waves of (TC x 16) x (TP x 16)
@@ -44,34 +48,76 @@ __global__ __launch_bounds__(256) void wgrad_mm_kernel(const WgradArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m_base = blockIdx.x * BM, d_base = blockIdx.y * BN, split = blockIdx.z;
   const int P = a.N * a.Hb * a.Wb;
-  const int niter = (P + KP - 1) / KP;
+  const int niter = TAPS ? ((a.N << (a.lw + a.lh)) + KP - 1) / KP : (P + KP - 1) / KP;
   const int per = (niter + a.splitk - 1) / a.splitk;
   const int it0 = split * per, it1 = min(niter, it0 + per);
-  const int ldx = a.g.C[0], ldd = a.d.C[0];          // row pitches in floats (single-source operands)
+  // the source tensor this tile's channels lie in (a virtual concat never straddles a tile: wgrad_mm_eligible)
+  const int tap0 = m_base >> a.log2Gc, chm0 = m_base & a.gc_mask;       // (one tap: log2Gc = 30, tap0 = 0)
+  const int gsrc = (!TAPS || chm0 < a.g.C[0]) ? 0 : 1, dsrc = (!TAPS || d_base < a.d.C[0]) ? 0 : 1;
+  const int ldx = a.g.C[gsrc], ldd = a.d.C[dsrc];     // pixel pitches in floats
+  const int gsub = gsrc ? a.g.C[0] : 0, dsub = dsrc ? a.d.C[0] : 0;
+  (void)tap0;
 
-  __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.g.ptr[0], (unsigned)((size_t)P * ldx * 4));
-  __amdgpu_buffer_rsrc_t rsD = make_rsrc(a.d.ptr[0], (unsigned)((size_t)P * ldd * 4));
-  // DMA lanes: instruction d of an operand covers 1024 / (4 * ROW) pixel rows; lane -> (pixel row of the stage, piece), rotated
+  __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.g.ptr[gsrc], (unsigned)((size_t)a.N * a.Hgin * a.Wgin * ldx * 4));
+  __amdgpu_buffer_rsrc_t rsD = make_rsrc(a.d.ptr[dsrc], (unsigned)((size_t)P * ldd * 4));
+  // DMA lanes: instruction d of an operand covers 1024 / (4 * ROW) pixel rows; lane -> (pixel row of the stage, piece), rotated.
+  // The rotation depends on (row & 3) only and a wave's instructions are 8 (4) rows apart: a lane's piece is the same in all of them.
   unsigned voA[JA], voB[JB];
+  int kkA[JA], kkB[JB];
+  int chA = 0, chB = 0, dhA = 0, dwA = 0;
+  bool okA = false, okB = false;
 #pragma unroll
   for (int j = 0; j < JA; ++j) {
     const int d = wave + 4 * j;
     const int kk = d * (256 / BM) + lane / NPA, i = lane % NPA;
-    const int ch = m_base + 4 * ((i - 4 * (kk & 3)) & (NPA - 1));
-    voA[j] = ch < a.Gc ? (unsigned)((kk * ldx + ch) * 4) : DMA_OOB;
+    const int m = m_base + 4 * ((i - 4 * (kk & 3)) & (NPA - 1));
+    kkA[j] = kk;
+    if (TAPS) {
+      const int tap = m >> a.log2Gc, ch = m & a.gc_mask;
+      okA = tap < a.ntaps && ch < a.Gc;
+      chA = ch - gsub;
+      int tdh = 0, tdw = 0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) if (t == tap) { tdh = a.taps.dh[t]; tdw = a.taps.dw[t]; }
+      dhA = tdh; dwA = tdw;
+      voA[j] = 0;
+    } else {
+      voA[j] = m < a.Gc ? (unsigned)((kk * ldx + m) * 4) : DMA_OOB;
+    }
   }
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
     const int d = wave + 4 * j;
     const int kk = d * (256 / BN) + lane / NPB, i = lane % NPB;
     const int ch = d_base + 4 * ((i - 4 * (kk & 3)) & (NPB - 1));
-    voB[j] = ch < a.Dc ? (unsigned)((kk * ldd + ch) * 4) : DMA_OOB;
+    kkB[j] = kk;
+    if (TAPS) { okB = ch < a.Dc; chB = ch - dsub; voB[j] = 0; }
+    else voB[j] = ch < a.Dc ? (unsigned)((kk * ldd + ch) * 4) : DMA_OOB;
   }
   // (the stage's pixel offset goes into the LANE offset: a raw buffer's range check covers the lane offset only, not the scalar one,
   // and the rows behind pixel P - 1 of the last stage must read zeros; out-of-range lanes are pinned so that the sum cannot wrap)
   auto issue = [&](int it, int stage) {
     uint4* la = reinterpret_cast<uint4*>(smem + stage * STAGE);
     uint4* lb = reinterpret_cast<uint4*>(smem + stage * STAGE + SA);
+    if constexpr (TAPS) {
+      const int mw = (1 << a.lw) - 1, mh = (1 << a.lh) - 1;
+#pragma unroll
+      for (int j = 0; j < JA; ++j) {
+        const int sl = it * KP + kkA[j];
+        const int r = sl & mw, q = (sl >> a.lw) & mh, n = sl >> (a.lw + a.lh);
+        const int ih = q * a.s + dhA, iw = r * a.s + dwA;
+        const bool ok = okA && r < a.Wb && q < a.Hb && n < a.N && (unsigned)ih < (unsigned)a.Hgin && (unsigned)iw < (unsigned)a.Wgin;
+        dma16_buf(rsX, ok ? (unsigned)((((n * a.Hgin + ih) * a.Wgin + iw) * ldx + chA) * 4) : 0xFFFFFFF0u, 0, la + (wave + 4 * j) * 64);
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const int sl = it * KP + kkB[j];
+        const int r = sl & mw, q = (sl >> a.lw) & mh, n = sl >> (a.lw + a.lh);
+        const bool ok = okB && r < a.Wb && q < a.Hb && n < a.N;
+        dma16_buf(rsD, ok ? (unsigned)((((n * a.Hb + q) * a.Wb + r) * ldd + chB) * 4) : 0xFFFFFFF0u, 0, lb + (wave + 4 * j) * 64);
+      }
+      return;
+    }
     const unsigned sx = (unsigned)it * (unsigned)(KP * 4) * (unsigned)ldx, sd = (unsigned)it * (unsigned)(KP * 4) * (unsigned)ldd;
 #pragma unroll
     for (int j = 0; j < JA; ++j) dma16_buf(rsX, voA[j] == DMA_OOB ? 0xFFFFFFF0u : voA[j] + sx, 0, la + (wave + 4 * j) * 64);
@@ -147,9 +193,9 @@ __global__ __launch_bounds__(256) void wgrad_mm_kernel(const WgradArgs a) {
         if (d >= a.Dreal) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int m = m0 + e;
-          if (m < a.Greal) {
-            float* o = a.dW + (size_t)m * a.Dreal + d;
+          const int m = m0 + e, tap = m >> a.log2Gc, gc = m & a.gc_mask;       // (one tap: tap = 0, gc = m)
+          if (tap < a.ntaps && gc < a.Greal) {
+            float* o = a.dW + ((size_t)tap * a.Greal + gc) * a.Dreal + d;
             *o = acc[tc][tp][e] + (a.accumulate ? *o : 0.f);
           }
         }
@@ -170,27 +216,42 @@ __global__ __launch_bounds__(256) void wgrad_mm_kernel(const WgradArgs a) {
 
 }  // namespace
 
-// one tap, stride 1, float32, prologue-free single-source operands whose pitches are multiples of 4 floats, tensors below 4 GiB
+// float32, prologue-free operands whose channel counts are multiples of 4, tensors below 4 GiB.  One tap, stride 1: the plain form.
+// k x k taps (or a strided one-tap layer): the gathering form, if no tile of either operand straddles a virtual concat.
+static bool mm_common(const WgradArgs& a, int cfg) {
+  if ((cfg != 0 && cfg != 1) || a.g.aff_a[0] || a.g.aff_a[1] || a.d.aff_a[0] || a.d.aff_a[1] || a.g.act != ACT_NONE || a.d.act != ACT_NONE) return false;
+  if ((a.g.C[0] & 3) || (a.g.C[1] & 3) || (a.d.C[0] & 3) || (a.d.C[1] & 3) || a.Mpad % 128 || a.Dpad % (cfg == 0 ? 128 : 64)) return false;
+  const unsigned long long pg = (unsigned long long)a.N * a.Hgin * a.Wgin, pd = (unsigned long long)a.N * a.Hb * a.Wb;
+  const unsigned long long cg = a.g.C[0] > a.g.C[1] ? a.g.C[0] : a.g.C[1], cd = a.d.C[0] > a.d.C[1] ? a.d.C[0] : a.d.C[1];
+  return pg * cg * 4 < 0xF0000000ull && pd * cd * 4 < 0xF0000000ull;
+}
+static bool mm_plain(const WgradArgs& a) {
+  return a.ntaps == 1 && a.s == 1 && a.taps.dh[0] == 0 && a.taps.dw[0] == 0 && !a.g.C[1] && !a.d.C[1] && a.Hgin == a.Hb && a.Wgin == a.Wb;
+}
 bool wgrad_mm_eligible(const WgradArgs& a, int cfg) {
-  static const bool on = !getenv("VP_NO_WGRAD_MM");
-  if (!on || a.ntaps != 1 || a.s != 1 || a.taps.dh[0] != 0 || a.taps.dw[0] != 0 || (cfg != 0 && cfg != 1)) return false;
-  if (a.g.C[1] || a.d.C[1] || a.g.aff_a[0] || a.d.aff_a[0] || a.g.act != ACT_NONE || a.d.act != ACT_NONE) return false;
-  if (a.Hgin != a.Hb || a.Wgin != a.Wb || (a.g.C[0] & 3) || (a.d.C[0] & 3) || a.Mpad % 128 || a.Dpad % (cfg == 0 ? 128 : 64)) return false;
-  const unsigned long long P = (unsigned long long)a.N * a.Hb * a.Wb;
-  return P * a.g.C[0] * 4 < 0xF0000000ull && P * a.d.C[0] * 4 < 0xF0000000ull;
+  static const int on = getenv("VP_WGRAD_MM") ? atoi(getenv("VP_WGRAD_MM")) : 3;      // bit 0: one-tap products, bit 1: convolutions with taps
+  if (!mm_common(a, cfg)) return false;
+  if (mm_plain(a)) return (on & 1) != 0;
+  if (!(on & 2)) return false;
+  const int bn = cfg == 0 ? 128 : 64;
+  // a 16-byte piece inside one tap, a 128-row tile inside one source: Gc a multiple of 4; with two sources the boundary on a tile edge
+  if (a.ntaps > 1 && (a.Gc & (a.Gc - 1))) return false;            // rows decode as (m >> log2Gc, m & gc_mask)
+  if (a.g.C[1] && (a.g.C[0] % 128 || a.Gc < 128)) return false;
+  if (a.d.C[1] && a.d.C[0] % bn) return false;
+  if (a.Gc < 128 && 128 % a.Gc) return false;
+  return ((long long)a.N << (a.lw + a.lh)) < (1ll << 30);
 }
 
 hipError_t launch_wgrad_mm(const WgradArgs& a, int cfg, hipStream_t st) {
   const int bn = cfg == 0 ? 128 : 64;
   dim3 grid(a.Mpad / 128, a.Dpad / bn, a.splitk);
   const size_t smem = 4 * (size_t)(16 * 128 * 4 + 16 * bn * 4);
-  if (cfg == 0) {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)wgrad_mm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
-    hipLaunchKernelGGL(wgrad_mm_kernel<4>, grid, dim3(256), smem, st, a);
-  } else {
-    hipLaunchKernelGGL(wgrad_mm_kernel<2>, grid, dim3(256), smem, st, a);
-  }
+  const bool taps = !mm_plain(a);
+  auto k = cfg == 0 ? (taps ? wgrad_mm_kernel<4, true> : wgrad_mm_kernel<4, false>) : (taps ? wgrad_mm_kernel<2, true> : wgrad_mm_kernel<2, false>);
+  static bool attr_done[4] = {false, false, false, false};
+  const int vi = (cfg == 0 ? 0 : 2) + (taps ? 1 : 0);
+  if (!attr_done[vi]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_done[vi] = true; }
+  hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);
   return hipGetLastError();
 }
 
