@@ -151,32 +151,33 @@ __global__ __launch_bounds__(256) void wgrad_mm_kernel(const WgradArgs a) {
       asm volatile("" ::: "memory");
       if (it + NST - 1 < it1) issue(it + NST - 1, st == 0 ? NST - 1 : st - 1);
       const int sb = st * STAGE;
-      // 4 k-steps of 4 pixels: row offset j * 4 rows as an immediate (A rows are 4 * BM bytes, B rows 4 * BN)
+      // 4 k-steps of 4 pixels (row offset j * 4 rows as an immediate: A rows are 4 * BM bytes, B rows 4 * BN).  All fragment reads are
+      // issued k-step by k-step, then every k-step waits only for ITS reads (LDS returns in order): the reads of the later steps land
+      // under the MFMAs of the earlier ones
       float fa[4][TC], fb[4][TP];
+      int ada[TC], adb[TP];
 #pragma unroll
-      for (int t = 0; t < TC; ++t) {
-        const int ad = adA[t] + sb;
-        fa[0][t] = lds_rd32<0>(ad); fa[1][t] = lds_rd32<4 * BM * 4>(ad); fa[2][t] = lds_rd32<8 * BM * 4>(ad); fa[3][t] = lds_rd32<12 * BM * 4>(ad);
-      }
+      for (int t = 0; t < TC; ++t) ada[t] = adA[t] + sb;
 #pragma unroll
-      for (int t = 0; t < TP; ++t) {
-        const int ad = adB[t] + sb;
-        fb[0][t] = lds_rd32<0>(ad); fb[1][t] = lds_rd32<4 * BN * 4>(ad); fb[2][t] = lds_rd32<8 * BN * 4>(ad); fb[3][t] = lds_rd32<12 * BN * 4>(ad);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < TC; ++t) asm volatile("" : "+v"(fa[j][t]));
-#pragma unroll
-        for (int t = 0; t < TP; ++t) asm volatile("" : "+v"(fb[j][t]));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-          for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][tc], fb[j][tp], acc[tc][tp], 0, 0, 0);
+      for (int t = 0; t < TP; ++t) adb[t] = adB[t] + sb;
+#define VP_RD_STEP(J)                                                                     \
+      _Pragma("unroll") for (int t = 0; t < TC; ++t) fa[J][t] = lds_rd32<J * 4 * BM * 4>(ada[t]); \
+      _Pragma("unroll") for (int t = 0; t < TP; ++t) fb[J][t] = lds_rd32<J * 4 * BN * 4>(adb[t]);
+#define VP_MMA_STEP(J, W)                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(W) : "memory");                             \
+      _Pragma("unroll") for (int t = 0; t < TC; ++t) asm volatile("" : "+v"(fa[J][t]));      \
+      _Pragma("unroll") for (int t = 0; t < TP; ++t) asm volatile("" : "+v"(fb[J][t]));      \
+      _Pragma("unroll") for (int tc = 0; tc < TC; ++tc)                                      \
+        _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)                                    \
+          acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[J][tc], fb[J][tp], acc[tc][tp], 0, 0, 0);
+      // (the 4-bit lgkmcnt holds 15: the reads run one k-step ahead of the MFMAs, at most two k-steps outstanding)
+      VP_RD_STEP(0) VP_RD_STEP(1)
+      VP_MMA_STEP(0, TC + TP) VP_RD_STEP(2)
+      VP_MMA_STEP(1, TC + TP) VP_RD_STEP(3)
+      VP_MMA_STEP(2, TC + TP)
+      VP_MMA_STEP(3, 0)
+#undef VP_MMA_STEP
+#undef VP_RD_STEP
       st = st == NST - 1 ? 0 : st + 1;
     }
   }
