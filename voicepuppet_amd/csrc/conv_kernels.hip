@@ -2049,7 +2049,7 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
   ProfScope prof("wgrad", sizeof(T) == 2, pbm, pbn, 2.0 * Pn * a.ntaps * a.Greal * a.Dreal,
                  sizeof(T) * ((double)a.N * a.Hgin * a.Wgin * a.Greal + Pn * a.Dreal) + 4.0 * a.ntaps * a.Greal * a.Dreal, st);
   if (sizeof(T) == 4 && wgrad_mm_eligible(a, cfg)) {               // one-tap float32 products: transpose-free LDS-DMA kernel (wgrad_mm.hip)
-    g_prof_family = "wgrad_mm";
+    g_prof_family = "mm";
     e = launch_wgrad_mm(a, cfg, st);
   } else
   switch (cfg) {
