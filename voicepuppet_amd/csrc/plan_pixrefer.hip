@@ -1333,6 +1333,11 @@ int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream) {
   return VP_OK;
 }
 
+// The executor's low-priority side stream (the discriminator-loss pass and the fused optimiser run there), for a data-parallel host that
+// wants to issue its collectives on it instead of creating one more stream: the GPU exposes a handful of hardware queues, and every
+// extra stream beyond them shares one with another stream (false serialisation).  NULL when the plan does not overlap.
+void* vp_pixrefer_side_stream(vp_pixrefer_t* h) { return (h && h->overlap) ? (void*)h->side : nullptr; }
+
 int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d_join: needs a training plan"); return VP_ERR_STATE; }
   if (h->forked && h->dfork_pending) {   // (no stage 0 ran since the fork: start the pass now)

@@ -206,7 +206,10 @@ class PixReferEngine:
       from .parallel import GradExchange
       ex = self._exchange
       if ex is None or ex.group is not group or ex.transport != self.grad_transport:
-        ex = self._exchange = GradExchange(group, self.grad_transport)
+        # the collectives go to the executor's side stream (behind the discriminator-loss pass, where the single-GPU schedule runs its
+        # optimiser): one stream fewer competing for the device's hardware queues.  VP_DP_OWN_STREAM=1: a stream of the exchange's own
+        sp = None if os.environ.get("VP_DP_OWN_STREAM") else self.L.vp_pixrefer_side_stream(self.h)
+        ex = self._exchange = GradExchange(group, self.grad_transport, torch.cuda.ExternalStream(sp) if sp else None)
       self.t_d += 1
       self.t_g += 1
       (m_g, v_g), (m_d, v_d) = self.adam["g"], self.adam["d"]

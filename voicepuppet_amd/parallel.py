@@ -59,13 +59,14 @@ class GradExchange(object):
   communication buffer (vp_grad_pack_bf16), summed as bf16, and written back as f32 times 1 / world (vp_grad_unpack_bf16): half
   the bytes on xGMI, one bf16 rounding per element and rank; the f32 arena, Adam state and parameters stay f32."""
 
-  def __init__(self, group, transport="f32"):
+  def __init__(self, group, transport="f32", stream=None):
+    """stream: a torch stream to issue the collectives on (the executor's side stream, engine.py); default: a stream of its own"""
     if transport not in ("f32", "bf16"):
       raise ValueError("gradient transport must be 'f32' or 'bf16', got %r" % (transport,))
     self.group, self.transport = group, transport
     self.world = dist.get_world_size(group)
     self.backend = dist.get_backend(group)
-    self.stream = torch.cuda.Stream()
+    self.stream = stream if stream is not None else torch.cuda.Stream()
     self.buffers = {}
 
   def _buffer(self, t):
