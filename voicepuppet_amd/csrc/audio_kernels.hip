@@ -3,6 +3,8 @@
 // The GEMM-shaped parts (DFT as a 512x514 matrix product, every 1x1 conv and dense layer) run on the
 // f32-MFMA implicit-GEMM kernel of conv_kernels.hip.
 // Reference: generator/generator.py:60-80, voicepuppet/bfmnet/tinynet.py:7-212, bfmnet.py:20-122.
+#include <stdlib.h>
+
 #include "audio_args.h"
 #include "gru_device.h"
 #include "vp_common.h"
@@ -166,6 +168,85 @@ __global__ __launch_bounds__(256) void dwconv7x3_kernel(const T* __restrict__ x,
   }
 }
 
+// float32 form: a thread owns TWO adjacent output columns x TWO channels.  The float4 kernel above is latency-bound at 247 registers
+// (two waves per SIMD) and loads every input element three times (left / centre / right column of three different threads); here the
+// four input columns of a column pair serve two outputs (2x instead of 3x) and 2-channel vectors halve the register file per thread
+// (four waves per SIMD): about twice the algorithmic bytes in flight per CU.  Lanes are consecutive channel pairs: 512-byte rows.
+__global__ __launch_bounds__(256) void dwconv7x3_f32_kernel(const float* __restrict__ x, const float* __restrict__ w /*[21][C]*/,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W, int C, int HS,
+                                                            int nseg, int rev) {
+  constexpr int PF = 3;
+  const int c2n = C >> 1, WP = (W + 1) >> 1;
+  const size_t total = (size_t)B * nseg * WP * c2n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % c2n) * 2;
+    size_t t = i / c2n;
+    const int ow = (int)(t % WP) * 2; t /= WP;
+    const int h0 = (int)(t % nseg) * HS;
+    const int b = (int)(t / nseg);
+    const int hs = h0 + HS <= H ? HS : H - h0;         // output rows of this segment
+    float2 wv[21];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) wv[k] = *reinterpret_cast<const float2*>(w + (size_t)(rev ? 20 - k : k) * C + c);
+    const float2 bv = bias ? *reinterpret_cast<const float2*>(bias + c) : make_float2(0.f, 0.f);
+    float2 acc0[7], acc1[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) { acc0[r] = bv; acc1[r] = bv; }
+    const bool okl = ow > 0, ok1 = ow + 1 < W, okr = ow + 2 < W;
+    const float* xb = x + ((size_t)b * H) * W * C + c;
+    float* yb = y + (((size_t)b * H + h0) * W + ow) * C + c;
+    const size_t o0 = (size_t)(okl ? ow - 1 : ow) * C, o1 = (size_t)ow * C, o2 = (size_t)(ok1 ? ow + 1 : ow) * C, o3 = (size_t)(okr ? ow + 2 : ow) * C;
+    const size_t rowstride = (size_t)W * C;
+    float2 ring[7][4];
+    auto loadrow = [&](int rel, float2 (&r)[4]) {      // input row h0 - 3 + rel (clamped: the mask below zeroes what lies outside)
+      int ih = h0 - 3 + rel;
+      ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+      const float* rp = xb + (size_t)ih * rowstride;
+      r[0] = *reinterpret_cast<const float2*>(rp + o0); r[1] = *reinterpret_cast<const float2*>(rp + o1);
+      r[2] = *reinterpret_cast<const float2*>(rp + o2); r[3] = *reinterpret_cast<const float2*>(rp + o3);
+    };
+#pragma unroll
+    for (int j = 0; j < PF; ++j) loadrow(j, ring[j]);
+    const int nrows = hs + 6;
+    for (int k7 = 0; k7 < nrows; k7 += 7) {
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int rel = k7 + u;
+        loadrow(rel + PF, ring[(u + PF) % 7]);
+        const int ih = h0 - 3 + rel;
+        const bool okh = (unsigned)ih < (unsigned)H;
+        const float m[4] = {(okh && okl) ? 1.f : 0.f, okh ? 1.f : 0.f, (okh && ok1) ? 1.f : 0.f, (okh && okr) ? 1.f : 0.f};
+        float2 xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xv[k] = ring[u][k]; xv[k].x *= m[k]; xv[k].y *= m[k]; }
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {               // output q = rel - kh lives in slot (u - kh) mod 7
+          float2& a0 = acc0[(u - kh + 7) % 7];
+          float2& a1 = acc1[(u - kh + 7) % 7];
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float2 ww = wv[kh * 3 + kw];
+            a0.x = fmaf(xv[kw].x, ww.x, a0.x); a0.y = fmaf(xv[kw].y, ww.y, a0.y);
+            a1.x = fmaf(xv[kw + 1].x, ww.x, a1.x); a1.y = fmaf(xv[kw + 1].y, ww.y, a1.y);
+          }
+        }
+        // output q = rel - 6 is complete (slot (u + 1) mod 7): store it and restart the slot
+        const int q = rel - 6;
+        float2 a0 = acc0[(u + 1) % 7], a1 = acc1[(u + 1) % 7];
+        acc0[(u + 1) % 7] = bv; acc1[(u + 1) % 7] = bv;
+        if (q >= 0 && q < hs) {
+          if (bias) {
+            a0.x = fminf(fmaxf(a0.x, 0.f), 6.f); a0.y = fminf(fmaxf(a0.y, 0.f), 6.f);
+            a1.x = fminf(fmaxf(a1.x, 0.f), 6.f); a1.y = fminf(fmaxf(a1.y, 0.f), 6.f);
+          }
+          *reinterpret_cast<float2*>(yb + (size_t)q * rowstride) = a0;
+          if (ok1) *reinterpret_cast<float2*>(yb + (size_t)q * rowstride + C) = a1;
+        }
+      }
+    }
+  }
+}
+
 // max-pool kxk, stride s, TF 'SAME' (padding never wins), 4 channels per thread
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void maxpool_same_kernel(const TI* __restrict__ x, TO* __restrict__ y, int B, int H, int W, int C,
@@ -259,8 +340,13 @@ hipError_t launch_dwconv7x3(const void* x, const float* w, const float* bias, vo
   const int hs = (H + nseg - 1) / nseg;
   nseg = (H + hs - 1) / hs;
   const dim3 grid(nblk(cols * nseg, 8192));
+  static const bool f32x2 = !getenv("VP_DW_F32X4");
   if (is_bf16) hipLaunchKernelGGL((dwconv7x3_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, hs, nseg, rev);
-  else hipLaunchKernelGGL((dwconv7x3_kernel<float>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C, hs, nseg, rev);
+  else if (f32x2) {
+    // column pairs x channel pairs: as many threads as the float4 form has for even W
+    const size_t th = (size_t)B * nseg * ((W + 1) / 2) * (C / 2);
+    hipLaunchKernelGGL(dwconv7x3_f32_kernel, dim3(nblk(th, 16384)), dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C, hs, nseg, rev);
+  } else hipLaunchKernelGGL((dwconv7x3_kernel<float>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C, hs, nseg, rev);
   return hipGetLastError();
 }
 hipError_t launch_maxpool_same(const void* x, void* y, int in_bf16, int out_bf16, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, hipStream_t st) {
