@@ -121,8 +121,9 @@ def test_infer_bfmvid_cli_through_the_clip_renderer(tmp_path, monkeypatch):
   frames = sorted(os.listdir("output"))
   nf = int(1 + 8000 / 640)
   assert len(frames) == nf and Image.open(os.path.join("output", "0.jpg")).size == (512, 512)
-  assert len(captured) == 1 and captured[0].shape == (nf, 512, 512, 3) and captured[0].dtype == np.uint8
-  drawn = captured[0].reshape(nf, -1)
+  # (the launcher keeps the rendered frames on the device: a uint8 torch tensor)
+  assert len(captured) == 1 and tuple(captured[0].shape) == (nf, 512, 512, 3) and captured[0].dtype == torch.uint8 and captured[0].is_cuda
+  drawn = captured[0].cpu().numpy().reshape(nf, -1)
   assert (drawn.max(axis=1) > 0).all()                                # every frame has a rasterised face pasted in
   assert any(not np.array_equal(drawn[0], drawn[i]) for i in range(1, nf))   # and the mouth / pose moves over the clip
   with_render = np.asarray(Image.open(os.path.join("output", "1.jpg"))).astype(np.int32)

@@ -68,7 +68,7 @@ def angle_sequence(frames, start=(0.0, 0.0, 0.0), shift=0.005):
   return out
 
 
-def render_faces(renderer, center_x, center_y, ratio, bfm_coeff_seq, img_shape, transform_params):
+def render_faces(renderer, center_x, center_y, ratio, bfm_coeff_seq, img_shape, transform_params, on_device=False):
   """render_face (infer_bfmvid.py:79-122) for every frame of the clip: one device pass for reconstruction + rasterisation, then the
   reference's channel swap / cv2.resize / paste for all frames in one more launch (csrc/resize.hip: OpenCV's fixed-point bilinear,
   byte for byte; voicepuppet_amd/utils/cv_resize.py)."""
@@ -81,7 +81,7 @@ def render_faces(renderer, center_x, center_y, ratio, bfm_coeff_seq, img_shape, 
   side = int(round(images.shape[1] / ratio))
   cx, cy = side // 2, side // 2
   out = resize_paste_u8(images, side, side, (img_shape[0], img_shape[1]), center_y - cy - ty, center_x - cx - tx, swap_rb=True)   # :110-121
-  return out.cpu().numpy()
+  return out if on_device else out.cpu().numpy()      # on_device: the clip loop consumes the frames where they are (no PCIe round trip)
 
 
 def main(argv=None):
@@ -177,29 +177,52 @@ def main(argv=None):
       coeff_seq = splice_coeff(photo['bfmcoeff'].reshape(1, 257), bfm_coeff_seq)[0]
       face3d_seq = render_faces(ClipRenderer(_BFM(loadmat(os.path.join('BFM', 'BFM_model_front.mat')))), int(photo['center_x']),
                                 int(photo['center_y']), float(photo['ratio']), coeff_seq, (img_size, img_size, 3),
-                                photo['transform_params'])
+                                photo['transform_params'], on_device=True)
     else:
       logger.warning('BFM assets unavailable: conditioning every frame on the reference 3-D face panel')
 
     T = bfm_coeff_seq.shape[1]
-    inputs = np.zeros([nb, img_size, img_size, 6], dtype=np.float32)
-    fg_inputs = np.zeros([nb, img_size, img_size, 3], dtype=np.float32)
-    targets = np.zeros([nb, img_size, img_size, 3], dtype=np.float32)
-    inputs[:, ..., 0:3] = face3d_refer
-    fg_inputs[:, ..., 0:3] = fg_refer
+    # the three feeds live on the device: only what changes per batch is written (the rendered faces are already there)
+    import torch
+    dev = torch.device('cuda', torch.cuda.current_device())
+    inputs = torch.zeros([nb, img_size, img_size, 6], dtype=torch.float32, device=dev)
+    fg_inputs = torch.zeros([nb, img_size, img_size, 3], dtype=torch.float32, device=dev)
+    targets = torch.full([nb, img_size, img_size, 3], 0.5, dtype=torch.float32, device=dev)
+    refer_t = torch.as_tensor(np.ascontiguousarray(face3d_refer, dtype=np.float32)).to(dev)
+    inputs[:, ..., 0:3] = refer_t
+    fg_inputs[:, ..., 0:3] = torch.as_tensor(np.ascontiguousarray(fg_refer, dtype=np.float32)).to(dev)
+    if face3d_seq is None:
+      inputs[:, ..., 3:6] = refer_t
     from PIL import Image
+    # jpg encoding (2-3 ms per 512 x 512 frame on one core, longer than the generator takes for it) on a small thread pool: PIL's
+    # encoder releases the GIL, the files are byte-identical to a serial loop, and the next batch's launches overlap the writes
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) - 1)))
+    pending = []
+
+    def write_jpg(arr_u8, path):
+      Image.fromarray(arr_u8).save(path)
     for i0 in range(0, T, nb):
-      for k in range(nb):
-        i = min(i0 + k, T - 1)
+      idx = [min(i0 + k, T - 1) for k in range(nb)]
+      if face3d_seq is not None:
         # render_face returns a BGR canvas that the caller swaps again (infer_bfmvid.py:233): net effect = rasteriser order
-        inputs[k, ..., 3:6] = face3d_refer if face3d_seq is None else face3d_seq[i][..., ::-1].astype(np.float32) / 255.0
+        inputs[:, ..., 3:6] = face3d_seq[idx].flip(-1).to(torch.float32) / 255.0
+      for k, i in enumerate(idx):
         bg = 'background/{}.jpg'.format(i % 100 + 1)
-        targets[k] = (ImageLoader(resize=(img_size, img_size)).get_data(bg)[:, :, ::-1] if os.path.exists(bg) else 0.5)
-      frames, last = sess.run([vid2vid_nodes['Outputs'], vid2vid_nodes['Outputs_FG']],
-                              feed_dict={inputs_holder: inputs, fg_inputs_holder: fg_inputs, targets_holder: targets})
+        if os.path.exists(bg):
+          targets[k] = torch.as_tensor(np.ascontiguousarray(ImageLoader(resize=(img_size, img_size)).get_data(bg)[:, :, ::-1], dtype=np.float32)).to(dev)
+        else:
+          targets[k] = 0.5
+      # (the reference fetches 'Outputs' and the unused 'Outputs_FG' as float32 and scales on the host, infer_bfmvid.py:240-243; the
+      # uint8 frame is formed on the device here: 6 MB instead of 50 MB across PCIe per batch of 8, identical bytes)
+      frames = sess.run([vid2vid_nodes['Outputs_u8']],
+                        feed_dict={inputs_holder: inputs, fg_inputs_holder: fg_inputs, targets_holder: targets})[0]
       for k in range(nb):
         if i0 + k < T:
-          Image.fromarray((np.clip(frames[k], 0, 1) * 255).astype(np.uint8)).save(os.path.join(out_dir, '{}.jpg'.format(i0 + k)))
+          pending.append(pool.submit(write_jpg, frames[k], os.path.join(out_dir, '{}.jpg'.format(i0 + k))))
+    for f in pending:
+      f.result()             # every frame is on disk (and any write error surfaces) before ffmpeg reads the directory
+    pool.shutdown()
 
     if shutil.which('ffmpeg'):
       # same command line as infer_bfmvid.py:245, as an argument vector (no shell: the audio path is user input)

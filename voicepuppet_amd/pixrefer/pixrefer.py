@@ -21,6 +21,7 @@ TRAIN_KEYS = ['Inputs', 'FGInputs', 'Targets', 'Masks', 'Outputs', 'Alphas', 'Ou
               'Perceptual_loss', 'Discrim_loss', 'Gen_loss_GAN', 'Gen_loss_L1', 'Gen_loss', 'Global_step', 'Lr', 'Train_op',
               'Discrim_grads_and_vars', 'Gen_grads_and_vars']
 INFER_KEYS = ['Inputs', 'FGInputs', 'Targets', 'Outputs', 'Alphas', 'Outputs_FG']
+EXTRA_INFER_KEYS = ['Outputs_u8']          # not nodes of the reference: see execute()
 
 
 class PixReferNet(ModelBuilder):
@@ -130,7 +131,7 @@ class PixReferNet(ModelBuilder):
     return self._bind(TRAIN_KEYS, {'Inputs': inputs, 'FGInputs': fg_inputs, 'Targets': targets, 'Masks': masks}, True)
 
   def build_inference_op(self, inputs, fg_inputs, targets):
-    return self._bind(INFER_KEYS, {'Inputs': inputs, 'FGInputs': fg_inputs, 'Targets': targets}, False)
+    return self._bind(INFER_KEYS + EXTRA_INFER_KEYS, {'Inputs': inputs, 'FGInputs': fg_inputs, 'Targets': targets}, False)
 
   # ---- execution (called by runtime.Session.run) --------------------------------------------------
   def _resolve(self, feed_dict):
@@ -172,6 +173,11 @@ class PixReferNet(ModelBuilder):
         out[n] = v[n].cpu().numpy()
       elif n == 'Outputs':
         out[n] = ((eng.tensor('Outputs_raw') + 1) / 2).cpu().numpy()                      # deprocess
+      elif n == 'Outputs_u8':
+        # not a node of the reference: (Outputs * 255).astype(uint8) formed on the device, for callers that only write the frames out
+        # (infer_bfmvid.py:243) - a quarter of the device-to-host bytes of 'Outputs' and no host pass; same float32 arithmetic, same bytes
+        import torch
+        out[n] = ((eng.tensor('Outputs_raw') + 1) / 2).clamp_(0, 1).mul_(255).to(torch.uint8).cpu().numpy()
       elif n == 'Alphas':
         out[n] = ((eng.tensor('gen_out4')[..., 3:] + 1) / 2).repeat(1, 1, 1, 3).cpu().numpy()
       elif n == 'Outputs_FG':
