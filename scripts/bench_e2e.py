@@ -31,12 +31,20 @@ with tempfile.TemporaryDirectory() as d:
   np.savez("photo.npz", bfmcoeff=coeff.reshape(1, 257), transform_params=np.array([512, 512, 1.0, 0.0, 0.0], np.float32),
            center_x=256, center_y=256, ratio=0.9)
   args = ["--config_path", cfg, "--frame_batch", str(fb), "--bfmcoeff", "photo.npz", "face.jpg", "a.wav"]
-  infer_bfmvid.main(args)                     # warm-up: library load, plans, first-touch
+  infer_bfmvid.main(args)                     # warm-up: library load, first-touch
+  # (a) a clip whose generator / face model have to be built and restored first (what every clip paid in round 2), (b) the next clip of
+  # the same process (infer_clips.py runs many per rank: the generator and the renderer are kept, only the clip-length BFMNet plan is new)
+  infer_bfmvid._GENERATORS.clear(); infer_bfmvid._RENDERERS.clear()
+  t0 = time.perf_counter()
+  infer_bfmvid.main(args)
+  dt_first = time.perf_counter() - t0
   t0 = time.perf_counter()
   infer_bfmvid.main(args)
   dt = time.perf_counter() - t0
   frames = len(os.listdir("output"))
   os.chdir(ROOT)
-print(json.dumps({"config": "infer_bfmvid end to end, 1 clip, 512x512, 1 GPU (includes plan construction, D2H and jpg encoding)",
-                  "audio_seconds": secs, "frames": frames, "wall_s": dt, "frames_per_s": frames / dt, "x_realtime_25fps": frames / dt / 25.0,
+print(json.dumps({"config": "infer_bfmvid end to end, 1 clip, 512x512, 1 GPU (D2H and jpg encoding included; wall_s: a clip after the first of its process, "
+                            "first_clip_wall_s: with generator / face-model construction)",
+                  "audio_seconds": secs, "frames": frames, "wall_s": dt, "first_clip_wall_s": dt_first, "frames_per_s": frames / dt,
+                  "first_clip_frames_per_s": frames / dt_first, "x_realtime_25fps": frames / dt / 25.0,
                   "vertices": int(fm.meanshape.size // 3), "triangles": int(fm.tri.shape[0]), "frame_batch": fb}))

@@ -68,6 +68,10 @@ def angle_sequence(frames, start=(0.0, 0.0, 0.0), shift=0.005):
   return out
 
 
+_GENERATORS = {}      # see main(): generator networks kept between clips of one process
+_RENDERERS = {}
+
+
 def render_faces(renderer, center_x, center_y, ratio, bfm_coeff_seq, img_shape, transform_params, on_device=False):
   """render_face (infer_bfmvid.py:79-122) for every frame of the clip: one device pass for reconstruction + rasterisation, then the
   reference's channel swap / cv2.resize / paste for all frames in one more launch (csrc/resize.hip: OpenCV's fixed-point bilinear,
@@ -139,19 +143,32 @@ def main(argv=None):
     bfmnet_nodes = bfmnet.build_inference_op(ear, mfcc, seq_len)
 
     ### Vid2VidNet setting
+    # A process that runs many clips (infer_clips.py) keeps the generator - its plan, its 35 M restored parameters - between calls:
+    # building and restoring it is 0.35 s, the frames of an 8 s clip take 0.25 s.  Keyed by what defines it (config, frame batch, image
+    # size, the checkpoint file and its modification time)
     nb = max(1, min(opts.frame_batch, pad_len))
-    vid2vidnet = PixReferNet(config_path)
-    params = vid2vidnet.params
-    params.batch_size = nb
-    params.add_hparam('is_training', False)
-    vid2vidnet.set_params(params)
-    inputs_holder = placeholder([None, img_size, img_size, 6])
-    fg_inputs_holder = placeholder([None, img_size, img_size, 3])
-    targets_holder = placeholder([None, img_size, img_size, 3])
-    vid2vid_nodes = vid2vidnet.build_inference_op(inputs_holder, fg_inputs_holder, targets_holder)
+    pix_ckpt = 'ckpt_pixrefer/pixrefernet-20000'
+    pix_file = next((f for f in (pix_ckpt + '.index', pix_ckpt + '.npz') if os.path.exists(f)), None)
+    pix_key = (os.path.abspath(config_path), nb, img_size, os.path.abspath(pix_file) if pix_file else None,
+               os.path.getmtime(pix_file) if pix_file else None)
+    cached = _GENERATORS.get(pix_key)
+    if cached is None:
+      vid2vidnet = PixReferNet(config_path)
+      params = vid2vidnet.params
+      params.batch_size = nb
+      params.add_hparam('is_training', False)
+      vid2vidnet.set_params(params)
+      inputs_holder = placeholder([None, img_size, img_size, 6])
+      fg_inputs_holder = placeholder([None, img_size, img_size, 3])
+      targets_holder = placeholder([None, img_size, img_size, 3])
+      vid2vid_nodes = vid2vidnet.build_inference_op(inputs_holder, fg_inputs_holder, targets_holder)
+    else:
+      vid2vidnet, inputs_holder, fg_inputs_holder, targets_holder, vid2vid_nodes = cached
 
     # infer_bfmvid.py:217-218: the TensorFlow checkpoints themselves (or .npz archives with the same variable names)
-    for net, ckpt in ((bfmnet, 'ckpt_bfmnet/bfmnet-65000'), (vid2vidnet, 'ckpt_pixrefer/pixrefernet-20000')):
+    for net, ckpt in ((bfmnet, 'ckpt_bfmnet/bfmnet-65000'), (vid2vidnet, pix_ckpt)):
+      if net is vid2vidnet and cached is not None:
+        continue                                     # restored when it was built
       if os.path.exists(ckpt + '.index'):
         net.restore(ckpt)
       elif os.path.exists(ckpt + '.npz'):
@@ -160,6 +177,11 @@ def main(argv=None):
         logger.warning('%s not found: running with randomly initialised weights', ckpt)
         if net is bfmnet:
           bfmnet.init_variables()
+
+    if cached is None:
+      if len(_GENERATORS) >= 4:
+        _GENERATORS.clear()                          # (a handful of shapes at most: do not grow without bound)
+      _GENERATORS[pix_key] = (vid2vidnet, inputs_holder, fg_inputs_holder, targets_holder, vid2vid_nodes)
 
     ### Run inference
     bfm_coeff_seq = sess.run(bfmnet_nodes['BFMCoeffDecoder'])
@@ -175,7 +197,12 @@ def main(argv=None):
           self.keypoints = np.squeeze(model['keypoints']).astype(np.int32) - 1
       photo = np.load(opts.bfmcoeff)
       coeff_seq = splice_coeff(photo['bfmcoeff'].reshape(1, 257), bfm_coeff_seq)[0]
-      face3d_seq = render_faces(ClipRenderer(_BFM(loadmat(os.path.join('BFM', 'BFM_model_front.mat')))), int(photo['center_x']),
+      mat = os.path.join('BFM', 'BFM_model_front.mat')
+      rkey = (os.path.abspath(mat), os.path.getmtime(mat))
+      if rkey not in _RENDERERS:
+        _RENDERERS.clear()
+        _RENDERERS[rkey] = ClipRenderer(_BFM(loadmat(mat)))           # the face model's bases on the device: once per process
+      face3d_seq = render_faces(_RENDERERS[rkey], int(photo['center_x']),
                                 int(photo['center_y']), float(photo['ratio']), coeff_seq, (img_size, img_size, 3),
                                 photo['transform_params'], on_device=True)
     else:
