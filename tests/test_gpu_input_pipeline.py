@@ -54,3 +54,37 @@ def test_prefetcher_equals_straight_loop_and_feeds_a_training_step():
     seen += 1
   torch.cuda.synchronize()
   assert seen == B and all(np.isfinite(v) for v in eng.losses().values())
+
+
+def test_device_dataset_of_the_training_launcher(monkeypatch, tmp_path):
+  """PixReferDataGenerator.get_device_dataset (what train_pixrefer.py iterates): batches are four float32 device tensors equal to the
+  host pipeline's arithmetic (pack_sample over the cropped / resized triptychs, PIL standing in for cv2.resize: 2e-6) on the same decoded
+  frames and crops, in order when the shuffle buffer is 1; pinned ring buffers are reused without corrupting batches in flight."""
+  from voicepuppet_amd.generator.generator import PixReferDataGenerator
+  from voicepuppet_amd.generator.device_pipeline import host_pack_reference, draw_crop
+  import random
+  cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "params.yml")
+  S, N, B = 64, 2, 7
+  rng = np.random.default_rng(3)
+  random.seed(5)
+  samples = [(rng.integers(0, 256, (S, 3 * S, 3)).astype(np.uint8), rng.integers(0, 256, (S, 3 * S, 3)).astype(np.uint8),
+              np.array([draw_crop(S, 0.9), draw_crop(S, 0.9)], np.int32)) for _ in range(N * B)]
+  gen = PixReferDataGenerator(cfg)
+  p = gen.params
+  p.batch_size, p.img_size, p.shuffle_bufsize = N, S, 1
+  p.dataset_path = str(tmp_path / "absent.txt")
+  gen.set_params(p)
+  monkeypatch.setattr(gen, "_frame_samples", lambda: iter(samples))
+  monkeypatch.setattr(gen, "set_params", lambda params: None)          # get_device_dataset re-applies the stored params: keep the test's
+  gen.batch_size, gen.img_size, gen.shuffle_bufsize = N, S, 1
+  it = gen.get_device_dataset().make_one_shot_iterator()
+  nodes = it.get_next()
+  assert [tuple(n.shape) for n in nodes] == [(N, S, S, 6), (N, S, S, 6), (N, S, S, 3), (N, S, S, 3)]
+  for b in range(B - 2):                                                # (the prefetcher keeps two batches in flight)
+    got = [t.clone() for t in it.next_batch()]
+    assert all(t.is_cuda and t.dtype == torch.float32 for t in got)
+    for j in range(N):
+      ex, cur, crops = samples[b * N + j]
+      want = host_pack_reference(ex, cur, crops, S)
+      for g, w in zip(got, want):
+        assert float(np.abs(g[j].cpu().numpy() - w).max()) < 2e-6

@@ -332,3 +332,101 @@ class PixReferDataGenerator(DataGenerator):
     self.set_params(self._params)
     S = self.img_size
     return Dataset(self.iterator, ([S, S, 6], [S, S, 6], [S, S, 3], [S, S, 3]), self.batch_size, self.shuffle_bufsize)
+
+  # ---- the same dataset with the per-sample arithmetic on the device ---------------------------------------------
+  def _frame_samples(self):
+    """(example frame, current frame, crops) per sample, as the device pipeline takes them: the two DECODED jpg triptychs
+    [S, 3S, 3] uint8 BGR (what cv2.imread returns) and the (rx, ry, rsize) each would be cropped with (generator.py:975-977) - the
+    crop / resize / packing themselves run in vp_pixrefer_pack_frames.  Decoding runs on a thread pool (PIL releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from .device_pipeline import draw_crop
+    S = self.img_size
+
+    def crops():
+      return np.array([draw_crop(S, self.crop_ratio), draw_crop(S, self.crop_ratio)], np.int32)
+    if self.data_list is None:
+      # synthetic frames: a small pool of random triptychs (smooth 8 x 8 blocks, a disc matte), fresh crops every time
+      rng = np.random.default_rng(random.randint(0, 2 ** 31))
+      yy, xx = np.mgrid[0:S, 0:S]
+      pool = []
+      for _ in range(16):
+        r = np.sqrt((yy - S / 2 - rng.normal(0, S / 40)) ** 2 + (xx - S / 2 - rng.normal(0, S / 40)) ** 2)
+        mask = np.clip((0.35 * S + 4 - r) / 8, 0, 1)[..., None].repeat(3, 2)
+        lo = rng.uniform(size=(S // 8, S // 8, 6)).astype(np.float32).repeat(8, 0).repeat(8, 1)
+        pool.append(np.ascontiguousarray((np.concatenate([lo[..., :3], lo[..., 3:] * mask, mask], axis=1) * 255).astype(np.uint8)))
+      while True:
+        yield pool[int(rng.integers(16))], pool[int(rng.integers(16))], crops()
+
+    def decode(path):
+      return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)[:, :, ::-1])      # BGR, as cv2.imread
+    workers = max(2, min(16, (os.cpu_count() or 4) - 1))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+      while True:
+        random.shuffle(self.data_list)
+        jobs = []
+        for line in self.data_list:
+          folder, img_count = line.strip().split('|')
+          img_count = int(img_count)
+          for i in range(img_count):
+            rnd_idx = random.randint(0, img_count - 1)
+            jobs.append((pool.submit(decode, os.path.join(folder, '{}.jpg'.format(rnd_idx))),
+                         pool.submit(decode, os.path.join(folder, '{}.jpg'.format(i)))))
+            while len(jobs) > 4 * workers:          # a bounded number of decodes in flight, handed out in order
+              a, b = jobs.pop(0)
+              yield a.result(), b.result(), crops()
+        for a, b in jobs:
+          yield a.result(), b.result(), crops()
+
+  def get_device_dataset(self):
+    """get_dataset() for a GPU training loop: same sample order semantics (shuffle buffer, repeat, batches), but a batch is four
+    float32 DEVICE tensors produced by vp_pixrefer_pack_frames from uint8 frames, copied and packed on a side stream under the previous
+    step (generator/device_pipeline.py)."""
+    self.set_params(self._params)
+    return _DeviceFrameDataset(self)
+
+
+class _DeviceFrameIterator(object):
+  def __init__(self, ds):
+    self.ds = ds
+    self._pf = None
+
+  def get_next(self):
+    b, S = self.ds.batch_size, self.ds.owner.img_size
+    return tuple(IteratorNext(self, k, (b, S, S, c)) for k, c in enumerate((6, 6, 3, 3)))
+
+  def _batches(self):
+    """Batches as PINNED torch tensors the prefetcher copies from directly (no staging copy): a ring of four, since a batch must stay
+    unchanged until two batches later (FramePrefetcher).  The samples of a batch are written straight into the ring slot."""
+    import torch
+    g = self.ds.owner
+    N, S = self.ds.batch_size, g.img_size
+    ring = [(torch.empty(N, S, 3 * S, 3, dtype=torch.uint8).pin_memory(), torch.empty(N, S, 3 * S, 3, dtype=torch.uint8).pin_memory(),
+             torch.empty(N, 2, 3, dtype=torch.int32).pin_memory()) for _ in range(4)]
+    views = [tuple(t.numpy() for t in slot) for slot in ring]
+    buf, it = [], g._frame_samples()
+    rng = np.random.default_rng()
+    k = 0
+    while True:
+      ex, cur, crops = views[k % 4]
+      for j in range(N):
+        while len(buf) < max(1, g.shuffle_bufsize):
+          buf.append(next(it))
+        s = buf.pop(int(rng.integers(len(buf))) if g.shuffle_bufsize > 1 else 0)
+        ex[j] = s[0]; cur[j] = s[1]; crops[j] = s[2]
+      yield ring[k % 4]
+      k += 1
+
+  def next_batch(self):
+    if self._pf is None:
+      from .device_pipeline import FramePrefetcher
+      self._pf = FramePrefetcher(self._batches(), self.ds.batch_size, self.ds.owner.img_size)
+    return self._pf.next()
+
+
+class _DeviceFrameDataset(object):
+  def __init__(self, owner):
+    self.owner, self.batch_size = owner, owner.batch_size
+
+  def make_one_shot_iterator(self):
+    return _DeviceFrameIterator(self)

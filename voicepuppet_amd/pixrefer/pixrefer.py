@@ -167,7 +167,9 @@ class PixReferNet(ModelBuilder):
     else:
       eng.forward(v['Inputs'], v['FGInputs'], v['Targets'], v.get('Masks'))
     out = {}
-    losses = eng.losses() if eng.training else {}
+    LOSS_KEYS = ('Perceptual_loss', 'Discrim_loss', 'Gen_loss_GAN', 'Gen_loss_L1', 'Gen_loss')
+    # (reading the losses waits for the step: only when one of them is fetched)
+    losses = eng.losses() if (eng.training and any(n in LOSS_KEYS for n in names)) else {}
     for n in names:
       if n in ('Inputs', 'FGInputs', 'Targets', 'Masks'):
         out[n] = v[n].cpu().numpy()

@@ -72,7 +72,10 @@ def main(argv=None):
   if opts.img_size:
     params.img_size = opts.img_size
   train_generator.set_params(params)
-  train_dataset = train_generator.get_dataset()
+  # the per-sample crop / resize / packing on the device, decoded uint8 frames copied under the previous step;
+  # amd: {device_input_pipeline: false} in params.yml restores the reference's host pipeline
+  use_device_pipeline = (params.get('amd') or {}).get('device_input_pipeline', True) not in (False, 'false', 'no', 0)
+  train_dataset = train_generator.get_device_dataset() if use_device_pipeline else train_generator.get_dataset()
 
   sess = Session()
   train_iter = train_dataset.make_one_shot_iterator()
@@ -108,10 +111,18 @@ def main(argv=None):
   t0 = time.time()
   for i in range(epochs):
     ### Run training
-    fetch = [train_nodes['Train_op'], train_nodes['Gen_loss_GAN'], train_nodes['Gen_loss_L1'], train_nodes['Discrim_loss'],
-             train_nodes['Lr'], train_nodes['Global_step']]
-    _, gen_loss_GAN, gen_loss_L1, discrim_loss, lr, global_step = sess.run(fetch)
-    if (global_step % params.summary_step == 0 and rank == 0):
+    # the reference fetches the three losses every step and prints them every summary_step (train_pixrefer.py:134-143).  Reading a
+    # loss waits for the step, and a host that waits every step cannot enqueue the next one under it: the losses are fetched on the
+    # steps that print them (both apply_gradients bump global_step: + 2 per iteration)
+    summary = (vid2vidnet.global_step + 2) % params.summary_step == 0
+    fetch = [train_nodes['Train_op'], train_nodes['Lr'], train_nodes['Global_step']]
+    if summary:
+      fetch += [train_nodes['Gen_loss_GAN'], train_nodes['Gen_loss_L1'], train_nodes['Discrim_loss']]
+    vals = sess.run(fetch)
+    lr, global_step = vals[1], vals[2]
+    if summary:
+      gen_loss_GAN, gen_loss_L1, discrim_loss = vals[3:6]
+    if (summary and rank == 0):
       print('Step {}, Lr= {:.2e}: \n\tgen_loss_GAN= {:.3f}, \n\tgen_loss_L1= {:.3f}, \n\tdiscrim_loss= {:.3f}'.format(
           global_step, lr, gen_loss_GAN, gen_loss_L1, discrim_loss))
       fps = (i + 1) * batch_size * world / (time.time() - t0)
