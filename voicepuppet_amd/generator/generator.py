@@ -223,8 +223,31 @@ class _MfccIterator(DatasetIterator):
     shapes = ((b, T, 257), (b, T, 1), (b, T * g.frame_mfcc_scale, g.num_mel_bins), (b,))
     return tuple(IteratorNext(self, k, s) for k, s in enumerate(shapes))
 
+  def _host_batches(self):
+    """The host half of a batch (file reads / slicing / shuffling / stacking: 19 ms for 32 synthetic clips) on a background thread, two
+    batches ahead: the training loop reads its loss after every step (train_bfmnet.py:96-97 prints it), and while it waits for the
+    device the interpreter is free to prepare the next batch.  The device half (log-mel) stays on the caller's thread."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=2)
+
+    def work():
+      try:
+        while True:
+          q.put(DatasetIterator.next_batch(self))
+      except BaseException as e:      # hand the failure to the consumer
+        q.put(e)
+    threading.Thread(target=work, daemon=True, name="bfmnet-batches").start()
+    while True:
+      item = q.get()
+      if isinstance(item, BaseException):
+        raise item
+      yield item
+
   def next_batch(self):
-    coeff, ear, pcm, n = DatasetIterator.next_batch(self)
+    if getattr(self, "_hb", None) is None:
+      self._hb = self._host_batches()
+    coeff, ear, pcm, n = next(self._hb)
     return self.ds.owner.process_data(coeff, ear, pcm, n.astype(np.int32))
 
 
