@@ -425,6 +425,9 @@ int vp_resize_paste_u8(const unsigned char* src, int frames, int src_h, int src_
                        unsigned char* canvas, int canvas_h, int canvas_w, int y0, int x0, void* workspace, void* stream);
 int vp_resize_linear_table(int src_size, int dst_size, int rows, int* ofs, short* a0, short* a1, int* row1);
 
+/* Host helper: CRC-32C (Castagnoli, the checksum of TensorFlow checkpoint bundles) of `n` bytes, continuing from `crc` (0 to start). */
+unsigned vp_crc32c(const void* data, size_t n, unsigned crc);
+
 #ifdef __cplusplus
 }
 #endif

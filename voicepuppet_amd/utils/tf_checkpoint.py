@@ -545,12 +545,33 @@ def _zero_bytes_operator(nbytes):
   return result
 
 
+_NATIVE_CRC = None
+
+
+def _native_crc():
+  """vp_crc32c of libvp_hip.so (the SSE4.2 instruction, host code) when the library can be loaded; False otherwise."""
+  global _NATIVE_CRC
+  if _NATIVE_CRC is None:
+    try:
+      from .. import _lib
+      _NATIVE_CRC = _lib.lib().vp_crc32c
+    except Exception:
+      _NATIVE_CRC = False
+  return _NATIVE_CRC
+
+
 def crc32c_fast(raw, lanes=16384):
-  """crc32c(raw) for large buffers: the buffer is cut into `lanes` equal pieces whose CRCs advance in lockstep through the byte
-  table (one numpy step per byte position), then the piece CRCs fold pairwise: crc(A || B) = shift(crc(A), len(B)) ^ crc(B)."""
+  """crc32c(raw) for large buffers.  Through the library's hardware-instruction helper when it is loadable; otherwise in numpy: the
+  buffer is cut into `lanes` equal pieces whose CRCs advance in lockstep through the byte table (one numpy step per byte
+  position), then the piece CRCs fold pairwise: crc(A || B) = shift(crc(A), len(B)) ^ crc(B)."""
   n = len(raw)
   if n < (1 << 16):
     return crc32c(raw)
+  f = _native_crc()
+  if f:
+    import ctypes
+    buf = np.frombuffer(raw, np.uint8)
+    return int(f(ctypes.c_void_p(buf.ctypes.data), n, 0))
   m = n // lanes
   body = np.frombuffer(raw, np.uint8, lanes * m).reshape(lanes, m).T.copy()      # [byte position][lane]
   tab = np.asarray(_CRC, np.uint32)
