@@ -229,27 +229,29 @@ def main(argv=None):
 
     def write_jpg(arr_u8, path):
       Image.fromarray(arr_u8).save(path)
-    for i0 in range(0, T, nb):
-      idx = [min(i0 + k, T - 1) for k in range(nb)]
-      if face3d_seq is not None:
-        # render_face returns a BGR canvas that the caller swaps again (infer_bfmvid.py:233): net effect = rasteriser order
-        inputs[:, ..., 3:6] = face3d_seq[idx].flip(-1).to(torch.float32) / 255.0
-      for k, i in enumerate(idx):
-        bg = 'background/{}.jpg'.format(i % 100 + 1)
-        if os.path.exists(bg):
-          targets[k] = torch.as_tensor(np.ascontiguousarray(ImageLoader(resize=(img_size, img_size)).get_data(bg)[:, :, ::-1], dtype=np.float32)).to(dev)
-        else:
-          targets[k] = 0.5
-      # (the reference fetches 'Outputs' and the unused 'Outputs_FG' as float32 and scales on the host, infer_bfmvid.py:240-243; the
-      # uint8 frame is formed on the device here: 6 MB instead of 50 MB across PCIe per batch of 8, identical bytes)
-      frames = sess.run([vid2vid_nodes['Outputs_u8']],
-                        feed_dict={inputs_holder: inputs, fg_inputs_holder: fg_inputs, targets_holder: targets})[0]
-      for k in range(nb):
-        if i0 + k < T:
-          pending.append(pool.submit(write_jpg, frames[k], os.path.join(out_dir, '{}.jpg'.format(i0 + k))))
-    for f in pending:
-      f.result()             # every frame is on disk (and any write error surfaces) before ffmpeg reads the directory
-    pool.shutdown()
+    try:
+      for i0 in range(0, T, nb):
+        idx = [min(i0 + k, T - 1) for k in range(nb)]
+        if face3d_seq is not None:
+          # render_face returns a BGR canvas that the caller swaps again (infer_bfmvid.py:233): net effect = rasteriser order
+          inputs[:, ..., 3:6] = face3d_seq[idx].flip(-1).to(torch.float32) / 255.0
+        for k, i in enumerate(idx):
+          bg = 'background/{}.jpg'.format(i % 100 + 1)
+          if os.path.exists(bg):
+            targets[k] = torch.as_tensor(np.ascontiguousarray(ImageLoader(resize=(img_size, img_size)).get_data(bg)[:, :, ::-1], dtype=np.float32)).to(dev)
+          else:
+            targets[k] = 0.5
+        # (the reference fetches 'Outputs' and the unused 'Outputs_FG' as float32 and scales on the host, infer_bfmvid.py:240-243; the
+        # uint8 frame is formed on the device here: 6 MB instead of 50 MB across PCIe per batch of 8, identical bytes)
+        frames = sess.run([vid2vid_nodes['Outputs_u8']],
+                          feed_dict={inputs_holder: inputs, fg_inputs_holder: fg_inputs, targets_holder: targets})[0]
+        for k in range(nb):
+          if i0 + k < T:
+            pending.append(pool.submit(write_jpg, frames[k], os.path.join(out_dir, '{}.jpg'.format(i0 + k))))
+      for f in pending:
+        f.result()           # every frame is on disk (and any write error surfaces) before ffmpeg reads the directory
+    finally:
+      pool.shutdown()        # (also on an error in the loop: the writer threads must not outlive the call)
 
     if shutil.which('ffmpeg'):
       # same command line as infer_bfmvid.py:245, as an argument vector (no shell: the audio path is user input)
