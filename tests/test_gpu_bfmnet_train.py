@@ -150,7 +150,8 @@ def test_two_stream_step_equals_one_stream_step(monkeypatch):
   assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("P,K,N", [(96, 256, 512), (3840, 192, 1152), (1000, 48, 32), (7, 1536, 256), (96, 64, 1007)])
+@pytest.mark.parametrize("P,K,N", [(96, 256, 512), (3840, 192, 1152), (1000, 48, 32), (7, 1536, 256), (96, 64, 1007),
+                                   (213, 128, 192), (50, 384, 64), (19200, 64, 384)])      # + the 128 x 64 tile of wgrad_mm.hip, a long K walk
 def test_matrix_products_against_numpy(P, K, N):
   """vp_mm_fwd_f32 / vp_mm_bwd_data_f32 / vp_mm_bwd_weight_f32 (csrc/mm_api.hip: the repo's own float32-MFMA kernels - no vendor GEMM
   library) against float64 numpy, at the shapes of the BFMNet training step: channel counts that are not powers of two, a handful
