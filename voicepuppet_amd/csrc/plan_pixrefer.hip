@@ -133,7 +133,12 @@ struct vp_pixrefer {
   double* bn_partial2;
   char* scratch3;             // ... and of the branch stream (the generator's foreground encoder branch, forward and backward)
   double* bn_partial3;
+  char* scratch4;             // ... and of the second branch stream (the foreground encoder branch of the BACKWARD pass, see branch2)
+  double* bn_partial4;
   hipStream_t side, branch;
+  hipStream_t branch2;             // backward: the foreground encoder chain, so that it does not queue behind the weight-gradient backlog of `branch`
+                                   // (== branch when VP_NO_FG_STREAM is set: a data-parallel host that brings streams of its own may want three)
+  hipEvent_t ev_b2join;
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
   hipEvent_t ev_skip;              // generator backward: the skip-connection data gradients issued on the branch stream so far are done
   hipEvent_t ev_upd_b, ev_upd_m;   // fused update: a generator bucket's weight gradients (branch stream) / data gradients (caller's stream) are done
@@ -479,6 +484,8 @@ static size_t carve_all(vp_pixrefer* h, char* base, size_t cap, std::vector<std:
     h->scratch2 = (char*)ar.alloc(h->scratch_bytes);
     h->bn_partial3 = (double*)ar.alloc((size_t)1024 * 2 * 512 * sizeof(double));
     h->scratch3 = (char*)ar.alloc(h->scratch_bytes);
+    h->bn_partial4 = (double*)ar.alloc((size_t)1024 * 2 * 512 * sizeof(double));
+    h->scratch4 = (char*)ar.alloc(h->scratch_bytes);
   }
   return ar.off + 256;
 }
@@ -540,8 +547,8 @@ static int run_pack(vp_pixrefer* h, Net& n, hipStream_t st) {
 }
 
 // scratch set of a stream: 0 = the caller's stream, 1 = side stream, 2 = branch stream
-static char* scratch_of(vp_pixrefer* h, int ss) { return ss == 2 ? h->scratch3 : ss == 1 ? h->scratch2 : h->scratch; }
-static double* bnp_of(vp_pixrefer* h, int ss) { return ss == 2 ? h->bn_partial3 : ss == 1 ? h->bn_partial2 : h->bn_partial; }
+static char* scratch_of(vp_pixrefer* h, int ss) { return ss == 3 ? h->scratch4 : ss == 2 ? h->scratch3 : ss == 1 ? h->scratch2 : h->scratch; }
+static double* bnp_of(vp_pixrefer* h, int ss) { return ss == 3 ? h->bn_partial4 : ss == 2 ? h->bn_partial3 : ss == 1 ? h->bn_partial2 : h->bn_partial; }
 
 // fused_chunks > 0: the conv epilogue already wrote that many partial chunks per group; only the finalize pass runs
 static int run_bn_stats(vp_pixrefer* h, Net& n, Layer& L, int fused_chunks, hipStream_t st, int ss = 0) {
@@ -976,6 +983,7 @@ int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d) {
     region_of(h->dl_d, 3 * M * 8 * es, "dl_d"); region_of(h->dl_g, M * 8 * es, "dl_g");
     region_of(h->d_din, px * 8 * es, "d_din"); region_of(h->d_vin, px * 8 * es, "d_vin"); region_of(h->dy4, px * 8 * es, "dy4");
     region_of(h->scratch2, h->scratch_bytes, "scratch2"); region_of(h->scratch3, h->scratch_bytes, "scratch3");
+    region_of(h->scratch4, h->scratch_bytes, "scratch4"); region_of(h->bn_partial4, (size_t)1024 * 2 * 512 * 8, "bn_partial4");
     region_of(h->bn_partial2, (size_t)1024 * 2 * 512 * 8, "bn_partial2"); region_of(h->bn_partial3, (size_t)1024 * 2 * 512 * 8, "bn_partial3");
   }
   delete h;
@@ -1015,6 +1023,9 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch, hipStreamNonBlocking));
+    if (getenv("VP_NO_FG_STREAM")) h->branch2 = h->branch;
+    else VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch2, hipStreamNonBlocking));
+    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_b2join, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bfork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bjoin, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_skip, hipEventDisableTiming));
@@ -1037,6 +1048,8 @@ void vp_pixrefer_destroy(vp_pixrefer_t* h) {
     (void)hipStreamSynchronize(h->branch);
     (void)hipEventDestroy(h->ev_bfork);
     (void)hipEventDestroy(h->ev_bjoin);
+    (void)hipEventDestroy(h->ev_b2join);
+    if (h->branch2 != h->branch) { (void)hipStreamSynchronize(h->branch2); (void)hipStreamDestroy(h->branch2); }
     (void)hipEventDestroy(h->ev_skip);
     (void)hipEventDestroy(h->ev_upd_b);
     (void)hipEventDestroy(h->ev_upd_m);
@@ -1465,30 +1478,36 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   const bool split_enc = h->overlap && g_overlap_on && l_lo == 0;
   const bool wsplit = h->overlap && g_overlap_on && !getenv("VP_NO_WSPLIT");
   bool forked = false, fg_forked = false;
+  bool b2_used = false;            // something of this call runs on the second branch stream (joined wherever `branch` is)
   for (int i = l_hi; i >= l_lo; --i) {
     Layer& L = G.l[i];
     Tens& to = G.t[L.out];
     const bool fg = split_enc && L.scope.rfind("encoder_fg_", 0) == 0;
     if (fg && !fg_forked) {      // the branch's first layer needs merged_encoder_2's data gradient, enqueued on `st` just before
       VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
-      VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
+      VP_HIP_CHECK(hipStreamWaitEvent(h->branch2, h->ev_bfork, 0));
       forked = fg_forked = true;
+      b2_used = h->branch2 != h->branch;
     }
-    hipStream_t s2 = fg ? h->branch : st;
-    const int ss = fg ? 2 : 0;
+    // (the foreground chain has a stream of its own: on `branch` it queued behind the weight gradients of every layer before it and
+    // ended the step 0.2-0.6 ms after the caller's chain)
+    hipStream_t s2 = fg ? h->branch2 : st;
+    const int ss = fg ? (h->branch2 != h->branch ? 3 : 2) : 0;
     if (i == i_md5 - 1) phase_mark(h, st, 4);
     if (i == i_me2 - 1) phase_mark(h, st, 5);
     if (g_phase_detail && !fg) phase_mark(h, st, 32 + i);                         // [32 + layer] = before the layer's backward on `st`
     if (L.has_bn) if ((rc = run_bn_bwd(h, G, L, true, 0, N, 0, 1, s2, ss))) return rc;
     if (wsplit && !fg) {
       // the weight gradient of a layer hangs off the chain (only its data gradient feeds the next layer): branch stream
+      static const bool skip_on_branch = getenv("VP_SKIP_ON_BRANCH") != nullptr;
+      // (alternating the weight gradients between the two branch streams was measured: slower - they then sit in front of the
+      // foreground chain again; batch 4 2.55 vs 2.50 ms)
       VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
       VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
       forked = true;
       // ... and so does the data gradient of a SECOND source (a decoder's skip connection, merged_encoder_2's foreground input): it is
       // first needed when the backward pass reaches the encoder that produced the tensor
       // (opt-in: measured +0.02 .. 0.05 ms at batch 4 / 8 / 32 - the branch stream, not this one, ends the step)
-      static const bool skip_on_branch = getenv("VP_SKIP_ON_BRANCH") != nullptr;
       const int bparts = (skip_on_branch && L.nsrc > 1) ? 1 | 4 : 1;
       if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, h->branch, 2, false, bparts))) return rc;
       if (bparts & 4) VP_HIP_CHECK(hipEventRecord(h->ev_skip, h->branch));
@@ -1512,10 +1531,18 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
         VP_HIP_CHECK(hipEventRecord(h->ev_upd_m, st));
         VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_upd_b, 0));
         VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_upd_m, 0));
+        if (b2_used) {                                   // weight gradients / the foreground encoders' chain on the second branch stream
+          VP_HIP_CHECK(hipEventRecord(h->ev_b2join, h->branch2));
+          VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_b2join, 0));
+        }
         su = h->side;
       } else if (h->overlap && g_overlap_on) {
         VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
         VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
+        if (b2_used) {
+          VP_HIP_CHECK(hipEventRecord(h->ev_b2join, h->branch2));
+          VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_b2join, 0));
+        }
         su = h->branch; forked = true;
       }
       if ((rc = update_range(h, G, h->upd.m_g, h->upd.v_g, h->upd.lr_t_g, off0, off1, l0, l1, su))) return rc;
@@ -1523,8 +1550,13 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     }
   }
   if (forked) {
+    if (g_phase_detail && (stage < 0 || stage == 2)) phase_mark(h, st, 60);      // [60] the caller's chain is done, [6] the branch stream's weight gradients too
     VP_HIP_CHECK(hipEventRecord(h->ev_bjoin, h->branch));
     VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
+    if (b2_used) {
+      VP_HIP_CHECK(hipEventRecord(h->ev_b2join, h->branch2));
+      VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_b2join, 0));
+    }
   }
   if (stage < 0 || stage == 2) phase_mark(h, st, 6);
   return VP_OK;
