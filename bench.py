@@ -315,6 +315,7 @@ def run_with_input_pipeline(per_gpu, height, dtype, steps, warmup, device):
     while True:
       yield pool[k % len(pool)]
       k += 1
+  eng.use_streams(3)      # the prefetcher's stream is the fourth busy one (include/vp_hip.h vp_pixrefer_use_streams)
   pf = FramePrefetcher(source(), per_gpu, S)
   for _ in range(warmup):
     eng.train_step(*pf.next(), lr=3e-4)

@@ -116,6 +116,9 @@ int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream);
  * stream of its own (the device has few hardware queues; streams beyond them share one).  Work the host enqueues on it runs behind the
  * discriminator-loss pass of the step.  NULL if the plan runs on a single stream (VP_NO_OVERLAP). */
 void* vp_pixrefer_side_stream(vp_pixrefer_t* h);
+/* Streams a training step is spread over: 4 (default) or 3.  A host that runs a busy stream of its own beside the step (an input
+ * prefetcher) asks for 3: the device has few hardware queues, a fifth busy stream shares one with an executor stream. */
+int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n);
 /* The same pass in vp_pixrefer_backward_g_stages() = 3 consecutive stages (stage < 0: all).  After stage s a contiguous
  * range of the generator gradient arena is final (0: from generator/merged_decoder_5 to the end; 1: from
  * generator/merged_encoder_2 up to merged_decoder_5; 2: the rest), so a data-parallel host can start that bucket's

@@ -139,6 +139,7 @@ struct vp_pixrefer {
   hipStream_t branch2;             // backward: the foreground encoder chain, so that it does not queue behind the weight-gradient backlog of `branch`
                                    // (== branch when VP_NO_FG_STREAM is set: a data-parallel host that brings streams of its own may want three)
   hipEvent_t ev_b2join;
+  bool use_b2;                     // vp_pixrefer_use_streams: false = the backward pass keeps to three streams (the host runs a stream of its own)
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
   hipEvent_t ev_skip;              // generator backward: the skip-connection data gradients issued on the branch stream so far are done
   hipEvent_t ev_upd_b, ev_upd_m;   // fused update: a generator bucket's weight gradients (branch stream) / data gradients (caller's stream) are done
@@ -1023,8 +1024,10 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch, hipStreamNonBlocking));
-    if (getenv("VP_NO_FG_STREAM")) h->branch2 = h->branch;
-    else VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch2, hipStreamNonBlocking));
+    // the fourth stream is created on first use (the backward pass of a handle that still wants four streams): hardware queues are
+    // handed out as streams are created, and a host stream created later (an input prefetcher's) must not be pushed onto a shared one
+    h->branch2 = nullptr;
+    h->use_b2 = !getenv("VP_NO_FG_STREAM");
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_b2join, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bfork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bjoin, hipEventDisableTiming));
@@ -1049,7 +1052,7 @@ void vp_pixrefer_destroy(vp_pixrefer_t* h) {
     (void)hipEventDestroy(h->ev_bfork);
     (void)hipEventDestroy(h->ev_bjoin);
     (void)hipEventDestroy(h->ev_b2join);
-    if (h->branch2 != h->branch) { (void)hipStreamSynchronize(h->branch2); (void)hipStreamDestroy(h->branch2); }
+    if (h->branch2) { (void)hipStreamSynchronize(h->branch2); (void)hipStreamDestroy(h->branch2); }
     (void)hipEventDestroy(h->ev_skip);
     (void)hipEventDestroy(h->ev_upd_b);
     (void)hipEventDestroy(h->ev_upd_m);
@@ -1351,6 +1354,16 @@ int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream) {
 // extra stream beyond them shares one with another stream (false serialisation).  NULL when the plan does not overlap.
 void* vp_pixrefer_side_stream(vp_pixrefer_t* h) { return (h && h->overlap) ? (void*)h->side : nullptr; }
 
+// Streams the executor spreads a training step over: 4 (default: the caller's, side, branch and the foreground chain's own in the backward
+// pass) or 3.  The device schedules a handful of hardware queues; a host that keeps a busy stream of its own next to the step (an input
+// prefetcher copying and packing the next batch) asks for 3, or its stream shares a queue with one of the executor's (measured: a
+// PCIe-fed step 8.5 -> 11.4 ms with five busy streams).  Takes effect from the next backward pass.
+int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n) {
+  if (!h || (n != 3 && n != 4)) { set_err("vp_pixrefer_use_streams: 3 or 4"); return VP_ERR_ARG; }
+  h->use_b2 = (n == 4) && h->overlap && !getenv("VP_NO_FG_STREAM");
+  return VP_OK;
+}
+
 int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d_join: needs a training plan"); return VP_ERR_STATE; }
   if (h->forked && h->dfork_pending) {   // (no stage 0 ran since the fork: start the pass now)
@@ -1485,14 +1498,15 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     const bool fg = split_enc && L.scope.rfind("encoder_fg_", 0) == 0;
     if (fg && !fg_forked) {      // the branch's first layer needs merged_encoder_2's data gradient, enqueued on `st` just before
       VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
-      VP_HIP_CHECK(hipStreamWaitEvent(h->branch2, h->ev_bfork, 0));
+      if (h->use_b2 && !h->branch2) VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch2, hipStreamNonBlocking));
+      VP_HIP_CHECK(hipStreamWaitEvent(h->use_b2 ? h->branch2 : h->branch, h->ev_bfork, 0));
       forked = fg_forked = true;
-      b2_used = h->branch2 != h->branch;
+      b2_used = h->use_b2;
     }
     // (the foreground chain has a stream of its own: on `branch` it queued behind the weight gradients of every layer before it and
     // ended the step 0.2-0.6 ms after the caller's chain)
-    hipStream_t s2 = fg ? h->branch2 : st;
-    const int ss = fg ? (h->branch2 != h->branch ? 3 : 2) : 0;
+    hipStream_t s2 = fg ? (h->use_b2 ? h->branch2 : h->branch) : st;
+    const int ss = fg ? (h->use_b2 ? 3 : 2) : 0;
     if (i == i_md5 - 1) phase_mark(h, st, 4);
     if (i == i_me2 - 1) phase_mark(h, st, 5);
     if (g_phase_detail && !fg) phase_mark(h, st, 32 + i);                         // [32 + layer] = before the layer's backward on `st`

@@ -61,6 +61,7 @@ class PixReferEngine:
     if training:
       self.adam = {"g": [z(counts[0]), z(counts[0])], "d": [z(counts[1]), z(counts[1])]}
     self.t_g = self.t_d = 0
+    self._dp_streams_set = False
     self.grad_transport = "f32"          # data parallel: 'bf16' halves the bytes of the gradient all-reduce (parallel.GradExchange)
     self._exchange = None
     self.fused_update = not os.environ.get("VP_NO_FUSED_UPDATE")      # single-GPU train_step: vp_pixrefer_backward_update (backward + Adam x 2 + re-pack in one call)
@@ -184,6 +185,11 @@ class PixReferEngine:
     b = off["generator/merged_encoder_2/conv2d/kernel"]
     return [(a, self.grads_g.numel()), (b, a), (0, b)]
 
+  def use_streams(self, n):
+    """3 or 4 executor streams (include/vp_hip.h vp_pixrefer_use_streams): a caller that feeds the step through a prefetcher with a stream
+    of its own (generator/device_pipeline.FramePrefetcher) asks for 3."""
+    _lib.check(self.L.vp_pixrefer_use_streams(self.h, int(n)), "vp_pixrefer_use_streams")
+
   def train_step(self, inputs, fg_inputs, targets, masks, lr, beta1=0.5, group=None):
     """One iteration of train_pixrefer.py:136-143 on this replica: forward, both backward passes,
     (data parallel: RCCL all-reduce-mean of the two gradient arenas, the discriminator's overlapped
@@ -204,6 +210,9 @@ class PixReferEngine:
       # data parallel: every bucket is all-reduced on the communication stream as soon as its stage has run, and its Adam update +
       # weight re-pack follow right behind the collective on that stream - under the stages that still compute
       from .parallel import GradExchange
+      if not self._dp_streams_set:
+        self.use_streams(3)        # RCCL brings streams of its own: the executor keeps to three (include/vp_hip.h vp_pixrefer_use_streams)
+        self._dp_streams_set = True
       ex = self._exchange
       if ex is None or ex.group is not group or ex.transport != self.grad_transport:
         # the collectives go to the executor's side stream (behind the discriminator-loss pass, where the single-GPU schedule runs its

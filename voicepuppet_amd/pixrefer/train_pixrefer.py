@@ -102,6 +102,8 @@ def main(argv=None):
     mkdir(params.summary_dir)
 
   train_nodes = vid2vidnet.build_train_op(*train_iter.get_next())
+  if use_device_pipeline:
+    vid2vidnet.engine.use_streams(3)      # the input prefetcher's stream is the fourth busy one (include/vp_hip.h vp_pixrefer_use_streams)
   if world > 1:   # identical initial weights on every replica
     for a in (vid2vidnet.engine.params_g, vid2vidnet.engine.params_d, vid2vidnet.engine.params_vgg):
       dist.broadcast(a, 0)
