@@ -13,6 +13,11 @@
 // an address class (pp & 3) have four different (px >> 2) & 3, so a 32-lane service group of a ds_read_b64 hits 32 distinct 8-byte
 // slots for every column shift.  Two chunks (K = 2 x 64 bytes per tap) per trip: channel counts are multiples of 64 (bf16) / 32 (f32).
 #include <stdlib.h>
+// VP_P3_ABL: build-time ablations of the loop for timing only (results are wrong): 1 no barrier, 2 no vmcnt wait, 4 no DMA in the
+// loop, 8 no epilogue, 16 no loop (make ablate3 ABL=n -> ../libvp_p3abl<n>.so, select with VP_LIB)
+#ifndef VP_P3_ABL
+#define VP_P3_ABL 0
+#endif
 
 #include <utility>
 
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   // ring stage U % NSTW.  In DMA order behind the weights of step U (issued at step U - LA): the patch piece of step U - LA, then per
   // later step its weights and its patch piece - a piece is issued at the steps with u < JP, always (behind the last chunk it
   // fetches bytes nobody reads, into the idle buffer)
-  for (int c = 0; c < nchunkc; c += 2) {
+  for (int c = 0; c < ((VP_P3_ABL & 16) ? 0 : nchunkc); c += 2) {
     const bool last_pair = c + 2 >= nchunkc;
     auto step = [&](auto uc) {
       constexpr int U = decltype(uc)::value;
@@ -173,21 +178,53 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
       constexpr int NPIECE = [] { int n = 0; for (int k = 1; k <= LA; ++k) n += ((U + 18 - k) % 18 % 9) < JP ? 1 : 0; return n; }();
       constexpr int NV = (LA - 1) * JA + NPIECE;
       constexpr int WLAST = (17 - U < LA - 1 ? 17 - U : LA - 1);                 // behind the last pair no weights of a next trip follow
+#if !(VP_P3_ABL & 2)
       if (U + LA - 1 > 17 && last_pair) wait_vm<WLAST * JA + NPIECE>();
       else wait_vm<NV>();
+#endif
+#if !(VP_P3_ABL & 1)
       __builtin_amdgcn_s_barrier();
+#endif
       asm volatile("" ::: "memory");
       // weights LA steps ahead (ring stage (U + LA) % NSTW, last read in step U - 1)
+#if !(VP_P3_ABL & 4)
       {
         constexpr int UL = (U + LA) % 18;
         if (U + LA < 18) issue_w(UL % 9, c + UL / 9, (U + LA) % NSTW);
         else if (!last_pair) issue_w(UL % 9, c + 2 + UL / 9, (U + LA) % NSTW);
       }
       if constexpr (u < JP) issue_p(c + cc + 1, 1 - cc, u);
+#endif
       // eight weight blocks per wave: two read batches of four (16 fragment registers instead of 32); the 64-accumulator tile at
       // two blocks per CU (128 registers per lane): batches of two
       constexpr int NA = TC == 8 ? 4 : ((TC == 4 && OCC == 4) ? 2 : TC);
       uint4 fb[TP];
+#ifndef VP_P3_NO_ROLL
+      if constexpr (TC / NA == 2) {
+        // rolling form: a weight block's registers are refilled with block + NA as soon as its MFMAs are issued, so the second
+        // read batch lands under the first batch's MFMAs
+        uint4 fa[NA];
+        u32x4 rn[NA];
+        patch3_frag_read<NA, TP, stage * WSTB, cc * PBUFB + pr * PW * 64, true>(aaddr, tb0[pc], fa, fb);
+        static_steps([&](auto tci) {
+          constexpr int tc = decltype(tci)::value;
+#pragma unroll
+          for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], fb[tp], acc[tc][tp]);
+          __builtin_amdgcn_sched_barrier(0);
+          rn[tc] = lds_rd128<stage * WSTB + (NA + tc) * 1024>(aaddr);
+          __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, NA>{});
+        static_steps([&](auto tci) {
+          constexpr int tc = decltype(tci)::value;
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA - 1 - tc) : "memory");
+          asm volatile("" : "+v"(rn[tc]));
+          const uint4 f = make_uint4(rn[tc].x, rn[tc].y, rn[tc].z, rn[tc].w);
+#pragma unroll
+          for (int tp = 0; tp < TP; ++tp) acc[NA + tc][tp] = mma16<T>(f, fb[tp], acc[NA + tc][tp]);
+          __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, NA>{});
+      } else
+#endif
 #pragma unroll
       for (int h = 0; h < TC / NA; ++h) {
         uint4 fa[NA];
@@ -205,7 +242,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
 
   constexpr int RINGB = NSTW * WSTB + 2 * PBUFB;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
-  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, Patch3TilePix<TW>{a, n, y0, x0}, c_base, blkA0, blkB0, acc, smem, bt, 0);
+  if (!(VP_P3_ABL & 8) || acc[0][0][0] == 1.2345f) staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, Patch3TilePix<TW>{a, n, y0, x0}, c_base, blkA0, blkB0, acc, smem, bt, 0);
 }
 
 template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int OCC, int NSTW = 3>
