@@ -13,6 +13,11 @@
 // an address class (pp & 3) have four different (px >> 2) & 3, so a 32-lane service group of a ds_read_b64 hits 32 distinct 8-byte
 // slots for every column shift.  Two chunks (K = 2 x 64 bytes per tap) per trip: channel counts are multiples of 64 (bf16) / 32 (f32).
 #include <stdlib.h>
+// outputs of this kernel are the perceptual trunk's full-resolution tensors (34-270 MB per launch): streamed stores (`nt`) in the
+// epilogue - batch 32: 8.25 -> 8.19 ms, every class of this file +1 %; for the other kernel families the hint is neutral (section 11)
+#ifndef VP_P3_NO_NT
+#define VP_NT_STORE 1
+#endif
 // VP_P3_ABL: build-time ablations of the loop for timing only (results are wrong): 1 no barrier, 2 no vmcnt wait, 4 no DMA in the
 // loop, 8 no epilogue, 16 no loop (make ablate3 ABL=n -> ../libvp_p3abl<n>.so, select with VP_LIB)
 #ifndef VP_P3_ABL

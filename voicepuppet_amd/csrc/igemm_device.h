@@ -110,8 +110,13 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
       const float4 e0 = reinterpret_cast<const float4*>(yp)[0], e1 = reinterpret_cast<const float4*>(yp)[1];
       v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w; v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
     }
+#ifdef VP_NT_STORE
+#pragma unroll
+    for (int e = 0; e < 8; ++e) __builtin_nontemporal_store(v[e], yp + e);
+#else
     reinterpret_cast<float4*>(yp)[0] = make_float4(v[0], v[1], v[2], v[3]);
     reinterpret_cast<float4*>(yp)[1] = make_float4(v[4], v[5], v[6], v[7]);
+#endif
   } else {
     bf16* yp = reinterpret_cast<bf16*>(a.Y) + off;
     if (a.accumulate) {
@@ -120,7 +125,12 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] += e[k];
     }
+#ifdef VP_NT_STORE
+    { const uint4 pk = Elem<bf16>::pack(v); __builtin_nontemporal_store(pk.x, reinterpret_cast<unsigned*>(yp)); __builtin_nontemporal_store(pk.y, reinterpret_cast<unsigned*>(yp) + 1);
+      __builtin_nontemporal_store(pk.z, reinterpret_cast<unsigned*>(yp) + 2); __builtin_nontemporal_store(pk.w, reinterpret_cast<unsigned*>(yp) + 3); }
+#else
     *reinterpret_cast<uint4*>(yp) = Elem<bf16>::pack(v);
+#endif
   }
 }
 
