@@ -173,17 +173,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch2_kernel(const IgemmArgs 
         for (int j = PC0; j < JP; ++j) issue_p(c + cc + 1, 1 - cc, j);
       }
       constexpr int NA = TC == 8 ? 4 : ((TC == 4 && OCC == 4) ? 2 : TC);
-      uint4 fb[TP];
-#pragma unroll
-      for (int h = 0; h < TC / NA; ++h) {
-        uint4 fa[NA];
-        if (h == 0) patch3_frag_read<NA, TP, stage * WSTB, cc * PBUFB + pr * PW * 64, true>(aaddr, tb0[pc], fa, fb);
-        else patch3_frag_read<NA, TP, stage * WSTB + NA * 1024, cc * PBUFB + pr * PW * 64, false>(aaddr, tb0[pc], fa, fb);
-#pragma unroll
-        for (int tc = 0; tc < NA; ++tc)
-#pragma unroll
-          for (int tp = 0; tp < TP; ++tp) acc[h * NA + tc][tp] = mma16<T>(fa[tc], fb[tp], acc[h * NA + tc][tp]);
-      }
+      patch_step_mma<T, TC, TP, NA, stage * WSTB, cc * PBUFB + pr * PW * 64, false>(aaddr, tb0[pc], acc);
     };
     static_steps(step, std::make_integer_sequence<int, NSTEP>{});
   }

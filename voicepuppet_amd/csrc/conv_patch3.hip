@@ -203,43 +203,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
       // eight weight blocks per wave: two read batches of four (16 fragment registers instead of 32); the 64-accumulator tile at
       // two blocks per CU (128 registers per lane): batches of two
       constexpr int NA = TC == 8 ? 4 : ((TC == 4 && OCC == 4) ? 2 : TC);
-      uint4 fb[TP];
-#ifndef VP_P3_NO_ROLL
-      if constexpr (TC / NA == 2) {
-        // rolling form: a weight block's registers are refilled with block + NA as soon as its MFMAs are issued, so the second
-        // read batch lands under the first batch's MFMAs
-        uint4 fa[NA];
-        u32x4 rn[NA];
-        patch3_frag_read<NA, TP, stage * WSTB, cc * PBUFB + pr * PW * 64, true>(aaddr, tb0[pc], fa, fb);
-        static_steps([&](auto tci) {
-          constexpr int tc = decltype(tci)::value;
-#pragma unroll
-          for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], fb[tp], acc[tc][tp]);
-          __builtin_amdgcn_sched_barrier(0);
-          rn[tc] = lds_rd128<stage * WSTB + (NA + tc) * 1024>(aaddr);
-          __builtin_amdgcn_sched_barrier(0);
-        }, std::make_integer_sequence<int, NA>{});
-        static_steps([&](auto tci) {
-          constexpr int tc = decltype(tci)::value;
-          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA - 1 - tc) : "memory");
-          asm volatile("" : "+v"(rn[tc]));
-          const uint4 f = make_uint4(rn[tc].x, rn[tc].y, rn[tc].z, rn[tc].w);
-#pragma unroll
-          for (int tp = 0; tp < TP; ++tp) acc[NA + tc][tp] = mma16<T>(f, fb[tp], acc[NA + tc][tp]);
-          __builtin_amdgcn_sched_barrier(0);
-        }, std::make_integer_sequence<int, NA>{});
-      } else
-#endif
-#pragma unroll
-      for (int h = 0; h < TC / NA; ++h) {
-        uint4 fa[NA];
-        if (h == 0) patch3_frag_read<NA, TP, stage * WSTB, cc * PBUFB + pr * PW * 64, true>(aaddr, tb0[pc], fa, fb);
-        else patch3_frag_read<NA, TP, stage * WSTB + NA * 1024, cc * PBUFB + pr * PW * 64, false>(aaddr, tb0[pc], fa, fb);
-#pragma unroll
-        for (int tc = 0; tc < NA; ++tc)
-#pragma unroll
-          for (int tp = 0; tp < TP; ++tp) acc[h * NA + tc][tp] = mma16<T>(fa[tc], fb[tp], acc[h * NA + tc][tp]);
-      }
+      patch_step_mma<T, TC, TP, NA, stage * WSTB, cc * PBUFB + pr * PW * 64, true>(aaddr, tb0[pc], acc);
     };
     static_steps(step, std::make_integer_sequence<int, 18>{});
   }

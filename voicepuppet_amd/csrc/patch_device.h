@@ -56,4 +56,48 @@ template <typename F, int... Is> __device__ __forceinline__ void static_steps(F&
   (f(std::integral_constant<int, Is>{}), ...);
 }
 
+// The MFMAs of one step (TC weight blocks x TP pixel blocks per wave; stage / buffer / tap offsets are the immediates AIMM, BIMM).
+// Weight blocks are read in batches of NA (register budget).  Two batches: rolling form - a block's registers are refilled with
+// block + NA as soon as its MFMAs are issued, so the second batch lands under the first batch's MFMAs (VP_P3_NO_ROLL: batch by batch).  ROLL: the 3x3 kernel (128x256 tile
+// 940 -> 970 TF); the 2x2-tap kernel measured 1.5 % slower with it
+template <typename T, int TC, int TP, int NA, int AIMM, int BIMM, bool ROLL>
+__device__ __forceinline__ void patch_step_mma(int aaddr, const int (&b0)[TP], f32x4 (&acc)[TC][TP]) {
+  uint4 fb[TP];
+#ifndef VP_P3_NO_ROLL
+  if constexpr (ROLL && TC / NA == 2) {
+    uint4 fa[NA];
+    u32x4 rn[NA];
+    patch3_frag_read<NA, TP, AIMM, BIMM, true>(aaddr, b0, fa, fb);
+    static_steps([&](auto tci) {
+      constexpr int tc = decltype(tci)::value;
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = mma16<T>(fa[tc], fb[tp], acc[tc][tp]);
+      __builtin_amdgcn_sched_barrier(0);
+      rn[tc] = lds_rd128<AIMM + (NA + tc) * 1024>(aaddr);
+      __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, NA>{});
+    static_steps([&](auto tci) {
+      constexpr int tc = decltype(tci)::value;
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA - 1 - tc) : "memory");
+      asm volatile("" : "+v"(rn[tc]));
+      const uint4 f = make_uint4(rn[tc].x, rn[tc].y, rn[tc].z, rn[tc].w);
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) acc[NA + tc][tp] = mma16<T>(f, fb[tp], acc[NA + tc][tp]);
+      __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, NA>{});
+    return;
+  }
+#endif
+  static_steps([&](auto hi) {
+    constexpr int h = decltype(hi)::value;
+    uint4 fa[NA];
+    patch3_frag_read<NA, TP, AIMM + h * NA * 1024, BIMM, h == 0>(aaddr, b0, fa, fb);
+#pragma unroll
+    for (int tc = 0; tc < NA; ++tc)
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) acc[h * NA + tc][tp] = mma16<T>(fa[tc], fb[tp], acc[h * NA + tc][tp]);
+  }, std::make_integer_sequence<int, TC / NA>{});
+}
+
+
 }  // namespace vp
