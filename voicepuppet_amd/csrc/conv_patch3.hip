@@ -211,7 +211,12 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
 
   constexpr int RINGB = NSTW * WSTB + 2 * PBUFB;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
-  if (!(VP_P3_ABL & 8) || acc[0][0][0] == 1.2345f) staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, Patch3TilePix<TW>{a, n, y0, x0}, c_base, blkA0, blkB0, acc, smem, bt, 0);
+#ifndef VP_P3_NO_FASTEPI
+  constexpr int NPASS16 = BC == 64 ? epi_passes16(BC, BP, WP, RINGB) : 0;    // 64-row tiles: +4 %; 128 rows: -8 %, 256 rows: +-0
+#else
+  constexpr int NPASS16 = 0;
+#endif
+  if (!(VP_P3_ABL & 8) || acc[0][0][0] == 1.2345f) staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS, NPASS16>(a, Patch3TilePix<TW>{a, n, y0, x0}, c_base, blkA0, blkB0, acc, smem, bt, 0);
 }
 
 template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int OCC, int NSTW = 3>

@@ -76,6 +76,13 @@ constexpr int epi_passes(int BC, int BP, int WP, int ring_bytes) {
   return WP;
 }
 
+// the same for the bf16-staged form of the epilogue (staged_epilogue, FASTBF)
+constexpr int epi_passes16(int BC, int BP, int WP, int ring_bytes) {
+  for (int np = 1; np <= WP; np *= 2)
+    if ((BP / np) * (BC * 2 + 16) + (BP / np) * 8 <= ring_bytes) return np;
+  return WP;
+}
+
 // finish 8 consecutive channels c0..c0+7 of one output pixel (offset `off`, BN group in the low byte of `ot`): bias, activation,
 // act'(ref) product, accumulate, one 16-byte store (two for f32)
 template <typename T>
@@ -168,9 +175,96 @@ __device__ __forceinline__ void direct_epilogue(const IgemmArgs& a, const long l
 // LDS, thread t sums column (channel) t % BC over its share of the rows - of the values AS STORED, i.e. rounded to T - into two
 // registers; after the last pass the NT / BC threads of a channel fold through LDS and the block writes one [2][channels]
 // partial per pixel tile for bn_finalize_kernel.  The tensor is never re-read.
-template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, bool STATS = false, typename PixFn>
+//
+// NPASS16 > 0 (bf16 kernels without statistics: the 3x3 patch kernel's perceptual-trunk launches): when the launch has no reference
+// product, no accumulation and a bf16 output, bias + activation + rounding are applied in the lane's own registers - the same
+// operations in the same order, so the stored bits are the same - and the tile is staged as bf16: half the LDS bytes, NPASS16
+// passes instead of NPASS, the store loop a plain copy; the fused max pool takes the maximum of the rounded values (rounding is monotonic).
+template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, bool STATS = false, int NPASS16 = 0, typename PixFn>
 __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn& pixfn, int c_base, int blkA0, int blkB0,
                                                 f32x4 (&acc)[TC][TP], char* smem, int pt = 0, int cls = 0) {
+  if constexpr (NPASS16 > 0 && sizeof(T) == 2 && !STATS) {
+    if (!a.ref && !a.accumulate && !a.y_f32 && (a.out_act == ACT_NONE || a.out_act == ACT_RELU)) {
+      constexpr int PITCHB = BC * 2 + 16, CGB = BC / 8, RPB = BP / NPASS16;
+      static_assert(RPB % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
+      const int tid = threadIdx.x, lane = tid & 63;
+      long long* otab = reinterpret_cast<long long*>(smem + RPB * PITCHB);
+#pragma unroll
+      for (int ps = 0; ps < NPASS16; ++ps) {
+        __syncthreads();
+        if (tid < RPB) otab[tid] = pixfn(ps * RPB + tid);
+        if (blkB0 * 16 >= ps * RPB && blkB0 * 16 < (ps + 1) * RPB) {
+#pragma unroll
+          for (int tc = 0; tc < TC; ++tc) {
+            const int ch = tile_chan0(a.rowperm, blkA0 + tc, lane >> 4);
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias && c_base + ch < a.Cout) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) b4[e] = a.bias[c_base + ch + e];
+            }
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) {
+              const int row = (blkB0 + tp) * 16 + (lane & 15) - ps * RPB;
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] = acc[tc][tp][e];
+                if (a.bias) v[e] += b4[e];
+                if (a.out_act != ACT_NONE) v[e] = act_apply(a.out_act, v[e]);
+              }
+              uint2 pk;
+              pk.x = Elem<bf16>::pack2(v[0], v[1]); pk.y = Elem<bf16>::pack2(v[2], v[3]);
+              *reinterpret_cast<uint2*>(smem + row * PITCHB + ch * 2) = pk;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __syncthreads();
+        bool store_y = true;
+        if constexpr (pix_has_pool<PixFn>::value) store_y = !(a.pool_out != nullptr && a.pool_only);
+        if (store_y)
+          for (int idx = tid; idx < RPB * CGB; idx += NT) {
+            const int p = idx / CGB, cgp = idx - p * CGB;
+            const long long ot = otab[p];
+            const int c0 = c_base + cgp * 8;
+            if (ot < 0 || c0 >= a.Cout) continue;
+            const uint4 pk = *reinterpret_cast<const uint4*>(smem + p * PITCHB + cgp * 16);
+            unsigned* yp = reinterpret_cast<unsigned*>(reinterpret_cast<bf16*>(a.Y) + (size_t)(ot >> 8) + c0);
+#ifdef VP_NT_STORE
+            __builtin_nontemporal_store(pk.x, yp); __builtin_nontemporal_store(pk.y, yp + 1);
+            __builtin_nontemporal_store(pk.z, yp + 2); __builtin_nontemporal_store(pk.w, yp + 3);
+#else
+            *reinterpret_cast<uint4*>(yp) = pk;
+#endif
+          }
+        if constexpr (pix_has_pool<PixFn>::value) {
+          if (a.pool_out != nullptr) {
+            static_assert(RPB % 32 == 0, "a pass must hold whole pairs of tile rows");
+            constexpr int PR = RPB / 4;
+            for (int idx = tid; idx < PR * CGB; idx += NT) {
+              const int pp = idx / CGB, cgp = idx - pp * CGB;
+              const int pyl = pp >> 3, pxl = pp & 7;
+              const int c0 = c_base + cgp * 8;
+              const long long po = pixfn.pool(ps * (RPB / 32) + pyl, pxl);
+              if (po < 0 || c0 >= a.Cout) continue;
+              const int r00 = pyl * 32 + pxl * 2;
+              float m[8];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int rr = r00 + (k >> 1) * 16 + (k & 1);
+                float v[8];
+                Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(smem + rr * PITCHB + cgp * 16), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = k == 0 ? v[e] : fmaxf(m[e], v[e]);
+              }
+              *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(a.pool_out) + po + c0) = Elem<bf16>::pack(m);
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   constexpr int PITCH = BC * 4 + 16;                 // bytes per pixel row (+16: conflict-free b128 writes)
   constexpr int CG = BC / 8;                         // 8-channel groups per row
   constexpr int RP = BP / NPASS;                     // pixel rows staged per pass (keeps the tile inside the ring's LDS)
