@@ -107,7 +107,7 @@ int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream);
 /* vp_pixrefer_backward runs the two (independent) halves CONCURRENTLY: the discriminator-loss pass on a HIP stream the handle
  * owns, forked from and joined into `stream` with events (no host blocking; bit-identical results).  The same for a host with
  * work of its own in between: _fork schedules the discriminator-loss pass (it starts inside stage 0 of the generator backward,
- * behind the generator-loss pass through the discriminator - or at once with vp_tune("d_backward_fork", 0)), _join makes `stream`
+ * behind the generator-loss pass through the discriminator - or at once with vp_pixrefer_set_option(h, "d_backward_fork", 0)), _join makes `stream`
  * wait for it; grads_d is final after the join, which may come after any stage (the later, the more of the pass is hidden).  (VP_NO_OVERLAP=1 in the environment at create time: both run
  * on `stream`, one after the other.) */
 int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream);
@@ -119,6 +119,11 @@ void* vp_pixrefer_side_stream(vp_pixrefer_t* h);
 /* Streams a training step is spread over: 4 (default) or 3.  A host that runs a busy stream of its own beside the step (an input
  * prefetcher) asks for 3: the device has few hardware queues, a fifth busy stream shares one with an executor stream. */
 int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n);
+/* Schedule options of ONE plan (no reference counterpart: the TF graph has one executor): "overlap" 0 / 1 (the whole step on `stream`
+ * / spread over the executor's streams, default 1), "d_backward_fork" 0..2 (where vp_pixrefer_backward starts the discriminator-loss
+ * pass, default 2), "d_beside_vgg" 0 / 1 (default 1).  Per handle: two plans in one process do not change each other's schedule.  The
+ * vp_tune keys of the same names only set the defaults a plan copies at vp_pixrefer_create.  Bit-identical results under every setting. */
+int vp_pixrefer_set_option(vp_pixrefer_t* h, const char* key, int value);
 /* The same pass in vp_pixrefer_backward_g_stages() = 3 consecutive stages (stage < 0: all).  After stage s a contiguous
  * range of the generator gradient arena is final (0: from generator/merged_decoder_5 to the end; 1: from
  * generator/merged_encoder_2 up to merged_decoder_5; 2: the rest), so a data-parallel host can start that bucket's

@@ -13,8 +13,7 @@ for overlap in (True, False):
   eng = PixReferEngine(n, 256, 64, 64, dtype="bf16", training=True)
   eng.load_params(eng.random_params(seed=0))
   eng.profile(False)
-  from voicepuppet_amd import _lib
-  _lib.check(_lib.lib().vp_tune(b"overlap", 1 if overlap else 0), "vp_tune overlap")
+  eng.set_option("overlap", 1 if overlap else 0)
   g = torch.Generator(device=dev).manual_seed(1)
   for s in range(steps):
     batch = [torch.rand(n, 256, 256, c, device=dev, generator=g) for c in (6, 6, 3, 3)]
@@ -22,7 +21,6 @@ for overlap in (True, False):
   torch.cuda.synchronize()
   res.append((eng.params_g.clone(), eng.params_d.clone(), eng.losses()))
   print("overlap" if overlap else "single stream", {k: round(v, 5) for k, v in res[-1][2].items()})
-_lib.check(_lib.lib().vp_tune(b"overlap", 1), "vp_tune overlap")
 ok = all(torch.isfinite(t).all().item() for r in res for t in r[:2])
 same = torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 print("finite:", ok, " bit-identical after %d steps:" % steps, same)

@@ -208,7 +208,7 @@ def full_width_batch(panels, bg, nsamp=4):
 def frame_pack():
   """Input-pipeline fixture: uint8 triptych frames + crops -> the four packed float tensors, computed by the
   host path (PIL bilinear on float planes standing in for cv2.resize, generator.py:956-1019)."""
-  from voicepuppet_amd.generator.device_pipeline import host_pack_reference
+  from oracle.input_pack_ref import pack_frames_ref as host_pack_reference
   S, N = 32, 4
   rng = np.random.default_rng(31)
   yy, xx = np.mgrid[0:S, 0:3 * S]

@@ -61,7 +61,8 @@ def test_device_dataset_of_the_training_launcher(monkeypatch, tmp_path):
   host pipeline's arithmetic (pack_sample over the cropped / resized triptychs, PIL standing in for cv2.resize: 2e-6) on the same decoded
   frames and crops, in order when the shuffle buffer is 1; pinned ring buffers are reused without corrupting batches in flight."""
   from voicepuppet_amd.generator.generator import PixReferDataGenerator
-  from voicepuppet_amd.generator.device_pipeline import host_pack_reference, draw_crop
+  from voicepuppet_amd.generator.device_pipeline import draw_crop
+  from oracle.input_pack_ref import pack_frames_ref as host_pack_reference
   import random
   cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "params.yml")
   S, N, B = 64, 2, 7
@@ -88,3 +89,34 @@ def test_device_dataset_of_the_training_launcher(monkeypatch, tmp_path):
       want = host_pack_reference(ex, cur, crops, S)
       for g, w in zip(got, want):
         assert float(np.abs(g[j].cpu().numpy() - w).max()) < 2e-6
+
+
+def test_pinned_sources_are_not_overwritten_under_a_busy_device():
+  """a source that rewrites a short ring of PINNED buffers while the host runs far ahead of the device (nothing reads a
+  loss, the device is kept busy) must not tear batches whose H2D copies have only been enqueued: the prefetcher host-waits for the
+  copies of batch k-2 before it asks the source for batch k."""
+  from voicepuppet_amd.generator.device_pipeline import FramePrefetcher
+  N, S, B, R = 2, 256, 24, 3
+  ring = [(torch.empty(N, S, 3 * S, 3, dtype=torch.uint8).pin_memory(), torch.empty(N, S, 3 * S, 3, dtype=torch.uint8).pin_memory(),
+           torch.empty(N, 2, 3, dtype=torch.int32).pin_memory()) for _ in range(R)]
+
+  def source():
+    for k in range(B):
+      ex, cur, crops = ring[k % R]
+      ex.fill_(k + 1); cur.fill_(2 * k + 3)             # every byte of a batch carries the batch number
+      crops.copy_(torch.tensor([[[0, 0, S], [0, 0, S]]] * N, dtype=torch.int32))
+      yield ring[k % R]
+
+  load = torch.empty(8192, 8192, device="cuda")
+  pf = FramePrefetcher(source(), N, S)
+  sums = []
+  for k, o in enumerate(pf):
+    for _ in range(40):
+      load.mul_(1.0001)                                 # ~ms of device work per batch on the consumer's stream, no host sync
+    sums.append((o[0][..., :3].amin(), o[0][..., :3].amax(), o[2].amin(), o[2].amax()))
+  torch.cuda.synchronize()
+  assert len(sums) == B
+  for k, (a0, a1, t0, t1) in enumerate(sums):
+    e, c = np.float32(k + 1) / np.float32(255.0), np.float32(2 * k + 3) / np.float32(255.0)
+    assert float(a0) == float(a1) == float(e), (k, float(a0), float(a1), float(e))     # example frame of batch k, untorn
+    assert float(t0) == float(t1) == float(c), (k, float(t0), float(t1), float(c))

@@ -53,8 +53,6 @@ struct IgemmArgs {
   float* partial;           // [nclass][splitk][P][CoutPad] when splitk > 1
   int vec_epi;              // staged (LDS) epilogue with 16-byte row stores (set by the launcher)
   int fastk;                // buffer-descriptor loader with scalar K stepping (set by the launcher)
-  int wide;                 // 128-byte K chunks: packed weights [chunk][row][64 k], igemm_wsw_kernel (plan-time decision)
-  int direct_epi;           // store straight from the accumulators (needs rowperm; set by the launcher, opt-in)
   int rowperm;              // packed weight rows are permuted inside every 64-row block (PackDesc::perm): MFMA tile t, row 4q+e of a
                             // block holds channel 32*(t>>1) + 8q + 4*(t&1) + e, so a lane ends with 2 x 8 consecutive channels per pixel
   int xcd_remap;            // conv_patch3.hip: pixel tiles dealt to the XCDs in contiguous runs (set by the launcher)

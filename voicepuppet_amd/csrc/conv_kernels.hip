@@ -10,8 +10,9 @@
 //   wgrad_kernel       bwd-weight: K = pixels (the strided NHWC dim): register loader + 8x8 transposes into LDS planes,
 //                      division-free padded-grid K walk, split-K slabs + deterministic reduces
 //   igemm_splitk_reduce_kernel, wgrad_reduce_kernel, wgrad_reduce_wave_kernel
-// Not in this library: the kernels that were measured slower live in experiments/igemm_experiments.inc and conv_db.hip and are only
-// compiled by `make experiments` (-DVP_EXPERIMENTS).  igemm_kernel (register loader with the deferred-BN prologue) serves the single-op API.
+// The kernel variants that were measured slower (register-operand loader, resident-weight persistent tiles, 128-byte K chunks,
+// register-double-buffered 256x256 tile, direct epilogue: EXPERIMENTS.md) were deleted in round 4; `git log -- voicepuppet_amd/csrc/conv_db.hip`
+// and `.../experiments/igemm_experiments.inc` have them.  igemm_kernel (register loader with the deferred-BN prologue) serves the single-op API.
 //
 // LDS plane layout of the register-loader kernels (igemm_kernel, wgrad_kernel): a tile of ROWS rows x 64 bytes of K is stored as 4
 // planes (one per 16-byte k-piece g), plane g = ROWS consecutive 16-byte slots.  MFMA lane (i = lane&15, g = lane>>4) reads
@@ -514,18 +515,6 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
     return;
   }
 #endif
-#ifdef VP_EXPERIMENTS
-  if constexpr (STAGED && !STATS && TC % 4 == 0) {
-    if (a.direct_epi) {
-      long long* otab = reinterpret_cast<long long*>(smem + NST * BUF * 16 + 64);     // behind the ring and the tap table
-      const LinearPix pix{a, cls, p_base, P};
-      for (int rrow = tid; rrow < BP; rrow += NT) otab[rrow] = pix(rrow);
-      __syncthreads();
-      direct_epilogue<T, TC, TP>(a, otab, c_base, blkA0, blkB0, acc);
-      return;
-    }
-  }
-#endif
   if (STAGED) {
     constexpr int RINGB = NST * BUF * 16;
     constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
@@ -715,26 +704,11 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
   }
   return;
 #endif
-#ifdef VP_EXPERIMENTS
-  if constexpr (!STATS && TC % 4 == 0) {
-    if (a.direct_epi) {
-      long long* otab = reinterpret_cast<long long*>(smem + NST * BUF * 16 + 64);
-      const LinearPix pix{a, cls, p_base, P};
-      for (int rrow = tid; rrow < BP; rrow += NT) otab[rrow] = pix(rrow);     // the producers are idle by now: they help
-      __syncthreads();
-      if (!producer) direct_epilogue<T, TC, TP>(a, otab, c_base, blkA0, blkB0, acc);
-      return;
-    }
-  }
-#endif
   constexpr int RINGB = NST * BUF * 16;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
   staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
 }
 
-#ifdef VP_EXPERIMENTS
-#include "experiments/igemm_experiments.inc"
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // conv_cin8_kernel: the first layers of the three nets (3- and 6-channel images padded to 8: VGG conv1_1, discriminator layer_1,
@@ -1710,77 +1684,12 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
     IgemmArgs b = a;
     b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
     // register-direct epilogue: measured SLOWER than the LDS-staged one (64-byte store segments vs 256-byte rows): opt-in
-#ifdef VP_EXPERIMENTS
-    static const bool direct_on = getenv("VP_DIRECT_EPI") != nullptr;
-    b.direct_epi = (direct_on && a.rowperm && b.vec_epi) ? 1 : 0;
-#else
-    b.direct_epi = 0;
-#endif
     // scalar-stepped loader: every 64-byte K chunk inside one tap and one source tensor, sources below the 2 GiB lane-offset range
     constexpr int KCE = 16 * 4 / (int)sizeof(T);
     const size_t xb0 = (size_t)a.N * a.Hin * a.Win * a.x.C[0] * sizeof(T), xb1 = (size_t)a.N * a.Hin * a.Win * a.x.C[1] * sizeof(T);
     static const bool fast_on = !getenv("VP_NO_FASTK");
     b.fastk = (fast_on && a.Cin % KCE == 0 && a.x.C[0] % KCE == 0 && a.x.C[1] % KCE == 0 && a.x.C[0] + a.x.C[1] == a.Cin &&
                xb0 < 0x70000000ull && xb1 < 0x70000000ull) ? 1 : 0;
-#ifdef VP_EXPERIMENTS
-    // 128-byte K chunks (plan-time decision: the packed weights are laid out for it)
-    if (a.wide) {
-      if constexpr (((BC + BP) / 8) % 4 == 0 && NW <= 8 && TC % 4 == 0) {
-        if (b.vec_epi && a.splitk == 1) {
-          constexpr int NSTQ = (BC == 64 && BP == 128) ? 3 : 2;
-          constexpr int RB = NSTQ * 8 * (BC + BP) * 16;
-          constexpr int NPE = epi_passes(BC, BP, WP, RB);
-          size_t sm = RB + 64;
-          const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
-          if (se > sm) sm = se;
-          auto kern = b.bn_part ? igemm_wsw_kernel<T, WC, WP, TC, TP, NSTQ, true> : igemm_wsw_kernel<T, WC, WP, TC, TP, NSTQ, false>;
-          if (sm > 64 * 1024) {
-            static bool done[2] = {false, false};
-            if (!done[b.bn_part ? 1 : 0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done[b.bn_part ? 1 : 0] = true; }
-          }
-          hipLaunchKernelGGL(kern, grid, dim3((NW + 4) * 64), sm, st, b);
-          return hipGetLastError();
-        }
-      }
-      return hipErrorInvalidValue;     // a wide plan must run on the wide kernel
-    }
-#else
-    if (a.wide) return hipErrorInvalidValue;   // 128-byte-chunk plans exist only in the experiments build
-#endif
-#ifdef VP_EXPERIMENTS
-    // resident-weight persistent kernel for 64-channel outputs with K <= 576 (conv1_2 and the 64-channel backward-data passes)
-    if constexpr (BC == 64 && BP == 128) {
-      static const bool wsr_on = getenv("VP_WSR") != nullptr;   // opt-in: measured SLOWER (conv1_2 0.66 vs 0.53 ms) - one 12-wave block per CU
-                                                                // leaves 8 MFMAs per wave between barriers, too little to hide the ds_read latency
-      constexpr int KCE2 = 16 * 4 / (int)sizeof(T);
-      const int nchunk = a.Kpad / KCE2;
-      if (wsr_on && b.vec_epi && b.fastk && !b.bn_part && a.splitk == 1 && a.CoutPad == 64 && nchunk * 4096 <= 72 * 1024 && P >= 64 * 256) {
-        constexpr int WPR = 8, TPR = 2, NSTR = 3, BPR = WPR * TPR * 16;
-        constexpr int NPE = epi_passes(64, BPR, WPR, VP_REGB_EPI_BYTES);
-        const size_t epib = (size_t)(BPR / NPE) * (64 * 4 + 16) + (BPR / NPE) * 8;
-        const size_t sm = (size_t)nchunk * 4096 + (size_t)NSTR * 4 * BPR * 16 + ((epib + 15) & ~(size_t)15) + 64;
-        const int ntile = (P + BPR - 1) / BPR;
-        int gx = 256 / a.nclass;
-        if (gx > ntile) gx = ntile;
-        dim3 g2(gx, 1, a.nclass);
-        auto kern = igemm_wsr_kernel<T, WPR, TPR, NSTR, false>;   // (tiles are 256 pixels here: the plan's statistics indexing assumes 128)
-        static bool attr_done = false;
-        if (!attr_done) {
-          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          attr_done = true;
-        }
-        hipLaunchKernelGGL(kern, g2, dim3((WPR + 4) * 64), sm, st, b);
-        return hipGetLastError();
-      }
-    }
-#endif
-#ifdef VP_EXPERIMENTS
-    // register-double-buffered kernel for the 128-accumulator tiles (256x256, 128x512): conv_db.hip
-    if constexpr (NW == 8 && TC == 8 && TP == 4) {
-      static const bool db_on = getenv("VP_DB") != nullptr;   // opt-in: measured no faster than the wave-specialised 256x256 kernel (round 2)
-      if (db_on && b.vec_epi && b.fastk && a.splitk == 1) return launch_igemm_db(b, sizeof(T) == 2, BC, grid, st);
-    }
-#endif
     // wave-specialised kernel, per tile shape (bit = launch_igemm cfg index): measured gains for 128x128 (cfg 0), 64x128 (cfg 1), 256x256 (cfg 7); 128x256 is faster without
     static const int ws_cfgs = getenv("VP_WS_CFG") ? atoi(getenv("VP_WS_CFG")) : ((1 << 0) | (1 << 1) | (1 << 7));
     constexpr int my_cfg = (BC == 128 && BP == 128) ? 0 : (BC == 64 && BP == 128) ? 1 : (BC == 128 && BP == 256) ? 6 : (BC == 256 && BP == 256) ? 7 :
@@ -1799,19 +1708,6 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         return hipGetLastError();
       }
     }
-#ifdef VP_EXPERIMENTS
-    static const int regb_on = getenv("VP_REGB") ? atoi(getenv("VP_REGB")) : 0;   // measured slower (round 1): opt-in experiment
-    if constexpr ((BC / 16) % NW == 0) {
-      if (regb_on && b.vec_epi && b.fastk && a.splitk == 1 && !b.bn_part) {
-        constexpr int NPE = epi_passes(BC, BP, WP, VP_REGB_EPI_BYTES);
-        size_t sm = 3 * 4 * BC * 16 + 64;
-        const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
-        if (se > sm) sm = se;
-        hipLaunchKernelGGL((igemm_regb_kernel<T, WC, WP, TC, TP>), grid, dim3(NW * 64), sm, st, b);
-        return hipGetLastError();
-      }
-    }
-#endif
     g_prof_family = "dma";
     if (b.vec_epi && b.bn_part) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, true>), grid, dim3(NW * 64), smem, st, b);
     else if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
@@ -1824,32 +1720,6 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-#ifdef VP_EXPERIMENTS
-template <typename T, int WC, int WP, int TC, int TP>
-static hipError_t launch_patch_cfg(const IgemmArgs& a, hipStream_t st) {
-  constexpr int BC = WC * TC * 16;
-  const int tiles = a.N * ((a.Hg + 7) / 8) * ((a.Wg + 15) / 16);
-  dim3 grid(tiles, a.CoutPad / BC, 1);
-  size_t smem = (3 * 4 * BC + 2 * 4 * 224) * 16;
-  const size_t epi = (size_t)64 * (BC * 4 + 16) + 128 * 8;
-  if (smem < epi) smem = epi;
-  IgemmArgs b = a;
-  b.vec_epi = 1;
-  hipLaunchKernelGGL((igemm_patch_kernel<T, WC, WP, TC, TP>), grid, dim3(256), smem, st, b);
-  return hipGetLastError();
-}
-
-// stride-1 convs whose channel chunks stay inside one tap, with the 16-byte row-store epilogue available
-static bool patch_ok(const IgemmArgs& a, int kc) {
-  // measured 3-6 % SLOWER than the gather-per-tap kernel on MI355X (round 1): the weight stream, not the pixel
-  // operand, saturates the LDS-DMA path; kept as an opt-in experiment
-  static const bool on = getenv("VP_PATCH") != nullptr;
-  return on && a.zeros && a.nclass == 1 && a.splitk == 1 && a.sh == 1 && a.sw == 1 && a.os == 1 && a.ntaps > 1 && a.x.C[1] == 0 &&
-         a.Cin % kc == 0 && a.Cin == a.x.C[0] && a.Wg >= 16 && a.Hg >= 8 && a.Cout % 8 == 0 && a.ldY % 8 == 0 &&
-         !a.x.aff_a[0] && a.x.act == ACT_NONE && a.Hof == a.Hg && a.Wof == a.Wg;
-}
-
-#endif
 
 template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int cfg, hipStream_t st) {
   hipError_t e;
@@ -1964,16 +1834,9 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
                    es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
     return launch_igemm_patch(a, sizeof(T) == 2, pbc, pbp, st);
   }
-#ifdef VP_EXPERIMENTS
-  const bool use_patch = (cfg == 0 || cfg == 1) && patch_ok(a, 4 * Elem<T>::E);
-#else
   const bool use_patch = false;
-#endif
   ProfScope prof(use_patch ? "patch" : "igemm", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
                  es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
-#ifdef VP_EXPERIMENTS
-  if (use_patch) return cfg == 0 ? launch_patch_cfg<T, 2, 2, 4, 4>(a, st) : launch_patch_cfg<T, 1, 4, 4, 2>(a, st);
-#endif
   switch (cfg) {
     case 0: e = launch_igemm_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 ch x 128 px
     case 1: e = launch_igemm_cfg<T, 1, 4, 4, 2>(a, st); break;   //  64 ch x 128 px
@@ -1984,9 +1847,6 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     case 6: e = launch_igemm_cfg<T, 2, 4, 4, 4>(a, st); break;   // 128 ch x 256 px, 8 waves
     case 7: e = launch_igemm_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 ch x 256 px, 8 waves
     case 8: e = launch_igemm_cfg<T, 1, 4, 4, 4>(a, st); break;   //  64 ch x 256 px, 4 waves
-#ifdef VP_EXPERIMENTS
-    case 9: e = launch_igemm_cfg<T, 1, 8, 8, 4>(a, st); break;   // 128 ch x 512 px, 8 waves (conv_db.hip)
-#endif
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -2055,10 +1915,6 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
   switch (cfg) {
     case 0: e = launch_wgrad_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 rows x 128 cols
     case 1: e = launch_wgrad_cfg<T, 2, 2, 4, 2>(a, st); break;   // 128 rows x  64 cols
-#ifdef VP_EXPERIMENTS
-    case 3: e = launch_wgrad_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 rows x 256 cols, 8 waves (VP_WGBIG: measured no faster)
-    case 4: e = launch_wgrad_cfg<T, 2, 4, 8, 2>(a, st); break;   // 256 rows x 128 cols, 8 waves
-#endif
     case 2: e = launch_wgrad_cfg<T, 4, 1, 2, 1>(a, st); break;   // 128 rows x  16 cols
     case 5: case 6: {                                               // 256 / 128 rows x 128 cols, LDS-DMA + transpose reads (wgrad_tr.hip; bf16, plain operands)
       const bool plain = a.zeros && !a.g.aff_a[0] && !a.g.aff_a[1] && a.g.act == ACT_NONE && !a.d.aff_a[0] && !a.d.aff_a[1] && a.d.act == ACT_NONE;

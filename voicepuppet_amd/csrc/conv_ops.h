@@ -39,13 +39,6 @@ inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
     if (rows % bc == 0) return force;
   }
   if (P >= 96) {
-#ifdef VP_EXPERIMENTS
-    // 128-accumulator tiles on the register-double-buffered kernel (one 8-wave block per CU): VP_DBTILE bit 0: 256x256, bit 1: 128x512
-    static const int dbt = getenv("VP_DBTILE") ? atoi(getenv("VP_DBTILE")) : 0;
-    static const int dbk = getenv("VP_DB_MINK") ? atoi(getenv("VP_DB_MINK")) : 512;
-    if ((dbt & 1) && rows % 256 == 0 && P >= 256 * 256 && Kpad >= dbk) return 7;
-    if ((dbt & 2) && rows % 128 == 0 && rows % 256 != 0 && P >= 256 * 512 && Kpad >= dbk) return 9;
-#endif
     // 256x256 runs one block per CU: its prologue / epilogue are exposed, only long K loops amortise them
     if ((big & 2) && rows % 256 == 0 && P >= 256 * 256 && Kpad >= 4096) return 7;
     if ((big & 1) && rows % 128 == 0 && P >= 256 * 512) return 6;
@@ -121,24 +114,6 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   p.pack.rows_pad = a.wp_rows;
   p.pack.Kpad = a.Kpad;
   p.pack.kc = kc_elems(is_bf16);
-  p.pack_elems = (size_t)a.nclass * a.wp_rows * a.Kpad;
-}
-
-// 128-byte K chunks (igemm_wsw_kernel): a plan-time decision because the packed weights are laid out for it, so everything the
-// launcher needs must hold here.  srcs_ok: every source tensor's channel count is a multiple of the wide chunk (64 bf16 / 32 f32).
-inline bool plan_wide_eligible(const IgemmPlan& p, int is_bf16, bool srcs_ok, bool prologue_free) {
-  static const int wide_cfgs = getenv("VP_WIDE_CFG") ? atoi(getenv("VP_WIDE_CFG")) : 0;
-  const IgemmArgs& a = p.a;
-  const int kcw = 2 * kc_elems(is_bf16);
-  return ((wide_cfgs >> p.cfg) & 1) && prologue_free && srcs_ok && a.splitk == 1 && a.Cout % 8 == 0 && a.Cin % kcw == 0;
-}
-inline void plan_make_wide(IgemmPlan& p, int is_bf16) {
-  IgemmArgs& a = p.a;
-  const int kcw = 2 * kc_elems(is_bf16);
-  a.wide = 1;
-  a.Kpad = round_up(a.ntaps * a.Cin, kcw);
-  p.pack.Kpad = a.Kpad;
-  p.pack.kc = kcw;
   p.pack_elems = (size_t)a.nclass * a.wp_rows * a.Kpad;
 }
 

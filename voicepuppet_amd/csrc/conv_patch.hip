@@ -49,7 +49,7 @@ struct PatchTilePix {
 };
 
 // fragment reads behind __restrict__ parameters: keeps hipcc from draining vmcnt in front of LDS reads that may alias a pending
-// LDS-DMA (conv_db.hip has the story); the counted vmcnt + barrier of the loop is what orders them
+// LDS-DMA (EXPERIMENTS.md, "double-buffered register fragments", has the story); the counted vmcnt + barrier of the loop is what orders them
 template <int TC, int TP>
 __device__ __forceinline__ void patch_frag_read(const uint4* __restrict__ pa, const char* __restrict__ pbuf, const int (&boff)[TP],
                                                 uint4 (&fa)[TC], uint4 (&fb)[TP]) {

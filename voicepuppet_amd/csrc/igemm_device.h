@@ -1,4 +1,4 @@
-// Device-side building blocks shared by the LDS-DMA implicit-GEMM kernels (conv_kernels.hip, conv_db.hip): the swizzled 16-row block
+// Device-side building blocks shared by the LDS-DMA implicit-GEMM kernels (conv_kernels.hip): the swizzled 16-row block
 // image, the LDS-DMA wrappers (flat and buffer-descriptor forms) and the staged LDS epilogue with 16-byte row stores.
 #pragma once
 #include "conv_args.h"
@@ -141,35 +141,6 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
   }
 }
 
-#ifdef VP_EXPERIMENTS
-// Direct epilogue (opt-in, IgemmArgs::direct_epi; measured slower than the staged one): with the permuted weight rows a lane's accumulators ARE two runs of 8 consecutive channels
-// per pixel and 64-row block, so the tile needs no LDS round trip: per pixel tile the lane finishes and stores its 16-byte runs
-// straight from registers (the four lanes of a pixel write 64 contiguous bytes per store).  Only the per-row output offsets come
-// from LDS (`otab`, BP entries computed cooperatively: they need two integer divisions each).
-template <typename T, int TC, int TP>
-__device__ __forceinline__ void direct_epilogue(const IgemmArgs& a, const long long* otab, int c_base, int blkA0, int blkB0,
-                                                f32x4 (&acc)[TC][TP]) {
-  static_assert(TC % 4 == 0, "whole 64-row blocks per wave");
-  const int lane = threadIdx.x & 63, q = lane >> 4;
-#pragma unroll
-  for (int tp = 0; tp < TP; ++tp) {
-    const long long ot = otab[(blkB0 + tp) * 16 + (lane & 15)];
-    if (ot < 0) continue;
-#pragma unroll
-    for (int hb = 0; hb < TC / 4; ++hb)
-#pragma unroll
-      for (int hi = 0; hi < 2; ++hi) {
-        const int c0 = c_base + ((blkA0 >> 2) + hb) * 64 + hi * 32 + 8 * q;
-        if (c0 >= a.Cout) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[hb * 4 + hi * 2][tp][e]; v[4 + e] = acc[hb * 4 + hi * 2 + 1][tp][e]; }
-        epi_store8<T>(a, ot, c0, (size_t)(ot >> 8) + c0, v);
-      }
-  }
-}
-
-#endif
 
 // STATS (a batch-normalised layer): the epilogue also produces the layer's batch statistics.  While a pass's f32 tile sits in
 // LDS, thread t sums column (channel) t % BC over its share of the rows - of the values AS STORED, i.e. rounded to T - into two

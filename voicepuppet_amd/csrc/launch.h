@@ -17,7 +17,6 @@ hipError_t launch_igemm_smallp(const IgemmArgs& a, int is_bf16, hipStream_t st);
 struct SmallPArgs;
 hipError_t launch_smallp(const SmallPArgs& s, int is_bf16, hipStream_t st);                                         // conv_smallp.hip (fused batch-norm forms)
 hipError_t launch_smallp_fused(const SmallPArgs& s, int is_bf16, hipStream_t st);                                   // ... with the per-launch profile record (conv_kernels.hip)
-hipError_t launch_igemm_db(const IgemmArgs& b, int is_bf16, int bc, dim3 grid, hipStream_t st);   // conv_db.hip
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
 bool wgrad_mm_eligible(const WgradArgs& a, int cfg);                                                                                      // wgrad_mm.hip
 hipError_t launch_wgrad_mm(const WgradArgs& a, int cfg, hipStream_t st);

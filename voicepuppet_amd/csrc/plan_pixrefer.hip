@@ -65,7 +65,6 @@ struct Tens {
   int producer = -1;          // layer that writes this tensor (-1: network input / pool)
   int n_bwd_consumers = 0;    // layers whose backward-data pass writes into dz
   int dz_writes = 0;          // ... of which have run in the current backward pass
-  bool dz_on_branch = false;  // the first gradient contribution of the pass was issued on the branch stream
   bool bn_bwd_done = false;   // the batch-norm backward of this tensor ran inside the last writer's launch (conv_smallp.hip, SP_BWD_BN)
   size_t elems() const { return (size_t)N * H * W * C; }
 };
@@ -141,9 +140,11 @@ struct vp_pixrefer {
   hipEvent_t ev_b2join;
   bool use_b2;                     // vp_pixrefer_use_streams: false = the backward pass keeps to three streams (the host runs a stream of its own)
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
-  hipEvent_t ev_skip;              // generator backward: the skip-connection data gradients issued on the branch stream so far are done
   hipEvent_t ev_upd_b, ev_upd_m;   // fused update: a generator bucket's weight gradients (branch stream) / data gradients (caller's stream) are done
   bool overlap, forked;
+  bool ov_on;                 // vp_pixrefer_set_option("overlap"): spread the step over the executor's streams (false: everything on the caller's)
+  int dfork_point;            // ... ("d_backward_fork"): where vp_pixrefer_backward starts the discriminator-loss pass on the side stream (0 / 1 / 2)
+  bool dsplit_on;             // ... ("d_beside_vgg"): discriminator passes on the branch stream beside the VGG passes
   // vp_tune("phase_marks", 1): HIP events on the caller's stream at the phase boundaries of a step (vp_pixrefer_phase_ms)
   hipEvent_t mark[64];
   int nmark;
@@ -295,12 +296,9 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       L.fwd.pack.s_row = L.g.Cin; L.fwd.pack.s_ch = 1; L.fwd.pack.s_kh = 0; L.fwd.pack.s_kw = 0;
     } else {
       L.fwd = plan_fwd(L.g, L.w_off, bf16);
-      bool srcs_ok = true;
-      for (int s = 0; s < L.nsrc; ++s) srcs_ok = srcs_ok && n.t[L.src[s]].C % (2 * kc_elems(bf16)) == 0;
       // the generator's few-pixel bottleneck: conv + K-split combine + batch-norm + activations in one launch (conv_smallp.hip)
       if (n.groups == 1 && alt_batch == 0 && plan_smallp_eligible(L.fwd, L.g.Cout, bf16, n.t[L.src[0]].C, L.nsrc > 1 ? n.t[L.src[1]].C : 0))
         plan_make_smallp(L.fwd, L.g.Cout, bf16);
-      else if (plan_wide_eligible(L.fwd, bf16, srcs_ok, true) && !(L.g.Cout < 8)) plan_make_wide(L.fwd, bf16);
       else if (plan_patch_eligible(L.fwd, L.g.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == L.g.Cin)) plan_make_patch(L.fwd, L.g.Cout, bf16);
       else if (plan_patch2_eligible(L.fwd, L.g.Cout, bf16, n.t[L.src[0]].C, L.nsrc > 1 ? n.t[L.src[1]].C : 0)) plan_make_patch2(L.fwd, L.g.Cout, bf16);
     }
@@ -316,7 +314,7 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       if (L.fwd.a.patch == 1 && plan_patch_eligible(L.fwd_half, g2.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == g2.Cin, true))
         plan_make_patch(L.fwd_half, g2.Cout, bf16);
       const PackDesc &pa = L.fwd.pack, &pb = L.fwd_half.pack;
-      if (L.fwd_half.a.splitk == 1 && !L.fwd_half.a.wide) {
+      if (L.fwd_half.a.splitk == 1) {
         if (pa.kswap != pb.kswap || pa.perm != pb.perm || pa.kc != pb.kc || pa.Kpad != pb.Kpad || pa.rows_pad != pb.rows_pad) {
           take(L.fwd_half);
           L.pk_fwd_half = L.fwd_half.pack.dst_off;
@@ -350,17 +348,11 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
         if (n.groups == 1 && alt_batch == 0 && !ts.is_input && plan_smallp_eligible(L.bwd[s], rows, bf16, L.g.CoutT, 0)) {
           plan_make_smallp(L.bwd[s], rows, bf16);
         } else {
-          const bool dy_ok = L.g.CoutT % (2 * kc_elems(bf16)) == 0;
-          bool wide = plan_wide_eligible(L.bwd[s], bf16, dy_ok, true);
-          if (alt_batch > 0) wide = wide && plan_wide_eligible(L.bwd_alt[s], bf16, dy_ok, true);
-          if (wide) { plan_make_wide(L.bwd[s], bf16); if (alt_batch > 0) plan_make_wide(L.bwd_alt[s], bf16); }
-          else {
-            // backward-data of a stride-1 conv is a stride-1 conv over dY (one tensor of CoutT channels): patch kernel, per batch size
-            if (plan_patch_eligible(L.bwd[s], rows, bf16, true)) plan_make_patch(L.bwd[s], rows, bf16);
-            else if (plan_patch2_eligible(L.bwd[s], rows, bf16, L.g.CoutT, 0)) plan_make_patch2(L.bwd[s], rows, bf16);
-            if (alt_batch > 0 && plan_patch_eligible(L.bwd_alt[s], rows, bf16, true)) plan_make_patch(L.bwd_alt[s], rows, bf16);
-            else if (alt_batch > 0 && plan_patch2_eligible(L.bwd_alt[s], rows, bf16, L.g.CoutT, 0)) plan_make_patch2(L.bwd_alt[s], rows, bf16);
-          }
+          // backward-data of a stride-1 conv is a stride-1 conv over dY (one tensor of CoutT channels): patch kernel, per batch size
+          if (plan_patch_eligible(L.bwd[s], rows, bf16, true)) plan_make_patch(L.bwd[s], rows, bf16);
+          else if (plan_patch2_eligible(L.bwd[s], rows, bf16, L.g.CoutT, 0)) plan_make_patch2(L.bwd[s], rows, bf16);
+          if (alt_batch > 0 && plan_patch_eligible(L.bwd_alt[s], rows, bf16, true)) plan_make_patch(L.bwd_alt[s], rows, bf16);
+          else if (alt_batch > 0 && plan_patch2_eligible(L.bwd_alt[s], rows, bf16, L.g.CoutT, 0)) plan_make_patch2(L.bwd_alt[s], rows, bf16);
         }
         take(L.bwd[s]);
         L.pk_bwd[s] = L.pk_bwd_alt[s] = L.bwd[s].pack.dst_off;
@@ -747,10 +739,6 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       written = true;
       if (!gpass) {
         ts.dz_writes++;
-        // a gradient contribution issued on the branch stream (a decoder's skip-connection source) must have landed before another
-        // stream accumulates into the same tensor
-        if (a.accumulate && ts.dz_on_branch && ss != 2) VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_skip, 0));
-        if (!a.accumulate) ts.dz_on_branch = ss == 2;
       }
       // chain rule through the consumer's activation and (for BN tensors) up to the normalised value
       // lrelu'/relu' only depend on the sign of the pre-activation == the sign of the materialised x~
@@ -848,14 +836,16 @@ int vp_pixrefer_phase_ms(vp_pixrefer_t* h, float* ms, int cap) {
   }
   return n;
 }
-static bool g_overlap_on = true;     // vp_tune("overlap", 0 / 1): per-kernel timing (bench.py's profile pass) needs one stream
-void vp_overlap_enable(int on) { g_overlap_on = on != 0; }
+// Schedule options are PER HANDLE (vp_pixrefer_set_option); the three vp_tune keys below only set the defaults a handle copies when it
+// is created, so an experiment can still say `bench.py --tune overlap=0` before any plan exists.
+static bool g_overlap_default = true;     // "overlap" 0 / 1: per-kernel timing (bench.py's profile pass) needs one stream
+void vp_overlap_enable(int on) { g_overlap_default = on != 0; }
 // where vp_pixrefer_backward starts the discriminator-loss pass on the side stream: 0 = at once, 1 = behind the generator-loss pass
 // through the discriminator, 2 = behind its pass through the VGG trunk as well (i.e. under the generator's own backward)
-static int g_dfork_point = 2;
-void vp_dfork_point(int p) { g_dfork_point = p < 0 ? 0 : (p > 2 ? 2 : p); }
-static bool g_dsplit_on = true;      // discriminator fwd / generator-loss bwd through it on the branch stream, beside the VGG passes
-void vp_dsplit_enable(int on) { g_dsplit_on = on != 0; }
+static int g_dfork_default = 2;
+void vp_dfork_point(int p) { g_dfork_default = p < 0 ? 0 : (p > 2 ? 2 : p); }
+static bool g_dsplit_default = true;      // discriminator fwd / generator-loss bwd through it on the branch stream, beside the VGG passes
+void vp_dsplit_enable(int on) { g_dsplit_default = on != 0; }
 
 int vp_version(void) { return 100; }
 const char* vp_last_error(void) { return g_err; }
@@ -1016,6 +1006,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
   }
   VP_HIP_CHECK(hipStreamSynchronize(st));   // descs are host vectors owned by the handle; copy is complete
   h->overlap = false; h->forked = false;
+  h->ov_on = g_overlap_default; h->dfork_point = g_dfork_default; h->dsplit_on = g_dsplit_default;
   if (d->training && !getenv("VP_NO_OVERLAP")) {
     // lowest priority: the side stream only fills the CUs the main stream's (longer, critical-path) passes leave idle
     int prio_lo = 0, prio_hi = 0;
@@ -1031,7 +1022,6 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_b2join, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bfork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bjoin, hipEventDisableTiming));
-    VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_skip, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_upd_b, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_upd_m, hipEventDisableTiming));
     h->overlap = true;
@@ -1053,7 +1043,6 @@ void vp_pixrefer_destroy(vp_pixrefer_t* h) {
     (void)hipEventDestroy(h->ev_bjoin);
     (void)hipEventDestroy(h->ev_b2join);
     if (h->branch2) { (void)hipStreamSynchronize(h->branch2); (void)hipStreamDestroy(h->branch2); }
-    (void)hipEventDestroy(h->ev_skip);
     (void)hipEventDestroy(h->ev_upd_b);
     (void)hipEventDestroy(h->ev_upd_m);
     (void)hipStreamDestroy(h->branch);
@@ -1101,7 +1090,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   VP_HIP_CHECK(launch_pack_inputs(pi, bf, st));
 
   // the real half of the perceptual trunk only needs the packed inputs: side stream, under the generator forward
-  bool split_vgg = d.training && h->overlap && g_overlap_on;
+  bool split_vgg = d.training && h->overlap && h->ov_on;
   if (split_vgg) for (Layer& L : h->V.l) split_vgg = split_vgg && L.has_fwd_half;
   if (split_vgg) {
     VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
@@ -1125,7 +1114,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
 
   // generator: the two encoder branches (encoder_1..4 on `inputs`, encoder_fg_1..4 on `fg_inputs`, pixrefer.py:169-213) are
   // independent chains of small kernels until merged_encoder_2: the foreground branch runs on the branch stream
-  const bool split_enc = d.training && h->overlap && g_overlap_on;
+  const bool split_enc = d.training && h->overlap && h->ov_on;
   if (split_enc) {
     VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
     VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
@@ -1149,7 +1138,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
 
   // discriminator on [real1 | real2 | fake] (pixrefer.py:295-306).  It and the fake half of the VGG trunk both hang off the
   // composite only: the discriminator (conv + batch-norm glue, HBM-bound in between) runs on the branch stream under the VGG convs
-  const bool split_d = h->overlap && g_overlap_on && g_dsplit_on;
+  const bool split_d = h->overlap && h->ov_on && h->dsplit_on;
   hipStream_t sd = split_d ? h->branch : st;
   const int ssd = split_d ? 2 : 0;
   if (split_d) {
@@ -1243,7 +1232,7 @@ static int update_d(vp_pixrefer_t* h, hipStream_t s) {
 int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward: needs a training plan"); return VP_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
-  if (!h->overlap || !g_overlap_on) {
+  if (!h->overlap || !h->ov_on) {
     int rc = vp_pixrefer_backward_d(h, stream);
     if (rc) return rc;
     return vp_pixrefer_backward_g(h, stream);
@@ -1251,7 +1240,7 @@ int vp_pixrefer_backward(vp_pixrefer_t* h, void* stream) {
   int rc;
   // per handle, and cleared on every way out: a failed call must not leave a pending fork behind for a later stand-alone
   // vp_pixrefer_backward_g_stage (data-parallel path), which would start an un-joined discriminator pass
-  h->dfork_pending = g_dfork_point;
+  h->dfork_pending = h->dfork_point;
   if (h->dfork_pending == 0 && (rc = fork_d(h, st))) { h->dfork_pending = 0; return rc; }
   rc = vp_pixrefer_backward_g(h, stream);
   h->dfork_pending = 0;
@@ -1268,7 +1257,7 @@ static int fork_d(vp_pixrefer_t* h, hipStream_t st) {
   int rc = backward_d_on(h, h->side, true);
   if (rc) return rc;
   // forked behind the generator-loss pass through the discriminator (point 2): nobody reads the discriminator's weights any more
-  if (h->upd.active && g_dfork_point == 2 && (rc = update_d(h, h->side))) return rc;
+  if (h->upd.active && h->dfork_point == 2 && (rc = update_d(h, h->side))) return rc;
   VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
   return VP_OK;
 }
@@ -1340,11 +1329,11 @@ int vp_pixrefer_backward_d(vp_pixrefer_t* h, void* stream) {
 int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream) {
   if (!h || !h->d.training) { set_err("vp_pixrefer_backward_d_fork: needs a training plan"); return VP_ERR_STATE; }
   hipStream_t st = (hipStream_t)stream;
-  h->forked = h->overlap && g_overlap_on;
+  h->forked = h->overlap && h->ov_on;
   if (!h->forked) return backward_d_on(h, st, false);
   // the pass starts where vp_pixrefer_backward starts it (vp_tune "d_backward_fork", default: inside stage 0 of the generator
   // backward, behind the generator-loss pass through D and the VGG trunk, i.e. under the generator's own layers); 0: at once
-  h->dfork_pending = g_dfork_point;
+  h->dfork_pending = h->dfork_point;
   if (h->dfork_pending == 0) return fork_d(h, st);
   return VP_OK;
 }
@@ -1362,6 +1351,22 @@ int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n) {
   if (!h || (n != 3 && n != 4)) { set_err("vp_pixrefer_use_streams: 3 or 4"); return VP_ERR_ARG; }
   h->use_b2 = (n == 4) && h->overlap && !getenv("VP_NO_FG_STREAM");
   return VP_OK;
+}
+
+// Schedule options of ONE plan (they used to be process globals: two engines in a process, or a profiling pass on one of them,
+// changed each other's schedule).  Takes effect from the next forward / backward call of this handle; results are bit-identical
+// under every setting (tests/test_gpu_soak.py).
+//   "overlap"          0 / 1   the step on the caller's stream only / spread over the executor's streams (default 1)
+//   "d_backward_fork"  0..2    where vp_pixrefer_backward starts the discriminator-loss pass on the side stream (default 2)
+//   "d_beside_vgg"     0 / 1   discriminator forward / generator-loss backward on the branch stream beside the VGG passes (default 1)
+int vp_pixrefer_set_option(vp_pixrefer_t* h, const char* key, int value) {
+  if (!h || !key) { set_err("vp_pixrefer_set_option: null argument"); return VP_ERR_ARG; }
+  const std::string k(key);
+  if (k == "overlap") { h->ov_on = value != 0; return VP_OK; }
+  if (k == "d_backward_fork") { h->dfork_point = value < 0 ? 0 : (value > 2 ? 2 : value); return VP_OK; }
+  if (k == "d_beside_vgg") { h->dsplit_on = value != 0; return VP_OK; }
+  set_err("vp_pixrefer_set_option: unknown key %s", key);
+  return VP_ERR_ARG;
 }
 
 int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream) {
@@ -1426,7 +1431,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   // ---- Gen_loss -> generator* (pixrefer.py:402-407) ----
   // (a) GAN term through the fake application of the discriminator (dX only, pre-update weights)
   // ... on the branch stream: independent of the VGG pass (b) until the composite (c) adds the two image gradients
-  const bool split_d = h->overlap && g_overlap_on && g_dsplit_on;
+  const bool split_d = h->overlap && h->ov_on && h->dsplit_on;
   hipStream_t sd = split_d ? h->branch : st;
   const int ssd = split_d ? 2 : 0;
   if (split_d) {
@@ -1484,12 +1489,12 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   ca.d_din = h->d_din; ca.d_vin = h->d_vin; ca.dy4 = h->dy4; ca.N = N; ca.HW = H * H; ca.l1_weight = d.l1_weight;
   VP_HIP_CHECK(launch_composite_bwd(ca, bf, st));
   phase_mark(h, st, 3);
-  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; t.dz_on_branch = false; }
+  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; }
   }
   // (d) generator, last layer first.  Below merged_encoder_2 the two encoder branches are independent again: the foreground
   // branch (encoder_fg_4 .. encoder_fg_1) runs on the branch stream, joined before this call returns control of `st`
-  const bool split_enc = h->overlap && g_overlap_on && l_lo == 0;
-  const bool wsplit = h->overlap && g_overlap_on && !getenv("VP_NO_WSPLIT");
+  const bool split_enc = h->overlap && h->ov_on && l_lo == 0;
+  const bool wsplit = h->overlap && h->ov_on && !getenv("VP_NO_WSPLIT");
   bool forked = false, fg_forked = false;
   bool b2_used = false;            // something of this call runs on the second branch stream (joined wherever `branch` is)
   for (int i = l_hi; i >= l_lo; --i) {
@@ -1513,19 +1518,15 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     if (L.has_bn) if ((rc = run_bn_bwd(h, G, L, true, 0, N, 0, 1, s2, ss))) return rc;
     if (wsplit && !fg) {
       // the weight gradient of a layer hangs off the chain (only its data gradient feeds the next layer): branch stream
-      static const bool skip_on_branch = getenv("VP_SKIP_ON_BRANCH") != nullptr;
       // (alternating the weight gradients between the two branch streams was measured: slower - they then sit in front of the
       // foreground chain again; batch 4 2.55 vs 2.50 ms)
       VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
       VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
       forked = true;
-      // ... and so does the data gradient of a SECOND source (a decoder's skip connection, merged_encoder_2's foreground input): it is
-      // first needed when the backward pass reaches the encoder that produced the tensor
-      // (opt-in: measured +0.02 .. 0.05 ms at batch 4 / 8 / 32 - the branch stream, not this one, ends the step)
-      const int bparts = (skip_on_branch && L.nsrc > 1) ? 1 | 4 : 1;
-      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, h->branch, 2, false, bparts))) return rc;
-      if (bparts & 4) VP_HIP_CHECK(hipEventRecord(h->ev_skip, h->branch));
-      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st, 0, false, 6 & ~bparts))) return rc;
+      // (the data gradient of a decoder's skip-connection source on the branch stream too was measured slower - EXPERIMENTS.md - and
+      // raced with the fourth stream: removed)
+      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, h->branch, 2, false, 1))) return rc;
+      if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st, 0, false, 6))) return rc;
     } else {
       if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, s2, ss))) return rc;
     }
@@ -1535,8 +1536,8 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
       const size_t off0 = G.l[l0].w_off, off1 = l1 + 1 < (int)G.l.size() ? G.l[l1 + 1].w_off : G.nparams;
       hipStream_t su = st;
       static const bool upd_on_side = !getenv("VP_UPDATE_ON_BRANCH");
-      const bool on_side = upd_on_side && h->overlap && g_overlap_on && h->dfork_pending == 0 && g_dfork_point >= 0;
-      if (h->overlap && g_overlap_on && on_side) {
+      const bool on_side = upd_on_side && h->overlap && h->ov_on && h->dfork_pending == 0 && h->dfork_point >= 0;
+      if (h->overlap && h->ov_on && on_side) {
         // the (HBM-bound) optimiser + re-pack of the bucket go to the SIDE stream, behind the discriminator-loss pass that runs there:
         // on the branch stream they sat between the weight gradients of the layers still to come and delayed the end of the step.
         // The bucket is final when its weight gradients (branch stream) and its data gradients (this stream: they read the packed
@@ -1550,7 +1551,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
           VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_b2join, 0));
         }
         su = h->side;
-      } else if (h->overlap && g_overlap_on) {
+      } else if (h->overlap && h->ov_on) {
         VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
         VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
         if (b2_used) {
@@ -1560,7 +1561,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
         su = h->branch; forked = true;
       }
       if ((rc = update_range(h, G, h->upd.m_g, h->upd.v_g, h->upd.lr_t_g, off0, off1, l0, l1, su))) return rc;
-      if (h->overlap && g_overlap_on && on_side) VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+      if (h->overlap && h->ov_on && on_side) VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
     }
   }
   if (forked) {

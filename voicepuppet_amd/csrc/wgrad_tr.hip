@@ -28,7 +28,7 @@ __device__ __forceinline__ int tr_swz(int p) { return ((p & 3) | (((p >> 3) & 1)
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
-// fragment reads behind a __restrict__ parameter (see conv_db.hip: keeps the waitcnt pass from draining vmcnt in front of LDS reads
+// fragment reads behind a __restrict__ parameter (found on the register-double-buffered tile of round 2, EXPERIMENTS.md: keeps the waitcnt pass from draining vmcnt in front of LDS reads
 // while LDS-DMAs are in flight); `off`: byte offset of the first 4-pixel group of this lane's 8 consecutive k, the second one is
 // four pixel rows further
 template <int ROWB>   // bytes of one pixel row of the tile

@@ -267,7 +267,11 @@ class PixReferEngine:
     """Per-launch HIP-event timing of the conv kernels; while it is on the executor keeps every kernel on one stream (timing a
     kernel that shares the GPU with another stream's kernels measures the sharing, not the kernel)."""
     self.L.vp_profile_enable(int(on))
-    self.L.vp_tune(b"overlap", 0 if on else 1)
+    self.set_option("overlap", 0 if on else 1)
+
+  def set_option(self, key, value):
+    """Schedule option of THIS engine's plan (vp_pixrefer_set_option: "overlap", "d_backward_fork", "d_beside_vgg")."""
+    _lib.check(self.L.vp_pixrefer_set_option(self.h, key.encode(), int(value)), "vp_pixrefer_set_option(%s)" % key)
 
   def phase_ms(self):
     """After vp_tune("phase_marks", 1) and a step on a training plan: milliseconds of the step's phases on the caller's stream

@@ -71,11 +71,18 @@ class FramePrefetcher:
       self.slots.append({"host": host, "dev": dev, "packer": DeviceFramePacker(batch, img_size, self.device),
                          "ready": torch.cuda.Event(), "free": torch.cuda.Event(), "busy": False})
     self.head = self.tail = 0
+    self._copied = []                                 # copy-done events of the last batches whose sources were read in place
     for _ in range(depth):
       self._fill()
 
   def _fill(self):
     slot = self.slots[self.head % len(self.slots)]
+    # The contract for pinned sources read in place: a buffer stays unchanged "until two batches later".  Enqueuing is not
+    # executing: nothing else throttles a host that runs ahead of the device (a launcher that reads no loss per step), so before the
+    # source may produce batch k - possibly into the buffer batch k-3 or older was read from - the H2D copies of batch k-2 (and, in
+    # stream order, of everything before it) must have EXECUTED.  They normally have; the wait is then a query.
+    if len(self._copied) >= 2:
+      self._copied[-2].synchronize()
     try:
       ex, cur, crops = next(self.source)
     except StopIteration:
@@ -99,6 +106,10 @@ class FramePrefetcher:
         self.stream.wait_event(slot["free"])          # the consumer of this slot's previous batch has been enqueued past it
       for d, h in zip(slot["dev"], srcs):
         d.copy_(h, non_blocking=True)
+      if not staged:
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self._copied = self._copied[-2:] + [ev]
       slot["packer"](*slot["dev"])
       slot["ready"].record(self.stream)
     slot["busy"] = True
@@ -123,20 +134,3 @@ class FramePrefetcher:
   def __iter__(self):
     return self
 
-
-def host_pack_reference(ex_u8, cur_u8, crops, img_size):
-  """The reference's host arithmetic for ONE sample with PIL standing in for cv2.resize (float planes, bilinear): what
-  PixReferDataGenerator._load_triptych + pack_sample compute.  Used by the fixture generator and the parity test."""
-  from PIL import Image
-  from .generator import pack_sample
-  S = img_size
-
-  def trip(u8, crop):
-    rx, ry, rsize = [int(v) for v in crop]
-    img = (u8.astype(np.float32) / 255.0)[:, :, ::-1]
-    img = np.concatenate([img[:, :S, :], img[:, S:S * 2, :], img[:, S * 2:, :]], axis=-1)
-    img = img[rx:rsize + rx, ry:rsize + ry, :]
-    planes = [np.asarray(Image.fromarray(np.ascontiguousarray(img[:, :, c]), mode="F").resize((S, S), Image.BILINEAR)) for c in range(9)]
-    img = np.stack(planes, axis=-1)
-    return np.concatenate([img[:, :, :3], img[:, :, 3:6], img[:, :, 6:]], axis=1)
-  return pack_sample(trip(ex_u8, crops[0]), trip(cur_u8, crops[1]), S)

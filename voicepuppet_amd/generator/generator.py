@@ -420,7 +420,8 @@ class _DeviceFrameIterator(object):
 
   def _batches(self):
     """Batches as PINNED torch tensors the prefetcher copies from directly (no staging copy): a ring of four, since a batch must stay
-    unchanged until two batches later (FramePrefetcher).  The samples of a batch are written straight into the ring slot."""
+    unchanged until two batches later (FramePrefetcher, which host-waits for the copies of batch k-2 before it asks for batch k: slot
+    k % 4 was last read for batch k-4).  The samples of a batch are written straight into the ring slot."""
     import torch
     g = self.ds.owner
     N, S = self.ds.batch_size, g.img_size
