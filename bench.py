@@ -124,14 +124,20 @@ def _timed_steps(step, n, warm, steps, cap_s):
   before one step)."""
   for _ in range(warm):
     step()
-  done, t0 = 0, time.time()
-  while done < steps:
+  per, t0 = [], time.time()
+  while len(per) < steps:
+    t1 = time.perf_counter()
     step()
-    done += 1
+    per.append(time.perf_counter() - t1)
     if time.time() - t0 > cap_s:
       break
   dt = time.time() - t0
-  return {"frames_per_s": n * done / dt, "steps": done, "warmup": warm, "batch": n, "seconds": round(dt, 2)}
+  per.sort()
+  med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+  # frames_per_s = the MEDIAN step (a shared host's outliers do not move it); the mean and the best step beside it
+  return {"frames_per_s": n / med, "frames_per_s_mean": n * len(per) / dt, "frames_per_s_best_step": n / per[0],
+          "step_s_min_median_max": [round(per[0], 4), round(med, 4), round(per[-1], 4)],
+          "steps": len(per), "warmup": warm, "batch": n, "seconds": round(dt, 2)}
 
 
 def usable_cores():
@@ -164,7 +170,7 @@ def cpu_baseline(h, ngf=64, ndf=64, cap_s=20.0):
   st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf)
   out["numpy_port_bs2"] = _timed_steps(lambda: st.step(*b2), 2, 1, 3, cap_s)
   tg = TorchGraph(p, ngf, ndf, torch.float32)
-  out["torch_cpu_bs2"] = _timed_steps(lambda: tg.step(*b2), 2, 2, 3, cap_s)
+  out["torch_cpu_bs2"] = _timed_steps(lambda: tg.step(*b2), 2, 2, 12, cap_s)     # >= 10 timed steps: the quoted baseline
   b32 = batch(32)
   tg = TorchGraph(p, ngf, ndf, torch.float32)
   out["torch_cpu_bs32"] = _timed_steps(lambda: tg.step(*b32), 32, 1, 3, 2 * cap_s)
@@ -173,7 +179,8 @@ def cpu_baseline(h, ngf=64, ndf=64, cap_s=20.0):
           "label": "CPU restatement (TF-CPU proxy): TensorFlow exists on neither box",
           "sample": "full G+D steps (fwd + both bwd + TF-Adam x2) at %dx%d, ngf=ndf=%d, float32, %d threads: numpy port "
                     "(oracle/pixrefer_ref.py) at the reference's batch 2, torch-CPU/oneDNN restatement (oracle/pixrefer_torch.py) "
-                    "at batch 2 and 32, each after warm-up; value = the fastest of them (%s)" % (h, h, ngf, cores, best),
+                    "at batch 2 (12 timed steps) and 32, each after warm-up; per run the MEDIAN step is quoted (min / median / max in `runs`); "
+                    "value = the fastest of them (%s)" % (h, h, ngf, cores, best),
           "runs": out}
 
 
@@ -245,12 +252,23 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
       dist.barrier(group=group)
     torch.cuda.synchronize()
 
-  for _ in range(warmup):
+  # rank liveness: a peer that dies inside a collective leaves this rank's streams spinning; the watchdog ends the process non-zero
+  from voicepuppet_amd.parallel import StepWatchdog
+  dog = StepWatchdog(rank=rank) if world > 1 else None
+
+  def step():
     eng.train_step(*batch, lr=lr, group=group)
+    if dog is not None:
+      ev = torch.cuda.Event()
+      ev.record()
+      dog.beat(ev)
+
+  for _ in range(warmup):
+    step()
   sync()
   t0 = time.perf_counter()
   for _ in range(steps):
-    eng.train_step(*batch, lr=lr, group=group)
+    step()
   sync()
   dt = time.perf_counter() - t0
   if world > 1:
@@ -261,6 +279,18 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
   res = {"ms_per_step": ms, "frames_per_s": per_gpu * world * steps / dt, "per_gpu_batch": per_gpu,
          "global_batch": per_gpu * world,
          "step_tflops": GFLOP_PER_FRAME_256 * 1e9 * (height / 256) ** 2 * per_gpu * world / (ms * 1e-3) / 1e12}
+  if world > 1:
+    # where the exchange's time goes (outside the timed region): HIP events on the communication stream around every bucket of two
+    # more steps; every rank runs them (they are collectives), rank 0 reports the second one
+    ex = eng._exchange
+    ex.timing = True
+    for _ in range(2):
+      step()
+    sync()
+    res["buckets"] = ex.bucket_ms()
+    ex.timing = False
+  if dog is not None:
+    dog.close()
   if profile and rank == 0:
     # per-kernel launch durations, HIP events on the launch stream, over a few extra steps (outside the timed region)
     eng.profile(True)
@@ -358,9 +388,8 @@ def main():
   device = torch.device("cuda", local)
   group = None
   if world > 1:
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=device)
-    group = dist.group.WORLD
+    from voicepuppet_amd.parallel import init_distributed
+    group = init_distributed("nccl", device_id=device)       # collective timeout + async error handling: a dead peer ends every rank non-zero
     assert dist.get_world_size() == args.gpus
 
   grad_dtype = args.dtype if args.grad_dtype == "auto" else args.grad_dtype
@@ -416,6 +445,7 @@ def main():
            "roofline": main_res.get("roofline"), "kernels": main_res.get("kernels"),
            "conv_launches_per_step": main_res.get("conv_launches_per_step"), "step_tflops": main_res["step_tflops"]}
     if dist_info is not None:
+      dist_info["buckets"] = main_res.get("buckets")
       out["distributed"] = dist_info
     if other is not None:
       out["other_scaling"] = other

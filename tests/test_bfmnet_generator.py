@@ -91,3 +91,44 @@ def test_synthetic_fallback_shapes():
   c, e, w, n = next(gen.iterator())
   assert c.shape == (24, 257) and e.shape == (24, 1) and w.shape == (gen.pcm_length(24),) and n == 24
   assert np.array_equal(c[:, :80], np.repeat(c[:1, :80], 24, 0))
+
+
+def test_background_batch_thread_is_reproducible_and_stops(monkeypatch):
+  """ADVICE r3 on _MfccIterator: the batch thread draws from a private random.Random seeded from the module-level state on the
+  caller's thread (so the sample order is a function of random.seed() even while the main thread draws), and it stops when the
+  iterator is closed or dropped.  process_data (log-mel, device) is replaced by the identity: this is the host half only."""
+  import gc
+  import random
+  import threading
+  import time
+  monkeypatch.setattr(BFMNetDataGenerator, "process_data", lambda self, c, e, p, n: (c, e, p, n))
+
+  def run(noise):
+    random.seed(123)
+    g = BFMNetDataGenerator(CFG)
+    prm = g.params
+    prm.dataset_path = "/nonexistent/train.txt"          # -> synthetic clips
+    prm.batch_size = 3
+    prm.shuffle_bufsize = 1                              # (the shuffle buffer itself draws from an unseeded numpy generator, as tf.data does)
+    g.set_params(prm)
+    it = g.get_dataset().make_one_shot_iterator()
+    out = []
+    for k in range(4):
+      if noise:
+        random.random()                                   # the main thread draws between batches: must not change the order
+      out.append(it.next_batch()[0].copy())
+    return it, out
+  it1, a = run(False)
+  it2, b = run(True)
+  for x, y in zip(a, b):
+    np.testing.assert_array_equal(x, y)
+  names = lambda: [t for t in threading.enumerate() if t.name == "bfmnet-batches" and t.is_alive()]
+  assert len(names()) == 2
+  it1.close()
+  assert len(names()) == 1
+  del it2, a, b
+  gc.collect()
+  t0 = time.time()
+  while names() and time.time() - t0 < 5:
+    time.sleep(0.1)
+  assert not names()

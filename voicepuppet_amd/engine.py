@@ -227,13 +227,14 @@ class PixReferEngine:
         m, v, t = (m_d, v_d, self.t_d) if which else (m_g, v_g, self.t_g)
         return lambda sp: _lib.check(self.L.vp_pixrefer_update_bucket(self.h, which, bucket, _ptr(m), _ptr(v), t, lr, beta1, 0.999, 1e-8, sp),
                                      "vp_pixrefer_update_bucket")
+      ex.begin_step()
       _lib.check(self.L.vp_pixrefer_backward_d_fork(self.h, _stream()), "vp_pixrefer_backward_d_fork")
       for stage, (lo, hi) in enumerate(self.grad_buckets_g()):
         self.backward_g_stage(stage)
-        ex.start(self.grads_g[lo:hi], then=update(0, stage))
+        ex.start(self.grads_g[lo:hi], then=update(0, stage), name="generator stage %d" % stage)
       # the discriminator-loss pass ran on the side stream under the generator's stages; its (small) bucket goes last
       _lib.check(self.L.vp_pixrefer_backward_d_join(self.h, _stream()), "vp_pixrefer_backward_d_join")
-      ex.start(self.grads_d, then=update(1, 0))       # (an event on this stream covers the joined pass: include/vp_hip.h)
+      ex.start(self.grads_d, then=update(1, 0), name="discriminator")       # (an event on this stream covers the joined pass: include/vp_hip.h)
       ex.finish()
       return
     self.adam_step(lr, beta1)

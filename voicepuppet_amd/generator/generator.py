@@ -170,8 +170,14 @@ class BFMNetDataGenerator(DataGenerator):
         pcm = np.pad(pcm, (0, pcm_start + pcm_length - pcm.shape[0]), 'constant', constant_values=(0))
       yield bfmcoeff_slice, ear_slice.astype(np.float32), pcm[pcm_start: pcm_start + pcm_length].astype(np.float32), bfmcoeff_slice.shape[0]
 
+  def _rand(self):
+    """The source of the order-defining draws (shuffle of the file list, seed of the synthetic clips): the module-level `random`,
+    or - once a background batch thread exists (_MfccIterator) - a private random.Random that was seeded FROM the module-level state
+    on the caller's thread, so the sample order is a function of random.seed() alone, whatever else the main thread draws meanwhile."""
+    return getattr(self, '_private_random', None) or random
+
   def _synthetic(self):
-    rng = np.random.default_rng(random.randint(0, 2 ** 31))
+    rng = np.random.default_rng(self._rand().randint(0, 2 ** 31))
     T = self.SLICE
     n = self.pcm_length(T)
     t = np.arange(n) / self.sample_rate
@@ -190,7 +196,7 @@ class BFMNetDataGenerator(DataGenerator):
     bfmcoeff_loader = BFMCoeffLoader()
     landmark_loader = LandmarkLoader(norm_size=1)
     wav_loader = WavLoader(sr=self.sample_rate)
-    random.shuffle(self.data_list)
+    self._rand().shuffle(self.data_list)
     for line in self.data_list:
       folder, img_count = line.strip().split('|')
       img_count = int(img_count)
@@ -229,20 +235,63 @@ class _MfccIterator(DatasetIterator):
     device the interpreter is free to prepare the next batch.  The device half (log-mel) stays on the caller's thread."""
     import queue
     import threading
+    import weakref
     q = queue.Queue(maxsize=2)
+    stop = threading.Event()
+    END = object()
+    # the worker's draws come from a generator of its own, seeded here - on the caller's thread - from the module-level state
+    self.ds.owner._private_random = random.Random(random.getrandbits(64))
+    nxt = DatasetIterator.next_batch
+    me = weakref.ref(self)                 # the thread must not keep the iterator alive: dropping the iterator stops the thread
+
+    def put(item):
+      while not stop.is_set():
+        try:
+          q.put(item, timeout=0.2)
+          return True
+        except queue.Full:
+          if me() is None:
+            return False
+      return False
 
     def work():
       try:
-        while True:
-          q.put(DatasetIterator.next_batch(self))
-      except BaseException as e:      # hand the failure to the consumer
-        q.put(e)
-    threading.Thread(target=work, daemon=True, name="bfmnet-batches").start()
-    while True:
-      item = q.get()
-      if isinstance(item, BaseException):
-        raise item
-      yield item
+        while not stop.is_set():
+          it = me()
+          if it is None:
+            return
+          batch = nxt(it)
+          del it
+          if not put(batch):
+            return
+      except StopIteration:               # a finite source ran out: a sentinel, not an exception object (PEP 479)
+        put(END)
+      except BaseException as e:          # hand the failure to the consumer
+        put(e)
+    th = threading.Thread(target=work, daemon=True, name="bfmnet-batches")
+    self._hb_stop, self._hb_thread = stop, th
+    th.start()
+    try:
+      while True:
+        item = q.get()
+        if item is END:
+          return
+        if isinstance(item, BaseException):
+          raise RuntimeError("the batch thread failed") from item
+        yield item
+    finally:
+      stop.set()
+
+  def close(self):
+    """Stop the background batch thread (also happens when the iterator is garbage-collected)."""
+    if getattr(self, "_hb_stop", None) is not None:
+      self._hb_stop.set()
+      self._hb_thread.join(timeout=2.0)
+      self._hb = None
+
+  def __del__(self):
+    if getattr(self, "_hb_stop", None) is not None:
+      self._hb_stop.set()
 
   def next_batch(self):
     if getattr(self, "_hb", None) is None:

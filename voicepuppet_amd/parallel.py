@@ -5,8 +5,113 @@ mean all-reduce of the two flat f32 gradient arenas (discriminator 2.77 M floats
 floats); batch-norm statistics stay per replica.  RCCL reduces with ncclAvg, so no extra
 scaling kernel runs on the device; the gloo branch (CPU tests) sums and scales.
 """
+import collections
+import datetime
+import logging
+import os
+import sys
+import threading
+import time
+
 import torch
 import torch.distributed as dist
+
+logger = logging.getLogger(__name__)
+
+WATCHDOG_EXIT_CODE = 75        # EX_TEMPFAIL: "try again" - the restart is a FRESH process from the last checkpoint
+
+
+def init_distributed(backend="nccl", timeout_s=None, **kw):
+  """dist.init_process_group for one process per GPU with the failure behaviour SURVEY.md 5 asks for: a collective that errors or
+  does not complete within `timeout_s` (default VP_COLLECTIVE_TIMEOUT_S or 600) aborts the communicator and raises in this rank
+  (TORCH_NCCL_ASYNC_ERROR_HANDLING=1: torch's RCCL watchdog thread tears the process down), the launcher (torch.distributed.run)
+  then stops the other ranks, and every rank's exit status is non-zero.  Nothing is re-executed in place: a process that has
+  touched the GPU is never exec'd over; the job is started again from the last checkpoint (train_pixrefer.py --resume)."""
+  if timeout_s is None:
+    timeout_s = float(os.environ.get("VP_COLLECTIVE_TIMEOUT_S", "600"))
+  os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+  return dist.group.WORLD
+
+
+class StepWatchdog(object):
+  """Rank-liveness watchdog of a training loop ('RCCL error / timeout -> abort all ranks; restart from the last
+  checkpoint').  The step never blocks the host, so a peer that died inside a collective shows up as a device stream that stops
+  making progress (RCCL kernels spin) while the host keeps enqueuing, or - with a host-blocking backend (gloo) - as a host that
+  stops calling beat().  Both are watched from a daemon thread:
+
+    beat(event)  once per step, `event` = a torch.cuda.Event recorded behind the step (None: the step is complete on return);
+    the thread fires when the OLDEST unfinished step was enqueued more than `timeout_s` ago, or when beat() has not been called
+    for `timeout_s` (after the first beat).
+
+  Firing logs the rank, the last finished step and the age, then ends the process with WATCHDOG_EXIT_CODE through os._exit (no
+  destructors: the communicator may be wedged); torch.distributed.run sees the non-zero status and stops the remaining ranks.
+  timeout_s <= 0 disables it.  on_timeout(info) replaces the exit (tests)."""
+
+  def __init__(self, timeout_s=None, rank=0, on_timeout=None, poll_s=0.25):
+    if timeout_s is None:
+      timeout_s = float(os.environ.get("VP_WATCHDOG_TIMEOUT_S", "300"))
+    self.timeout_s, self.rank, self.on_timeout, self.poll_s = float(timeout_s), rank, on_timeout, poll_s
+    self.pending = collections.deque()
+    self.lock = threading.Lock()
+    self.steps_enqueued = self.steps_done = 0
+    self.last_beat = None
+    self.fired = None
+    self._stop = threading.Event()
+    self.thread = None
+    if self.timeout_s > 0:
+      self.thread = threading.Thread(target=self._run, name="vp-step-watchdog", daemon=True)
+      self.thread.start()
+
+  def beat(self, event=None):
+    now = time.monotonic()
+    with self.lock:
+      self.steps_enqueued += 1
+      self.last_beat = now
+      self.pending.append((now, event, self.steps_enqueued))
+
+  def _drain(self):
+    with self.lock:
+      while self.pending:
+        t, ev, k = self.pending[0]
+        if ev is not None and not ev.query():
+          break
+        self.pending.popleft()
+        self.steps_done = k
+
+  def _check(self, now):
+    self._drain()
+    with self.lock:
+      if self.pending and now - self.pending[0][0] > self.timeout_s:
+        return {"why": "device", "rank": self.rank, "age_s": now - self.pending[0][0], "last_finished_step": self.steps_done,
+                "oldest_unfinished_step": self.pending[0][2]}
+      if self.last_beat is not None and now - self.last_beat > self.timeout_s:
+        return {"why": "host", "rank": self.rank, "age_s": now - self.last_beat, "last_finished_step": self.steps_done,
+                "oldest_unfinished_step": self.steps_done + 1}
+    return None
+
+  def _run(self):
+    while not self._stop.wait(self.poll_s):
+      info = self._check(time.monotonic())
+      if info is None:
+        continue
+      self.fired = info
+      logger.error("rank %d: no progress for %.1f s (%s stalled: step %d has not finished, last finished step %d) - a peer is gone or a "
+                   "collective hangs; ending this rank with status %d, restart the job from the last checkpoint",
+                   info["rank"], info["age_s"], info["why"], info["oldest_unfinished_step"], info["last_finished_step"], WATCHDOG_EXIT_CODE)
+      if self.on_timeout is not None:
+        self.on_timeout(info)
+        return
+      for h in logging.getLogger().handlers:
+        h.flush()
+      sys.stderr.flush()
+      os._exit(WATCHDOG_EXIT_CODE)
+
+  def close(self):
+    self._stop.set()
+    if self.thread is not None:
+      self.thread.join(timeout=2.0)
 
 
 class _Done(object):
@@ -68,6 +173,8 @@ class GradExchange(object):
     self.backend = dist.get_backend(group)
     self.stream = stream if stream is not None else torch.cuda.Stream()
     self.buffers = {}
+    self.timing = False           # True: HIP events on the communication stream around every bucket (bucket_ms)
+    self.marks = []
 
   def _buffer(self, t):
     key = (t.data_ptr(), t.numel())
@@ -76,7 +183,22 @@ class GradExchange(object):
       b = self.buffers[key] = torch.empty(t.numel(), dtype=torch.bfloat16, device=t.device)
     return b
 
-  def start(self, t, then=None):
+  def begin_step(self):
+    self.marks = []
+
+  def bucket_ms(self):
+    """After a synchronize, with timing on: per bucket of the last step, in issue order, {name, bytes (on the wire per rank and
+    direction), wait_ms (the communication stream idle until the bucket's gradients were final, measured from the previous bucket's
+    end), allreduce_ms (pack + collective + unpack), update_ms (the Adam update + re-pack behind it)} - HIP events on the
+    communication stream, so a scaling record can say where the exchange's time goes."""
+    out, prev = [], None
+    for name, nbytes, e0, e1, e2 in self.marks:
+      out.append({"name": name, "bytes": nbytes, "wait_ms": round(prev.elapsed_time(e0), 4) if prev is not None else None,
+                  "allreduce_ms": round(e0.elapsed_time(e1), 4), "update_ms": round(e1.elapsed_time(e2), 4)})
+      prev = e2
+    return out
+
+  def start(self, t, then=None, name=""):
     """Mean all-reduce of the contiguous f32 range `t` on the communication stream, ordered behind everything enqueued on the
     current stream; `then(stream_pointer)` is called right behind it to enqueue work that consumes the reduced range on that
     stream (the bucket's Adam update)."""
@@ -87,6 +209,9 @@ class GradExchange(object):
     with torch.cuda.stream(self.stream):
       self.stream.wait_event(ready)
       sp = ctypes.c_void_p(self.stream.cuda_stream)
+      if self.timing:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record(self.stream)
       # (a blocking-style call: with RCCL it only orders the communication stream behind the collective, the host does not wait)
       if self.transport == "bf16":
         buf = self._buffer(t)
@@ -99,8 +224,13 @@ class GradExchange(object):
       else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         t.div_(self.world)
+      if self.timing:
+        ev[1].record(self.stream)
       if then is not None:
         then(sp)
+      if self.timing:
+        ev[2].record(self.stream)
+        self.marks.append((name, t.numel() * (2 if self.transport == "bf16" else 4), ev[0], ev[1], ev[2]))
 
   def finish(self):
     """Everything started so far is ordered before what the current stream does next."""

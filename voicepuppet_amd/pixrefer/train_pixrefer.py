@@ -6,7 +6,9 @@
 
 One process per GPU; under torch.distributed.run (WORLD_SIZE > 1) the G/D gradient arenas are
 all-reduced over RCCL every step (plain data parallel, per-replica batch statistics).
-Extra, optional flags (defaults reproduce the reference run): --steps, --batch_size, --img_size.
+Extra, optional flags (defaults reproduce the reference run): --steps, --batch_size, --img_size, --resume (continue from the
+latest checkpoint in ckpt_pixrefer - the block the reference keeps commented out at train_pixrefer.py:93-99; what a restart after a
+lost rank does: a FRESH process from the last checkpoint, never a re-exec of one that touched the GPU).
 """
 import logging
 import os
@@ -42,6 +44,7 @@ def main(argv=None):
   cmd_parser.add_option('--steps', type="int", dest="steps", default=None, help='iterations to run (default: training.epochs)')
   cmd_parser.add_option('--batch_size', type="int", dest="batch_size", default=2, help='per-GPU batch (reference: 2)')
   cmd_parser.add_option('--img_size', type="int", dest="img_size", default=None, help='override amd.img_size')
+  cmd_parser.add_option('--resume', action="store_true", dest="resume", default=False, help='restore the latest checkpoint of save_dir')
   opts, _ = cmd_parser.parse_args(argv)
 
   if (opts.config_path is None):
@@ -59,9 +62,8 @@ def main(argv=None):
   torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
   group = None
   if world > 1:
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl')
-    group = dist.group.WORLD
+    from voicepuppet_amd.parallel import init_distributed
+    group = init_distributed('nccl')      # collective timeout + async error handling (parallel.py)
 
   batch_size = opts.batch_size
   ### Generator for training setting
@@ -104,11 +106,21 @@ def main(argv=None):
   train_nodes = vid2vidnet.build_train_op(*train_iter.get_next())
   if use_device_pipeline:
     vid2vidnet.engine.use_streams(3)      # the input prefetcher's stream is the fourth busy one (include/vp_hip.h vp_pixrefer_use_streams)
+  if opts.resume or (params.get('amd') or {}).get('resume', False):
+    from voicepuppet_amd.utils import tf_checkpoint
+    latest = tf_checkpoint.latest_checkpoint(params.save_dir) if os.path.isdir(params.save_dir) else None
+    if latest is not None:
+      vid2vidnet.restore(latest)
+      logger.info('resumed from %s (global_step %d)', latest, vid2vidnet.global_step)
   if world > 1:   # identical initial weights on every replica
     for a in (vid2vidnet.engine.params_g, vid2vidnet.engine.params_d, vid2vidnet.engine.params_vgg):
       dist.broadcast(a, 0)
     vid2vidnet.engine.params_changed()
 
+  # rank liveness: losses are read only on summary steps, so a peer lost inside a collective shows up as a device
+  # stream that stops finishing steps; the watchdog then ends this rank non-zero and torch.distributed.run stops the others
+  from voicepuppet_amd.parallel import StepWatchdog
+  dog = StepWatchdog(rank=rank) if world > 1 else None
   saved = []
   t0 = time.time()
   for i in range(epochs):
@@ -122,6 +134,10 @@ def main(argv=None):
       fetch += [train_nodes['Gen_loss_GAN'], train_nodes['Gen_loss_L1'], train_nodes['Discrim_loss']]
     vals = sess.run(fetch)
     lr, global_step = vals[1], vals[2]
+    if dog is not None:
+      ev = torch.cuda.Event()
+      ev.record()
+      dog.beat(ev)
     if summary:
       gen_loss_GAN, gen_loss_L1, discrim_loss = vals[3:6]
     if (summary and rank == 0):
@@ -142,6 +158,8 @@ def main(argv=None):
         for suffix in ('.index', '.data-00000-of-00001'):
           if os.path.exists(old + suffix):
             os.remove(old + suffix)
+  if dog is not None:
+    dog.close()
   if world > 1:
     dist.destroy_process_group()
 

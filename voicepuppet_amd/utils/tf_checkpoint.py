@@ -16,6 +16,13 @@ Format (tensorflow/core/util/tensor_bundle, tensorflow/core/lib/io/table*, resta
   <prefix>.data-SSSSS-of-NNNNN    raw little-endian tensor bytes at (shard_id, offset, size).
 A V1 checkpoint (one file, e.g. the slim vgg_16.ckpt download) is the same SSTable with SavedTensorSlices protos as values;
 `read_checkpoint` reads that form too (full-tensor slices, float / int32 / int64 data).
+
+UNPINNED BY TENSORFLOW: this module has never read a file TensorFlow wrote, nor has TensorFlow read one it wrote.  The three
+checkpoints above are external downloads, TensorFlow is not installable in the build container and the reference ships no bundle.
+What pins it: the published format restated above, CRC-32C known answers, and fixtures that tests/golden/make_tf_bundle.py encodes
+byte by byte from that description with its own protobuf / varint / block writer (a SECOND encoding by the same author - exactly how
+a misread of the V1 slice proto hid for a round).  Treat "reads V1 / V2" as "reads what the format description says V1 / V2 is" until
+a real `vgg_16.ckpt` or `pixrefernet-20000` has been through it.
 """
 import os
 import re
