@@ -223,6 +223,10 @@ class BFMNetDataGenerator(DataGenerator):
 
 
 class _MfccIterator(DatasetIterator):
+  def __init__(self, ds):
+    DatasetIterator.__init__(self, ds)
+    self._seed = random.getrandbits(64)     # drawn where the iterator is made, on the caller's thread (see _host_batches)
+
   def get_next(self):
     g, b = self.ds.owner, self.ds.batch_size
     T = g.SLICE
@@ -239,8 +243,8 @@ class _MfccIterator(DatasetIterator):
     q = queue.Queue(maxsize=2)
     stop = threading.Event()
     END = object()
-    # the worker's draws come from a generator of its own, seeded here - on the caller's thread - from the module-level state
-    self.ds.owner._private_random = random.Random(random.getrandbits(64))
+    # the worker's draws come from a generator of its own, seeded from the module-level state when the iterator was made
+    self.ds.owner._private_random = random.Random(self._seed)
     nxt = DatasetIterator.next_batch
     me = weakref.ref(self)                 # the thread must not keep the iterator alive: dropping the iterator stops the thread
 
