@@ -11,6 +11,10 @@ except the f32 generator output and discriminator logits); packed weights; mater
 Outputs_FG where it enters the discriminator / VGG batches; every stored gradient tensor (loss seeds, backward-data
 results incl. the read-modify-write accumulation over skip consumers, batch-norm backward output).  Accumulation,
 batch-norm statistics, losses and weight gradients are not rounded (f32/f64 on the device).
+
+`hi` (round 4): generator tensors the device keeps in float32 (batch-normalised few-pixel tensors, <= 256 pixels: DESIGN.md "few-pixel
+tensors stay float32"): their raw output and their accumulated gradient are rounded to float32, not to the compute dtype; the
+materialised activations and the batch-norm backward's result (both MFMA operands) are still rounded to the compute dtype.
 """
 import numpy as np
 
@@ -59,8 +63,8 @@ def _per_group(y, arr, groups):
 class Net(object):
   """One sub-network (generator / discriminator) in device dataflow."""
 
-  def __init__(self, spec, params, prefix, q, groups=1):
-    self.spec, self.p, self.prefix, self.q, self.groups = spec, params, prefix, q, groups
+  def __init__(self, spec, params, prefix, q, groups=1, hi=()):
+    self.spec, self.p, self.prefix, self.q, self.groups, self.hi = spec, params, prefix, q, groups, frozenset(hi)
     self.y, self.xa, self.bn, self.dy_log = {}, {}, {}, {}
 
   def wname(self, scope, kind):
@@ -83,7 +87,7 @@ class Net(object):
       w = q(self.p[self.wname(scope, kind)])
       bias = None if bn else f32(self.p[self.wname(scope, kind).replace('kernel', 'bias')])
       y = ops.conv2d_fwd(x, w, bias, stride, 1) if kind == 'conv' else ops.deconv4s2_fwd(x, w, bias)
-      y = f32(y) if final else q(y)            # thin f32 outputs are not rounded
+      y = f32(y) if (final or scope in self.hi) else q(y)            # thin f32 outputs / float32 few-pixel tensors are not rounded
       if y_override is not None and scope in y_override:
         o = np.asarray(y_override[scope], dtype=np.float64)
         self.fwd_err[scope] = float(np.linalg.norm(y - o) / max(np.linalg.norm(o), 1e-30))
@@ -145,7 +149,8 @@ class Net(object):
           din[s] = q(g)
           continue
         g = g * ACT_GRAD[pre](xv)                  # masks from the sign of the STORED activation
-        dz[s] = q(g) if s not in dz else q(dz[s] + g)   # read-modify-write accumulation over skip consumers
+        qa = f32 if s in self.hi else q            # a float32 few-pixel tensor accumulates its gradient in float32
+        dz[s] = qa(g) if s not in dz else qa(dz[s] + g)   # read-modify-write accumulation over skip consumers
       self.dy_log[scope] = d
     return grads, din
 
@@ -166,7 +171,7 @@ def _dspec(ndf):
 
 
 def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64, l1_weight=500.0, gan_weight=1.0, q=round_bf16,
-                     out4_override=None, g_override=None, d_override=None):
+                     out4_override=None, g_override=None, d_override=None, hi=()):
   """Same contract as pixrefer_ref.forward_backward (inputs in [0,1]); q = IDENT gives the float64 graph.
   out4_override: use this generator output (post-tanh, [N,H,H,4]) for everything downstream of the generator.  The
   generator's own bottleneck (batch-norm over N*1*1 .. N*4*4 values) amplifies single-ulp differences chaotically, so a
@@ -177,7 +182,7 @@ def forward_backward(p, inputs, fg_inputs, targets, masks, ngf=64, ndf=64, l1_we
   N = inputs.shape[0]
   inp, fg, tgt = f32(f32(inputs) * 2 - 1), f32(f32(fg_inputs) * 2 - 1), f32(f32(targets) * 2 - 1)
   masks = f32(masks)
-  G = Net(_gspec(ngf), p, 'generator', q)
+  G = Net(_gspec(ngf), p, 'generator', q, hi=hi)
   y4 = G.forward({'inputs': q(inp), 'fg_inputs': q(fg[..., :3])}, g_override)
   out4 = np.tanh(y4) if out4_override is None else f32(out4_override)
   outputs, alphas, outputs_fg = ref.composite(out4, tgt)

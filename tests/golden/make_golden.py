@@ -13,6 +13,8 @@
   full_width_n4.npz  the same three steps on a batch of FOUR different samples (every batch-norm has real statistics, the 1x1
                      bottleneck included), with a strided sample of every step-1 gradient tensor
                      (`python tests/golden/make_golden.py full_n4`: ~10 minutes)
+  full_width_512_n2.npz  ONE step at 512 x 512 (BASELINE config 4's image size) on two samples, same contents as full_width_n4
+                     (`python tests/golden/make_golden.py full_512`: ~10 minutes)
   frame_pack.npz     input pipeline: uint8 triptych frames + crops -> packed float tensors by the host path (PIL bilinear)
   logmel.npz         log-mel of a seeded 4096-sample chirp+noise, and the 257x80 mel matrix
   bfmnet.npz         BFMNet coefficients for a seeded 5-frame clip (parameters regenerated from the seed)
@@ -205,6 +207,49 @@ def full_width_batch(panels, bg, nsamp=4):
   np.savez_compressed(os.path.join(HERE, "full_width_n%d.npz" % nsamp), **d)
 
 
+def batch_512(frame, face3d, matte):
+  """BASELINE config 4's image size at a batch the float64 oracle can afford: TWO 512 x 512 samples (sample/22.jpg at its native size
+  and a mirrored, re-lit variant), quantised to uint8 exactly as the device is fed.  (At 512 x 512 the deepest tensor is 2 x 2, so a
+  batch of two still gives every batch-norm eight or more values per channel - unlike N = 2 at 256 x 256.)
+  tests/test_gpu_fullwidth.py rebuilds the batch from the three stored panels with the same four lines."""
+  f, a, m = [x.astype(np.float64) / 255.0 for x in (frame, face3d, matte)]
+  variants = [(f, a, m), (f[:, ::-1] * 0.8 + 0.1, np.roll(a[:, ::-1], 7, axis=0), m[:, ::-1])]
+  inputs = np.stack([np.concatenate([a, v[1]], axis=-1) for v in variants])
+  fg = np.stack([np.concatenate([f * m, v[0] * v[2]], axis=-1) for v in variants])
+  targets, masks = np.stack([v[0] for v in variants]), np.stack([v[2] for v in variants])
+  return [(x * 255).round().astype(np.uint8) for x in (inputs, fg, targets, masks)]
+
+
+def full_width_512():
+  """config 4 (512 x 512, 8 per GPU) was checked through size-independent properties only.  ONE G+D step at ngf = ndf = 64
+  on the two-sample 512 x 512 batch above: losses, output crops, per-tensor gradient norms and the strided gradient samples of
+  full_width_batch.  (`python tests/golden/make_golden.py full_512`: ~10 minutes.)"""
+  from PIL import Image
+  img = Image.open(os.path.join(REF, "sample", "22.jpg")).convert("RGB")
+  assert img.size == (1536, 512)
+  frame, face3d, matte = [np.asarray(img.crop((k * 512, 0, (k + 1) * 512, 512))) for k in range(3)]
+  ngf = ndf = 64
+  seed = 17
+  u8 = batch_512(frame, face3d, matte)
+  inputs, fg, targets, masks = [x.astype(np.float64) / 255.0 for x in u8]
+  p = {k: v.astype(np.float64) for k, v in ref.init_params(ngf, ndf, seed=seed, dtype=np.float32).items()}
+  st = ref.TrainState({k: v.copy() for k, v in p.items()}, ngf, ndf, f32_probs=True)
+  nodes = st.step(inputs, fg, targets, masks)
+  keys = ("Discrim_loss", "Gen_loss_GAN", "Gen_loss_L1", "Gen_loss", "Perceptual_loss")
+  names = sorted(nodes["Gen_grads"]) + sorted(nodes["Discrim_grads"])
+  grads = [nodes["Gen_grads" if n.startswith("generator") else "Discrim_grads"][n] for n in names]
+  samp = []
+  for n, g in zip(names, grads):
+    want = 32768 if (n.endswith("kernel") and any(("/%s/" % b) in n for b in BOTTLENECK)) else 4096
+    samp.append(g.reshape(-1)[grad_sample_index(g.size, want)])
+  d = {"seed": seed, "ngf": ngf, "frame": frame, "face3d": face3d, "matte": matte, "grad_names": np.array(names),
+       "losses": np.array([nodes[k] for k in keys]), "Outputs_crop": nodes["Outputs"][:, 192:320, 192:320].astype(np.float32),
+       "grad_norms": np.array([np.linalg.norm(g) for g in grads]), "grad_sample_sizes": np.array([len(x) for x in samp]),
+       "grad_samples": np.concatenate(samp).astype(np.float32), "saturated_fake_predictions": int((nodes["Predict_fake"] == 1).sum())}
+  print("full-width 512x512 N=2", dict(zip(keys, d["losses"])), flush=True)
+  np.savez_compressed(os.path.join(HERE, "full_width_512_n2.npz"), **d)
+
+
 def frame_pack():
   """Input-pipeline fixture: uint8 triptych frames + crops -> the four packed float tensors, computed by the
   host path (PIL bilinear on float planes standing in for cv2.resize, generator.py:956-1019)."""
@@ -290,6 +335,9 @@ if __name__ == "__main__":
     sys.exit(0)
   if sys.argv[1:] == ["full_n4"]:
     full_width_batch(*sample22(), nsamp=4)
+    sys.exit(0)
+  if sys.argv[1:] == ["full_512"]:
+    full_width_512()
     sys.exit(0)
   if sys.argv[1:] == ["raster"]:
     raster()

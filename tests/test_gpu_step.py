@@ -192,8 +192,12 @@ def test_step_parity_bf16_against_rounding_aware_oracle(oracle_step):
   p64 = {k: v.astype(np.float64) for k, v in o["params"].items()}
   g_dev = {sc: eng.tensor("g/" + sc).float().cpu().numpy() for sc, *_ in ref.generator_spec(o["ngf"])}
   d_dev = {sc: eng.tensor("d/" + sc).float().cpu().numpy() for sc, *_ in ref.discriminator_spec(o["ndf"])}
+  # the few-pixel batch-normalised tensors are float32 on the device (round 4): the oracle rounds them to float32 as well
+  hi = {sc for sc, *_ in ref.generator_spec(o["ngf"]) if sc != "decoder_1" and eng.tensor("g/" + sc).dtype == torch.float32}
+  print("\n[float32 few-pixel tensors]", sorted(hi))
+  assert "merged_encoder_5" in hi and "merged_decoder_5" in hi and "encoder_2" not in hi
   nodes = lowp.forward_backward(p64, *[b.astype(np.float64) for b in o["batch"]], ngf=o["ngf"], ndf=o["ndf"], q=lowp.round_bf16,
-                                out4_override=out4, g_override=g_dev, d_override=d_dev)
+                                out4_override=out4, g_override=g_dev, d_override=d_dev, hi=hi)
   # layer-by-layer forward parity of the generator: each layer recomputed from the device's own previous tensors
   fwd = nodes["G"].fwd_err
   print("\n[bf16 generator forward, per layer from device inputs] worst:", sorted(((v, k) for k, v in fwd.items()), reverse=True)[:4])
@@ -224,7 +228,12 @@ def test_step_parity_bf16_against_rounding_aware_oracle(oracle_step):
   # (before the discriminator was teacher-forced too, d_din of this 8-channel mini net moved between 1.5e-2 and 3.7e-2 with anything
   # that changes one bf16 rounding upstream - the split-K setting of a layer, the summation order of the generator's bottleneck)
   assert max(mid.values()) < 3e-2, mid
-  bad = {k: v for k, v in worst.items() if v > 5e-2}   # measured worst: 3.0e-2 (a bias gradient), typical 1e-2
+  # merged_encoder_5's output is 1x1: at this fixture's N = 2 its batch-norm is over TWO values per channel, whose backward pass
+  # vanishes analytically - what reaches the layer's kernel gradient is rounding residue, and since round 4 the device forms it from
+  # float32 tensors in float32 arithmetic where the oracle rounds float64 results to float32 (measured 5.8e-2; the well-posed case,
+  # N = 4 at full width, is test_gpu_fullwidth.py::test_bf16_generator_gradients_at_full_width_against_the_rounding_aware_oracle: 5e-3)
+  bound = lambda k: 1.5e-1 if "/merged_encoder_5/" in k else 5e-2
+  bad = {k: v for k, v in worst.items() if v > bound(k)}   # measured worst elsewhere: 4.2e-2 (a batch-norm gamma), typical 1e-2
   assert not bad, bad
 
 

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
   float* coef = reinterpret_cast<float*>(smem + 128);  // [5][32] per-channel coefficients of the final pass
   float* red = reinterpret_cast<float*>(smem + SP_HDR);   // [4 waves][PT][SP_PITCH]
   const IgemmArgs& a = s.g;
+  const bool hi = MODE != SP_PLAIN && sizeof(T) == 2 && s.hi != 0;     // float32 storage of the batch-normalised tensor (smallp_args.h)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
       const int tap = tv >> 24, dh = (int)(signed char)((tv >> 8) & 0xff), dw = (int)(signed char)(tv & 0xff);
       const T* wp = wbase + (size_t)(tap * cpt + cc) * wstep;
 #pragma unroll
-      for (int tc = 0; tc < 2; ++tc) fa[u][tc] = *(live ? reinterpret_cast<const uint4*>(wp + tc * 16 * KC) : zeros);
+      for (int tc = 0; tc < 2; ++tc) fa[u][tc] = *(live ? reinterpret_cast<const uint4*>(wp + tc * 16 * KC) : zeros);   // (streamed `nt` weight loads: +-0, EXPERIMENTS.md)
       const int c = cc * KC + (lane >> 4) * E;
       const bool s1 = c >= C0;
       const T* xb = s1 ? x1 : x0;
@@ -254,18 +255,24 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
           }
           if (a.accumulate) {
             float old[8];
-            load8<T>(reinterpret_cast<const T*>(a.Y) + off, old);
+            if (hi) load8<float>(reinterpret_cast<const float*>(a.Y) + off, old);
+            else load8<T>(reinterpret_cast<const T*>(a.Y) + off, old);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += old[e];
           }
         }
-        store8t_wt<T>(rs_y, off, v);
+        if (hi) {
+          store8t_wt<float>(rs_y, off, v);               // float32 tensor: nothing is rounded, the statistics see what is stored
+        } else {
+          store8t_wt<T>(rs_y, off, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = round_as_stored(v[e], (T*)nullptr);
+          for (int e = 0; e < 8; ++e) v[e] = round_as_stored(v[e], (T*)nullptr);
+        }
       }
       if (MODE == SP_BWD_BN) {
         float y[8];
-        load8<T>(reinterpret_cast<const T*>(s.bn_y) + off, y);
+        if (hi) load8<float>(reinterpret_cast<const float*>(s.bn_y) + off, y);
+        else load8<T>(reinterpret_cast<const T*>(s.bn_y) + off, y);
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = v[e] * ((y[e] - s.bn_mu[c0 + e]) * s.bn_rstd[c0 + e]);
       }
@@ -336,8 +343,13 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
       const int idx = idx0 + u * 256;
       const int ii = idx < NP * 4 ? idx : idx0;
       const size_t off = (size_t)(ii >> 2) * a.ldY + ct * SP_CT + (ii & 3) * 8;
-      load8<T>(reinterpret_cast<const T*>(a.Y) + off, f[u]);
-      if (MODE == SP_BWD_BN) load8<T>(reinterpret_cast<const T*>(s.bn_y) + off, y[u]);
+      if (hi) {
+        load8<float>(reinterpret_cast<const float*>(a.Y) + off, f[u]);
+        if (MODE == SP_BWD_BN) load8<float>(reinterpret_cast<const float*>(s.bn_y) + off, y[u]);
+      } else {
+        load8<T>(reinterpret_cast<const T*>(a.Y) + off, f[u]);
+        if (MODE == SP_BWD_BN) load8<T>(reinterpret_cast<const T*>(s.bn_y) + off, y[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < FU; ++u) {
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
           const float zh = (y[u][e] - coef[64 + k]) * coef[96 + k];
           f[u][e] = coef[128 + k] * (f[u][e] - coef[k] - zh * coef[32 + k]);
         }
-        store8t<T>(reinterpret_cast<T*>(a.Y) + off, f[u]);
+        store8t<T>(reinterpret_cast<T*>(hi ? s.dy_out : a.Y) + off, f[u]);
       }
     }
   }
@@ -396,6 +408,7 @@ hipError_t launch_smallp(const SmallPArgs& s, int is_bf16, hipStream_t st) {
   const int Pc = a.N * a.Hg * a.Wg;
   const int npt = (Pc + PT - 1) / PT;
   if (a.CoutPad % SP_CT || !s.cnt || !a.zeros || (a.splitk > 1 && !s.slab) || (s.mode != SP_PLAIN && !s.part)) return hipErrorInvalidValue;
+  if (s.hi && (!is_bf16 || s.mode == SP_PLAIN || (s.mode == SP_BWD_BN && !s.dy_out))) return hipErrorInvalidValue;
   dim3 grid((a.CoutPad / SP_CT) * a.nclass * npt, a.splitk, 1);
   if (is_bf16) {
     if (npt_t == 1) return launch_smallp_t<bf16, 1>(s, grid, st);

@@ -66,6 +66,13 @@ struct Tens {
   int n_bwd_consumers = 0;    // layers whose backward-data pass writes into dz
   int dz_writes = 0;          // ... of which have run in the current backward pass
   bool bn_bwd_done = false;   // the batch-norm backward of this tensor ran inside the last writer's launch (conv_smallp.hip, SP_BWD_BN)
+  // bf16 plans: a batch-normalised tensor whose producer and every gradient contribution run on the few-pixel kernel (<= 256 pixels per
+  // launch class, i.e. N*1*1 .. N*8*8 values per channel at small batches) is kept in FLOAT32: y (raw output) is a float buffer and the
+  // gradient accumulates in dz32; dz stays the bf16 dL/dy the producer's weight / data gradients read (smallp_args.h `hi`).  The
+  // batch-norm backward over so few values subtracts two projections from the tensor - with bf16 storage the rounding of the tensor was
+  // of the size of the result (element-wise gradient errors of 0.35-0.75 against the float64 oracle).
+  bool hi = false;
+  void* dz32 = nullptr;
   size_t elems() const { return (size_t)N * H * W * C; }
 };
 
@@ -381,6 +388,14 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
     }
   }
   n.packed_elems = pk;
+  {
+    static const bool hi_on = !getenv("VP_NO_F32_FEWPIXEL");
+    for (Tens& t : n.t) t.hi = hi_on && bf16 && t.has_bn && n.groups == 1 && alt_batch == 0 && t.producer >= 0 && n.l[t.producer].fwd.a.patch == 3;
+    if (training)
+      for (Layer& L : n.l)
+        for (int s = 0; s < L.nsrc; ++s)
+          if (L.need_bwd[s] && L.bwd[s].a.patch != 3) n.t[L.src[s]].hi = false;
+  }
   for (size_t i = 0; i < n.l.size(); ++i) n.l[i].desc1 = i + 1 < n.l.size() ? n.l[i + 1].desc0 : n.descs.size();
   for (Tens& t : n.t) t.n_bwd_consumers = 0;
   n.sp_cnt_n = 0;
@@ -400,7 +415,7 @@ static void carve_net(Net& n, Arena& ar, int es, bool training) {
     if (t.name == "decoder_1" || t.name == "layer_5") {   // thin f32 outputs live in the plan-level buffers
       continue;
     }
-    if (!t.is_input) t.y = ar.alloc(t.elems() * es);
+    if (!t.is_input) t.y = ar.alloc(t.elems() * (t.hi ? sizeof(float) : (size_t)es));
     for (int k = 1; k < 3; ++k) if (t.need_act[k]) t.xa[k] = ar.alloc(t.elems() * es);
     if (t.has_bn) {
       const size_t gc = (size_t)n.groups * t.C * sizeof(float);
@@ -460,7 +475,7 @@ static size_t carve_all(vp_pixrefer* h, char* base, size_t cap, std::vector<std:
     carve_net(h->D, ar, es, true);
     carve_net(h->V, ar, es, true);
     // gradient buffers.  generator + discriminator: one per non-input tensor.
-    for (Tens& t : h->G.t) if (!t.is_input && t.name != "decoder_1") t.dz = ar.alloc(t.elems() * es);
+    for (Tens& t : h->G.t) if (!t.is_input && t.name != "decoder_1") { t.dz = ar.alloc(t.elems() * es); if (t.hi) t.dz32 = ar.alloc(t.elems() * sizeof(float)); }
     for (Tens& t : h->D.t) if (!t.is_input && t.name != "layer_5") { t.dz = ar.alloc(t.elems() * es); t.dz2 = ar.alloc(t.elems() / 3 * es); }
     // VGG backward runs on the fake half only
     for (Tens& t : h->V.t) if (!t.is_input) t.dz = ar.alloc(t.elems() / 2 * es);
@@ -615,6 +630,7 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
     for (int c = 0; c < 4; ++c) sp.tap_mask[c] = a.sp_mask[c];
     sp.slab = a.partial; sp.cnt = a.sp_cnt; sp.part = bnp_of(h, ss);
     sp.mode = L.has_bn ? SP_FWD_BN : SP_PLAIN;
+    sp.hi = to.hi ? 1 : 0;               // float32 raw output + statistics of the unrounded values (Tens::hi)
     if (L.has_bn) {
       sp.gamma = n.params + L.gamma_off; sp.beta = n.params + L.beta_off;
       sp.aff_a = to.bn.a; sp.aff_b = to.bn.b; sp.mu = to.bn.mu; sp.rstd = to.bn.rstd;
@@ -734,6 +750,10 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       a.accumulate = 0;
     } else {
       a.Y = gpass ? ts.dz2 : ts.dz;
+      if (ts.hi) {
+        if (gpass || alt || a.patch != 3) { set_err("%s: float32 few-pixel tensor %s reached by a launch that is not the few-pixel kernel", L.scope.c_str(), ts.name.c_str()); return VP_ERR_STATE; }
+        a.Y = ts.dz32; a.y_f32 = 1;        // the gradient accumulates in float32 (Tens::hi)
+      }
       bool& written = gpass ? ts.dz2_written : ts.dz_written;
       a.accumulate = written ? 1 : 0;
       written = true;
@@ -759,9 +779,11 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       sp.slab = a.partial; sp.cnt = a.sp_cnt; sp.part = bn_partial;
       static const bool fuse_bn = !getenv("VP_SMALLP_NO_BNBWD");
       const bool last = !ts.is_input && !gpass && ts.has_bn && ts.producer >= 0 && ts.dz_writes == ts.n_bwd_consumers && n.groups == 1;
-      if (fuse_bn && last) {
+      if (ts.hi && !last && ts.dz_writes == ts.n_bwd_consumers) { set_err("%s: float32 tensor %s needs its batch-norm backward in the launch", L.scope.c_str(), ts.name.c_str()); return VP_ERR_STATE; }
+      if ((fuse_bn || ts.hi) && last) {
         const Layer& Lp = n.l[ts.producer];
         sp.mode = SP_BWD_BN;
+        if (ts.hi) { sp.hi = 1; sp.dy_out = ts.dz; sp.g.y_f32 = 0; }      // dz32 / y in float32, dL/dy out as T into dz
         sp.bn_y = ts.y; sp.bn_mu = ts.bn.mu; sp.bn_rstd = ts.bn.rstd; sp.bn_gamma = n.params + Lp.gamma_off;
         sp.c1 = ts.bn.c1; sp.c2 = ts.bn.c2;
         sp.dgamma = n.grads + Lp.gamma_off; sp.dbeta = n.grads + Lp.beta_off; sp.dbias_zero = n.grads + Lp.b_off;
@@ -782,6 +804,7 @@ static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample
                       int ss = 0, bool gpass = false) {
   Tens& t = n.t[L.out];
   if (!gpass && t.bn_bwd_done) { t.bn_bwd_done = false; return VP_OK; }   // done inside the last gradient contribution's launch (conv_smallp.hip)
+  if (t.hi) { set_err("%s: the batch-norm backward of a float32 few-pixel tensor runs inside the few-pixel launch only", L.scope.c_str()); return VP_ERR_STATE; }
   BnArgs b;
   memset(&b, 0, sizeof(b));
   b.y = (const char*)t.y + (size_t)sample0 * t.H * t.W * t.C * h->es;
@@ -921,7 +944,7 @@ int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d) {
     for (const Tens& t : n->t) {
       const std::string nm = t.name;
       if (t.name == "decoder_1" || t.name == "layer_5") continue;       // thin f32 outputs live in handle-level buffers (checked below)
-      region_of(t.y, t.elems() * es, (nm + ".y").c_str());
+      region_of(t.y, t.elems() * (t.hi ? 4 : es), (nm + ".y").c_str());
       for (int k = 1; k < 3; ++k) if (t.need_act[k]) region_of(t.xa[k], t.elems() * es, (nm + ".xa").c_str());
       if (t.has_bn) {
         const size_t gc = (size_t)n->groups * t.C * sizeof(float);
@@ -931,6 +954,7 @@ int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d) {
       if (d->training && !t.is_input) {
         const size_t div = n == &h->V ? 2 : 1;
         region_of(t.dz, t.elems() / div * es, (nm + ".dz").c_str());
+        if (t.hi) region_of(t.dz32, t.elems() * 4, (nm + ".dz32").c_str());
         if (n == &h->D) region_of(t.dz2, t.elems() / 3 * es, (nm + ".dz2").c_str());
       }
     }
@@ -1530,7 +1554,9 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     } else {
       if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, s2, ss))) return rc;
     }
-    // a bucket of the gradient arena is final (stage boundaries above): its Adam update + re-pack, on the branch stream
+    // a bucket of the gradient arena is final (stage boundaries above): its Adam update + re-pack, on the side stream
+    // (holding the first bucket's update back until the end of stage 1, so that it does not run beside the weight-streaming few-pixel
+    // layers of that stage, was measured: +0.02 .. 0.08 ms at batch 4, +-0 at 8 / 32 - EXPERIMENTS.md)
     if (h->upd.active && (i == i_md5 || i == i_me2 || i == 0)) {
       const int l0 = i, l1 = i == i_md5 ? (int)G.l.size() - 1 : (i == i_me2 ? i_md5 - 1 : i_me2 - 1);
       const size_t off0 = G.l[l0].w_off, off1 = l1 + 1 < (int)G.l.size() ? G.l[l1 + 1].w_off : G.nparams;
@@ -1612,7 +1638,8 @@ int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t s
   if (k != std::string::npos) { field = rest.substr(k + 1); rest = rest.substr(0, k); }
   for (Tens& t : n->t) {
     if (t.name != rest) continue;
-    if (field.empty()) return ret(t.y, t.N, t.H, t.W, t.is_f32 ? (t.name == "decoder_1" ? 4 : 1) : t.C, t.is_f32 ? VP_F32 : cd);
+    if (field.empty()) return ret(t.y, t.N, t.H, t.W, t.is_f32 ? (t.name == "decoder_1" ? 4 : 1) : t.C, (t.is_f32 || t.hi) ? VP_F32 : cd);
+    if (field == "dz32") return t.hi ? ret(t.dz32, t.N, t.H, t.W, t.C, VP_F32) : VP_ERR_ARG;
     if (field == "dy") return ret(t.dz, n == &h->V ? t.N / 2 : t.N, t.H, t.W, t.C, cd);
     if (!t.has_bn) return VP_ERR_ARG;
     if (field == "scale") return ret(t.bn.a, n->groups, t.C, 1, 1, VP_F32);

@@ -29,6 +29,13 @@ struct SmallPArgs {
   const void* bn_y;
   const float* bn_mu; const float* bn_rstd; const float* bn_gamma;
   float* c1; float* c2; float* dgamma; float* dbeta; float* dbias_zero;
+  // f32 storage of a few-pixel tensor on the bf16 path (hi != 0; DESIGN.md "few-pixel tensors stay float32"): a batch-norm over N*1*1 ..
+  // N*8*8 values per channel subtracts two projections from the tensor, and bf16 rounding of the tensor (2^-9) is then of the order of
+  // what is left.  SP_FWD_BN: g.Y (the raw output) is float, statistics of the unrounded values, the consumers' activations stay T.
+  // SP_BWD_BN: g.Y (the accumulated dz) and bn_y are float; the batch-norm backward's result dL/dy goes to dy_out as T (the MFMA operand
+  // of the producer's weight / data gradients).  SP_PLAIN contributions to such a tensor use g.y_f32.
+  int hi;
+  void* dy_out;
 };
 
 }  // namespace vp
