@@ -383,6 +383,12 @@ int vp_maxpool_hw_bwd(const float* x, const float* dy, float* dx, int b, int h, 
 int vp_stem_im2col(const float* x, float* col, int b, int h, int w, void* stream);
 int vp_gru_train_fwd(const float* xg, const float* xc, const float* whg, const float* whc, const int* seq_len, float* out, float* r, float* u, float* c,
                      float* hprev, int b, int t, void* stream);
+/* glue of the training step (bias gradients = column sums over the B*T rows, the recurrent halves of the GRUCell kernels split and
+ * transposed in one launch, element-wise products of the dropout masks / gate products, the ear padding of bfmnet.py:117,210) */
+int vp_colsum_f32(const float* x, int rows, int cols, float* out, void* stream);
+int vp_gru_split_recurrent(const float* gates_kernel, const float* cand_kernel, float* whg, float* whc, float* whg_t, float* whc_t, void* stream);
+int vp_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream);
+int vp_add_ears_f32(float* out, const float* ears, int rows, void* stream);
 int vp_gru_train_bwd(const float* dout, const float* whg_t, const float* whc_t, const int* seq_len, const float* r, const float* u, const float* c,
                      const float* hprev, float* dag, float* dac, int b, int t, void* stream);
 int vp_vertex_loss_partials(int b, int j);

@@ -204,3 +204,8 @@ def test_training_step_holds_no_vendor_gemm():
           bad.append("%s:%d %s" % (os.path.join(d, f), line, text.strip()[:80]))
   assert not bad, bad
   assert not os.path.exists(os.path.join(root, "bfmnet", "gemm_tuning"))
+  # nor the at::native reductions / transposes / copies the step still ran in round 3 (bias gradients through
+  # torch.sum, the recurrent kernels through .t().contiguous() and [256:].contiguous(), the output through .clone())
+  eng = open(os.path.join(root, "bfmnet", "train_engine.py")).read()
+  for pat in (r"torch\.sum\(", r"\.t\(\)\.contiguous\(\)", r"\[256:\]\.contiguous\(\)", r"\bo\.clone\(\)"):
+    assert not re.search(pat, eng), pat

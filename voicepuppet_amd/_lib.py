@@ -148,6 +148,10 @@ _SIGNATURES = {
     "vp_stem_im2col": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "vp_gru_train_fwd": (ctypes.c_int, [_P] * 10 + [ctypes.c_int, ctypes.c_int, _P]),
     "vp_gru_train_bwd": (ctypes.c_int, [_P] * 10 + [ctypes.c_int, ctypes.c_int, _P]),
+    "vp_colsum_f32": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "vp_gru_split_recurrent": (ctypes.c_int, [_P] * 7),
+    "vp_mul_f32": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
+    "vp_add_ears_f32": (ctypes.c_int, [_P, _P, ctypes.c_int, _P]),
     "vp_vertex_loss_partials": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "vp_bfm_vertex_loss": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "vp_sumsq_partials": (ctypes.c_int, [ctypes.c_size_t]),

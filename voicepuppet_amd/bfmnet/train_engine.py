@@ -322,6 +322,17 @@ class BFMNetTrainEngine:
                                            P, K, N, _ptr(self._mm_ws(P, K, N)), _stream()), "vp_mm_bwd_data_f32")
     return dx
 
+  def _colsum(self, x, out):
+    """out[c] = sum over rows of x: the bias gradients (vp_colsum_f32; it was torch.sum, an at::native reduction)"""
+    assert x.is_contiguous() and out.is_contiguous() and out.numel() == x.shape[1]
+    _lib.check(self.L.vp_colsum_f32(_ptr(x), int(x.shape[0]), int(x.shape[1]), _ptr(out), _stream()), "vp_colsum_f32")
+
+  def _mul(self, a, b):
+    out = torch.empty_like(a)
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    _lib.check(self.L.vp_mul_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "vp_mul_f32")
+    return out
+
   def _mm_dw(self, x, dy, out, k_real=None):
     """x [P, K]^T . dy [P, N] -> out [k_real, N] (contiguous; k_real < K: x carries zero padding columns, the stem)"""
     P, K = x.shape
@@ -483,7 +494,10 @@ class BFMNetTrainEngine:
     wg, wc = p[GRU + "gates/kernel"], p[GRU + "candidate/kernel"]
     xg = self._mm(c1, wg[:256], p[GRU + "gates/bias"])
     xc = self._mm(c1, wc[:256], p[GRU + "candidate/bias"])
-    whg, whc = wg[256:].contiguous(), wc[256:].contiguous()
+    # the recurrent halves of the two GRUCell kernels, as they are (forward) and transposed (backward): one launch, no at::native copies
+    whg, whg_t = (torch.empty(256, 512, dtype=torch.float32, device=self.dev), torch.empty(512, 256, dtype=torch.float32, device=self.dev))
+    whc, whc_t = (torch.empty(256, 256, dtype=torch.float32, device=self.dev), torch.empty(256, 256, dtype=torch.float32, device=self.dev))
+    _lib.check(L.vp_gru_split_recurrent(_ptr(wg), _ptr(wc), _ptr(whg), _ptr(whc), _ptr(whg_t), _ptr(whc_t), _stream()), "vp_gru_split_recurrent")
     rnn, sr, su, scand, shp = (torch.empty(B * T, 256, dtype=torch.float32, device=self.dev) for _ in range(5))
     _lib.check(L.vp_gru_train_fwd(_ptr(xg), _ptr(xc), _ptr(whg), _ptr(whc), _ptr(seq), _ptr(rnn), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), B, T,
                                   _stream()), "vp_gru_train_fwd")
@@ -492,8 +506,8 @@ class BFMNetTrainEngine:
     d0 = dense(rnn_m, "bfm_coeff_decoder/dense/kernel", "bfm_coeff_decoder/dense/bias", ACT_LRELU, mk("d0", 128))
     d1 = dense(d0, "bfm_coeff_decoder/dense_1/kernel", "bfm_coeff_decoder/dense_1/bias", ACT_LRELU, mk("d1", 64))
     o = dense(d1, "bfm_coeff_decoder/dense_2/kernel", "bfm_coeff_decoder/dense_2/bias", ACT_NONE, None)
-    o = o.clone()
-    o[:, 16:20] += (ears.reshape(B * T, 1) * self.ears_scale)                       # + tf.pad(ears * [-2,-2,-2,-4], [16, 44])
+    # + tf.pad(ears * [-2,-2,-2,-4], [16, 44]), in place (the last dense layer has no activation: its backward never reads its output)
+    _lib.check(L.vp_add_ears_f32(_ptr(o), _ptr(ears.reshape(B * T).contiguous()), B * T, _stream()), "vp_add_ears_f32")
     self.last_out = o.view(B, T, 64)
 
     loss_data, do = self._vertex_loss(o, bfm_coeffs, seq)
@@ -506,26 +520,25 @@ class BFMNetTrainEngine:
       dz = dy if (act == ACT_NONE and mask is None) else self._act_bwd(dy, y, act, mask)
       def wg(x=x, dz=dz, wname=wname, bname=bname):
         self._mm_dw(x, dz, g[wname])
-        torch.sum(dz, 0, out=g[bname])
+        self._colsum(dz, g[bname])
       self._fork(wg, x, dz)
       return self._mm_dx(dz, p[wname])
     d = dense_bwd(do)
     d = dense_bwd(d)
     d = dense_bwd(d)                                                                 # d loss / d rnn_m
     if mr is not None:
-      d = d * mr
+      d = self._mul(d, mr)
     dag, dac = torch.empty(B * T, 512, dtype=torch.float32, device=self.dev), torch.empty(B * T, 256, dtype=torch.float32, device=self.dev)
-    whg_t, whc_t = wg[256:].t().contiguous(), wc[256:].t().contiguous()             # the backward kernel reads the recurrent kernels transposed
     _lib.check(L.vp_gru_train_bwd(_ptr(d.contiguous()), _ptr(whg_t), _ptr(whc_t), _ptr(seq), _ptr(sr), _ptr(su), _ptr(scand), _ptr(shp), _ptr(dag), _ptr(dac),
                                   B, T, _stream()), "vp_gru_train_bwd")
-    srh = sr * shp
+    srh = self._mul(sr, shp)
     def gru_wg():
       self._mm_dw(c1, dag, g[GRU + "gates/kernel"][:256])
       self._mm_dw(shp, dag, g[GRU + "gates/kernel"][256:])
-      torch.sum(dag, 0, out=g[GRU + "gates/bias"])
+      self._colsum(dag, g[GRU + "gates/bias"])
       self._mm_dw(c1, dac, g[GRU + "candidate/kernel"][:256])
       self._mm_dw(srh, dac, g[GRU + "candidate/kernel"][256:])
-      torch.sum(dac, 0, out=g[GRU + "candidate/bias"])
+      self._colsum(dac, g[GRU + "candidate/bias"])
     self._fork(gru_wg, c1, shp, srh, dag, dac)
     d = self._mm_dx(dag, wg[:256])
     self._mm_dx(dac, wc[:256], out=d, accumulate=True)                               # d loss / d c1

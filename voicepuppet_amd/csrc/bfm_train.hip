@@ -630,6 +630,71 @@ int vp_gru_train_bwd(const float* dout, const float* whg_t, const float* whc_t, 
   return VP_OK;
 }
 
+// ---- small glue of the training step that used to run as at::native kernels --------------------------------------
+// out[c] = sum over rows of x[r][c] (bias gradients of the dense / GRU layers, bfmnet.py:194-211): one thread per column, rows in
+// ascending order (deterministic); rows = B * T (96 .. 768), cols <= 512
+__global__ __launch_bounds__(64) void colsum_rows_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  int r = 0;
+  for (; r + 4 <= rows; r += 4) {           // four loads in flight, added in row order
+    const float a0 = x[(size_t)r * cols + c], a1 = x[(size_t)(r + 1) * cols + c], a2 = x[(size_t)(r + 2) * cols + c], a3 = x[(size_t)(r + 3) * cols + c];
+    s += a0; s += a1; s += a2; s += a3;
+  }
+  for (; r < rows; ++r) s += x[(size_t)r * cols + c];
+  out[c] = s;
+}
+int vp_colsum_f32(const float* x, int rows, int cols, float* out, void* stream) {
+  if (!x || !out || rows < 1 || cols < 1) { set_err("vp_colsum_f32: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, rows, cols, out);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// The recurrent halves of tf.contrib.rnn.GRUCell's kernels (bfmnet.py:53: gates/kernel [512, 512] = [x | h] rows, candidate/kernel
+// [512, 256]) as the four images the recurrence kernels read: rows 256.. as they are (forward) and transposed (backward), one launch
+__global__ __launch_bounds__(256) void gru_split_kernel(const float* __restrict__ gk, const float* __restrict__ ck, float* __restrict__ whg,
+                                                        float* __restrict__ whc, float* __restrict__ whg_t, float* __restrict__ whc_t) {
+  const int i = blockIdx.x * 256 + threadIdx.x;                 // over 256 x (512 + 256)
+  if (i >= 256 * 768) return;
+  const int r = i / 768, c = i - r * 768;
+  if (c < 512) { const float v = gk[(size_t)(256 + r) * 512 + c]; whg[r * 512 + c] = v; whg_t[c * 256 + r] = v; }
+  else { const int cc = c - 512; const float v = ck[(size_t)(256 + r) * 256 + cc]; whc[r * 256 + cc] = v; whc_t[cc * 256 + r] = v; }
+}
+int vp_gru_split_recurrent(const float* gates_kernel, const float* cand_kernel, float* whg, float* whc, float* whg_t, float* whc_t, void* stream) {
+  if (!gates_kernel || !cand_kernel || !whg || !whc || !whg_t || !whc_t) { set_err("vp_gru_split_recurrent: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(gru_split_kernel, dim3(768), dim3(256), 0, (hipStream_t)stream, gates_kernel, cand_kernel, whg, whc, whg_t, whc_t);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[i];
+}
+int vp_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream) {
+  if (!a || !b || !out || n < 1) { set_err("vp_mul_f32: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(mul_kernel, dim3(tblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// out[r][16 + k] += ears[r] * (-2, -2, -2, -4)[k]: tf.pad(ears * [-2, -2, -2, -4], [[0,0],[0,0],[16,44]]) added to the decoder output
+// (bfmnet.py:117,210), in place
+__global__ __launch_bounds__(256) void add_ears_rows_kernel(float* __restrict__ out, const float* __restrict__ ears, int rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * 4) return;
+  const int r = i >> 2, k = i & 3;
+  out[(size_t)r * 64 + 16 + k] += ears[r] * (k == 3 ? -4.f : -2.f);
+}
+int vp_add_ears_f32(float* out, const float* ears, int rows, void* stream) {
+  if (!out || !ears || rows < 1) { set_err("vp_add_ears_f32: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(add_ears_rows_kernel, dim3((rows * 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, ears, rows);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
 // number of f64 partials vp_bfm_vertex_loss / vp_sumsq write (sum them on the host or with one more reduction)
 int vp_vertex_loss_partials(int b, int j) { return (int)(((size_t)b * j + 255) / 256); }
 int vp_bfm_vertex_loss(const float* d, const float* vmask, const int* seq_len, int b, int t, int j, float* gd, double* partial, void* stream) {
