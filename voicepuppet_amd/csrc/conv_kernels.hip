@@ -1838,7 +1838,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   ProfScope prof(use_patch ? "patch" : "igemm", sizeof(T) == 2, pbc, pbp, 2.0 * Pn * a.Cout * kreal,
                  es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
   switch (cfg) {
-    case 0: e = launch_igemm_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 ch x 128 px
+    case 0: e = launch_igemm_cfg<T, 2, 2, 4, 4>(a, st); break;   // 128 ch x 128 px (the same tile on 8 + 4 waves for small grids: +-0, EXPERIMENTS.md 0.2)
     case 1: e = launch_igemm_cfg<T, 1, 4, 4, 2>(a, st); break;   //  64 ch x 128 px
     case 2: e = launch_igemm_cfg<T, 1, 4, 1, 2>(a, st); break;   //  16 ch x 128 px
     case 3: e = launch_igemm_cfg<T, 4, 1, 2, 2>(a, st); break;   // 128 ch x  32 px
