@@ -108,3 +108,33 @@ def test_config5_clips_sharded_over_two_ranks(tmp_path, monkeypatch):
   for i, nsamp in enumerate((8000, 4000, 12000)):
     frames = os.listdir(os.path.join("output_clips", "clip_%d" % i))
     assert len(frames) == int(1 + nsamp / 640), (i, len(frames))
+
+
+def test_watchdog_sees_a_device_stream_that_stops_finishing_steps():
+  """parallel.StepWatchdog with real HIP events (the CPU tests drive it with fakes): a step whose kernels do not finish within the
+  timeout - here a long device-side sleep standing in for an RCCL kernel spinning on a dead peer - fires the `device` condition while
+  the host keeps enqueuing; steps that do finish never fire it."""
+  import time
+  from voicepuppet_amd.parallel import StepWatchdog
+  fired = []
+  dog = StepWatchdog(timeout_s=0.5, rank=0, on_timeout=fired.append, poll_s=0.05)
+  x = torch.ones(1024, device="cuda")
+  for _ in range(5):                                   # healthy steps
+    x.mul_(1.0)
+    ev = torch.cuda.Event(); ev.record()
+    dog.beat(ev)
+  torch.cuda.synchronize()
+  time.sleep(0.3)
+  assert not fired
+  big = torch.ones(512 * 1024 * 1024, device="cuda")    # 2 GB: one in-place pass is ~0.8 ms of device time
+  for _ in range(2500):                                # ~2 s of queued device work: the "collective" that does not return in time
+    big.mul_(1.0)
+  ev = torch.cuda.Event(); ev.record()
+  dog.beat(ev)
+  t0 = time.monotonic()
+  while not fired and time.monotonic() - t0 < 5:
+    time.sleep(0.05)
+    dog.beat(None)                                     # the host is alive: only the device is stuck
+  dog.close()
+  torch.cuda.synchronize()
+  assert fired and fired[0]["why"] == "device" and fired[0]["last_finished_step"] == 5 and fired[0]["oldest_unfinished_step"] == 6

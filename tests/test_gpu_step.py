@@ -388,9 +388,17 @@ def test_bucketed_train_step_through_rccl_single_rank():
       eng.load_params(eng.random_params(2))
       if mode != "plain":
         eng.grad_transport = mode
-      for _ in range(2):
+      for k in range(2):
+        if mode != "plain" and k == 1:
+          eng._exchange.timing = True             # round 4: HIP events on the communication stream around every bucket (bench.py `distributed.buckets`)
         eng.train_step(*batch, lr=3e-4, group=None if mode == "plain" else dist.group.WORLD)
       torch.cuda.synchronize()
+      if mode != "plain":
+        bk = eng._exchange.bucket_ms()
+        assert [b["name"] for b in bk] == ["generator stage 0", "generator stage 1", "generator stage 2", "discriminator"]
+        nel = [hi - lo for lo, hi in eng.grad_buckets_g()] + [eng.grads_d.numel()]
+        assert [b["bytes"] for b in bk] == [n * (2 if mode == "bf16" else 4) for n in nel]
+        assert all(b["allreduce_ms"] > 0 and b["update_ms"] > 0 for b in bk) and bk[0]["wait_ms"] is None and all(b["wait_ms"] >= 0 for b in bk[1:])
       outs[mode] = (eng.params_g.clone(), eng.params_d.clone(), eng.grads_g.clone(), eng.grads_d.clone())
     for a, b in zip(outs["plain"], outs["f32"]):
       assert torch.equal(a, b)
