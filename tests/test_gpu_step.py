@@ -410,6 +410,11 @@ def test_bucketed_train_step_through_rccl_single_rank():
       # two Adam steps of +-lr each: parameters stay within 2 lr of each other, and on average far closer (sign flips are rare)
       d = (outs["plain"][k] - outs["bf16"][k]).abs()
       assert float(d.max()) <= 4 * 3e-4 * 1.01 and float(d.mean()) < 0.05 * 3e-4
+    # bench.py's multi-rank leg (watchdog beats, per-bucket timing into the `distributed` record) on this one-rank group: the 8-GPU
+    # scaling run is the driver's, so the code it will execute runs here first (world = 2 is only the number the record is scaled by)
+    import bench
+    res = bench.run_config(2, 256, "bf16", 2, 1, 0, 2, torch.device("cuda", 0), dist.group.WORLD, False, "bf16")
+    assert res["ms_per_step"] > 0 and len(res["buckets"]) == 4 and all(b["allreduce_ms"] > 0 for b in res["buckets"])
   finally:
     dist.destroy_process_group()
 
