@@ -21,6 +21,25 @@ def test_stft_matches_naive_dft_and_frame_count():
     np.testing.assert_allclose(mag[1, f], naive, rtol=1e-9, atol=1e-9)
 
 
+def test_stft_against_two_third_party_implementations():
+  """A third-party second opinion for the one piece of the audio front-end the reference takes from a library (tf.signal.stft,
+  generator/generator.py:63): scipy.signal.stft and torch.stft configured the way TF's documentation defines the op - periodic Hann
+  window of 512, hop 128, 512-point rFFT, no centring, no padding at either end.  (scipy divides by the window sum.)"""
+  import scipy.signal as ss
+  rng = np.random.default_rng(3)
+  pcm = np.clip(0.1 * rng.normal(size=(3, 16384)) + 0.3 * np.sin(2 * np.pi * 440 * np.arange(16384) / 16000.0), -1, 1)
+  mag = ar.stft_mag(pcm, 512, 128, 512)
+  win = ss.get_window("hann", 512, fftbins=True)                     # fftbins=True: the PERIODIC window
+  np.testing.assert_allclose(win, ar.hann_periodic(512), atol=1e-15)
+  _, _, z = ss.stft(pcm, window=win, nperseg=512, noverlap=384, nfft=512, boundary=None, padded=False, axis=-1)
+  sp = np.abs(z).transpose(0, 2, 1) * win.sum()
+  assert sp.shape == mag.shape == (3, 125, 257)
+  np.testing.assert_allclose(mag, sp, rtol=1e-9, atol=1e-9)
+  tz = torch.stft(torch.tensor(pcm), n_fft=512, hop_length=128, win_length=512, window=torch.hann_window(512, periodic=True, dtype=torch.float64),
+                  center=False, return_complex=True)
+  np.testing.assert_allclose(mag, tz.abs().numpy().transpose(0, 2, 1), rtol=1e-9, atol=1e-9)
+
+
 def test_mel_matrix_properties():
   m = ar.linear_to_mel_weight_matrix()
   assert m.shape == (257, 80)
