@@ -49,6 +49,14 @@ struct IgemmArgs {
   const float* ref_a;
   const float* ref_b;
   int ref_act, ref_group_n, accumulate;
+  // Two-output form (split_c > 0; backward-data of a layer that reads the virtual concat of two tensors of split_c channels each -
+  // the decoders' skip connections): ONE GEMM over the rows of both sources; output channels [0, split_c) go to Y / ref / accumulate,
+  // channels [split_c, 2 * split_c) to Y2 / ref2 / accumulate2 (same pixel stride ldY = split_c).  Both data gradients share the dY
+  // operand and, at 4-8 frames per GPU, one launch on the step's critical chain instead of two
+  int split_c;
+  void* Y2;
+  const void* ref2;
+  int accumulate2;
   int splitk;
   float* partial;           // [nclass][splitk][P][CoutPad] when splitk > 1
   int vec_epi;              // staged (LDS) epilogue with 16-byte row stores (set by the launcher)

@@ -128,8 +128,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int 
   const int q = rem / a.Wg;
   const int r = rem - q * a.Wg;
   const size_t pix = ((size_t)n * a.Hof + (q * a.os + a.o0h[cls])) * a.Wof + (r * a.os + a.o0w[cls]);
-  const size_t off = pix * a.ldY + c0;
   const int nv = min(4, a.Cout - c0);
+  void* Yp = a.Y;
+  const void* refp = a.ref;
+  int accu = a.accumulate;
+  if (a.split_c && c0 >= a.split_c) { Yp = a.Y2; refp = a.ref2; accu = a.accumulate2; c0 -= a.split_c; }     // two-output form (conv_args.h)
+  const size_t off = pix * a.ldY + c0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (e < nv) {
@@ -137,8 +141,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int 
       v[e] = act_apply(a.out_act, v[e]);
     }
   }
-  if (a.ref) {
-    const T* rp = reinterpret_cast<const T*>(a.ref) + off;
+  if (refp) {
+    const T* rp = reinterpret_cast<const T*>(refp) + off;
     const int goff = (n / a.ref_group_n) * a.Cout + c0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -150,8 +154,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int 
     }
   }
   if (a.y_f32) {
-    float* yp = reinterpret_cast<float*>(a.Y) + off;
-    if (a.accumulate) {
+    float* yp = reinterpret_cast<float*>(Yp) + off;
+    if (accu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (e < nv) v[e] += yp[e];
     }
@@ -161,8 +165,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int 
       for (int e = 0; e < 4; ++e) if (e < nv) yp[e] = v[e];
     }
   } else {
-    T* yp = reinterpret_cast<T*>(a.Y) + off;
-    if (a.accumulate) {
+    T* yp = reinterpret_cast<T*>(Yp) + off;
+    if (accu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (e < nv) v[e] += Elem<T>::ld(yp + e);
     }

@@ -87,6 +87,13 @@ constexpr int epi_passes16(int BC, int BP, int WP, int ring_bytes) {
 // act'(ref) product, accumulate, one 16-byte store (two for f32)
 template <typename T>
 __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int c0, size_t off, float (&v)[8]) {
+  void* Yp = a.Y;
+  const void* refp = a.ref;
+  int accu = a.accumulate;
+  if (a.split_c && c0 >= a.split_c) {      // second output of the two-output form (uniform per 8-channel group; per block in practice)
+    Yp = a.Y2; refp = a.ref2; accu = a.accumulate2;
+    c0 -= a.split_c; off -= (size_t)a.split_c;
+  }
   if (a.bias) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += a.bias[c0 + e];
@@ -95,9 +102,9 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act_apply(a.out_act, v[e]);
   }
-  if (a.ref) {
+  if (refp) {
     float z[8];
-    const T* rp = reinterpret_cast<const T*>(a.ref) + off;
+    const T* rp = reinterpret_cast<const T*>(refp) + off;
     if (sizeof(T) == 2) Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(rp), z);
     else {
       Elem<float>::unpack(reinterpret_cast<const uint4*>(rp)[0], z);
@@ -112,8 +119,8 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
     for (int e = 0; e < 8; ++e) v[e] *= act_grad(a.ref_act, z[e]);
   }
   if (a.y_f32 || sizeof(T) == 4) {
-    float* yp = reinterpret_cast<float*>(a.Y) + off;
-    if (a.accumulate) {
+    float* yp = reinterpret_cast<float*>(Yp) + off;
+    if (accu) {
       const float4 e0 = reinterpret_cast<const float4*>(yp)[0], e1 = reinterpret_cast<const float4*>(yp)[1];
       v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w; v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
     }
@@ -125,8 +132,8 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
     reinterpret_cast<float4*>(yp)[1] = make_float4(v[4], v[5], v[6], v[7]);
 #endif
   } else {
-    bf16* yp = reinterpret_cast<bf16*>(a.Y) + off;
-    if (a.accumulate) {
+    bf16* yp = reinterpret_cast<bf16*>(Yp) + off;
+    if (accu) {
       float e[8];
       Elem<bf16>::unpack(*reinterpret_cast<const uint4*>(yp), e);
 #pragma unroll
@@ -155,7 +162,7 @@ template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, bool ST
 __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn& pixfn, int c_base, int blkA0, int blkB0,
                                                 f32x4 (&acc)[TC][TP], char* smem, int pt = 0, int cls = 0) {
   if constexpr (NPASS16 > 0 && sizeof(T) == 2 && !STATS) {
-    if (!a.ref && !a.accumulate && !a.y_f32 && (a.out_act == ACT_NONE || a.out_act == ACT_RELU)) {
+    if (!a.ref && !a.accumulate && !a.y_f32 && !a.split_c && (a.out_act == ACT_NONE || a.out_act == ACT_RELU)) {
       constexpr int PITCHB = BC * 2 + 16, CGB = BC / 8, RPB = BP / NPASS16;
       static_assert(RPB % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
       const int tid = threadIdx.x, lane = tid & 63;

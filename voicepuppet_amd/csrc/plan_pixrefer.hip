@@ -89,6 +89,11 @@ struct Layer {
   size_t pk_fwd = 0, pk_bwd[2] = {0, 0}, pk_bwd_alt[2] = {0, 0};   // pk_bwd_alt == pk_bwd unless the two batch sizes run different kernel families
   bool need_bwd[2] = {false, false};
   IgemmPlan fwd, bwd[2], bwd_alt[2];   // bwd_alt: discriminator G-loss pass (batch N)
+  // both data gradients of a two-source layer (a decoder and its skip connection, merged_encoder_2) as ONE two-output GEMM over the
+  // shared dY (IgemmArgs::split_c): one launch on the critical chain of the backward pass instead of two, dY read once
+  IgemmPlan bwd_pair;
+  size_t pk_bwd_pair = 0;
+  bool has_pair = false;
   IgemmPlan fwd_half;                  // VGG: forward of one half (N) of the [real | fake] batch, so the real half can run early on the side stream
   size_t pk_fwd_half = 0;
   bool has_fwd_half = false;
@@ -375,6 +380,18 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
         }
       }
       row0 += rows;
+    }
+    {
+      static const bool pair_on = !getenv("VP_NO_BWD_PAIR");
+      const int c0 = n.t[L.src[0]].C, c1 = L.nsrc > 1 ? n.t[L.src[1]].C : 0;
+      if (pair_on && L.nsrc == 2 && n.groups == 1 && alt_batch == 0 && L.need_bwd[0] && L.need_bwd[1] && c0 == c1 && !n.t[L.src[0]].is_input &&
+          !n.t[L.src[1]].is_input && L.bwd[0].a.patch == 0 && L.bwd[1].a.patch == 0 && L.g.Cin_real == c0 + c1) {
+        L.bwd_pair = plan_bwd_data(L.g, L.w_off, 0, c0 + c1, c0 + c1, c0, bf16);
+        L.bwd_pair.a.split_c = c0;
+        take(L.bwd_pair);
+        L.pk_bwd_pair = L.bwd_pair.pack.dst_off;
+        L.has_pair = true;
+      }
     }
     if (want_wgrad) {
       if (L.tapgemm) {
@@ -737,6 +754,26 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
     }
   }
+  if (L.has_pair && (parts & 6) == 6 && !alt && !gpass) {
+    // both sources' data gradients in one two-output launch (Layer::bwd_pair)
+    Tens &t0 = n.t[L.src[0]], &t1 = n.t[L.src[1]];
+    IgemmArgs a = L.bwd_pair.a;
+    set_single_src(a.x, dy, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
+    a.Wp = n.packed + L.pk_bwd_pair * es;
+    a.partial = (float*)scratch;
+    a.Y = t0.dz; a.accumulate = t0.dz_written ? 1 : 0;
+    a.Y2 = t1.dz; a.accumulate2 = t1.dz_written ? 1 : 0;
+    t0.dz_written = t1.dz_written = true;
+    t0.dz_writes++; t1.dz_writes++;
+    a.ref = (const char*)t0.xa[L.in_act] + (size_t)sample0 * t0.H * t0.W * t0.C * es;
+    a.ref2 = (const char*)t1.xa[L.in_act] + (size_t)sample0 * t1.H * t1.W * t1.C * es;
+    a.ref_act = L.in_act;
+    a.ref_group_n = group_n;
+    a.zeros = h->zeros;
+    profile_tag((L.scope + ":bwd").c_str());
+    VP_HIP_CHECK(launch_igemm(a, h->bf16, L.bwd_pair.cfg, st));
+    return VP_OK;
+  }
   for (int s = 0; s < L.nsrc; ++s) {
     if (!(parts & (2 << s))) continue;
     if (!L.need_bwd[s]) continue;
@@ -979,6 +1016,7 @@ int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d) {
         if (p.a.splitk < 1 || p.a.CoutPad < p.a.Cout) fail("%s %s: splitk %d CoutPad %d", L.scope.c_str(), what, p.a.splitk, p.a.CoutPad);
       };
       plan_ok(L.fwd, "fwd");
+      if (d->training && L.has_pair) plan_ok(L.bwd_pair, "bwd_pair");
       if (d->training)
         for (int s2 = 0; s2 < L.nsrc; ++s2) if (L.need_bwd[s2]) { plan_ok(L.bwd[s2], "bwd"); if (n == &h->D || n == &h->V) plan_ok(L.bwd_alt[s2], "bwd_alt"); }
       if (d->training && n != &h->V && L.wg.partial_bytes > h->scratch_bytes) fail("%s wgrad: slab %zu > scratch %zu", L.scope.c_str(), L.wg.partial_bytes, h->scratch_bytes);
