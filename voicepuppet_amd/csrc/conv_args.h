@@ -57,6 +57,7 @@ struct IgemmArgs {
   void* Y2;
   const void* ref2;
   int accumulate2;
+  int y2_f32;               // the second output is float32 (a float32 few-pixel tensor's gradient accumulator) although T is bf16
   int splitk;
   float* partial;           // [nclass][splitk][P][CoutPad] when splitk > 1
   int vec_epi;              // staged (LDS) epilogue with 16-byte row stores (set by the launcher)

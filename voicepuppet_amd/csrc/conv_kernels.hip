@@ -131,8 +131,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int 
   const int nv = min(4, a.Cout - c0);
   void* Yp = a.Y;
   const void* refp = a.ref;
-  int accu = a.accumulate;
-  if (a.split_c && c0 >= a.split_c) { Yp = a.Y2; refp = a.ref2; accu = a.accumulate2; c0 -= a.split_c; }     // two-output form (conv_args.h)
+  int accu = a.accumulate, yf32 = a.y_f32;
+  if (a.split_c && c0 >= a.split_c) { Yp = a.Y2; refp = a.ref2; accu = a.accumulate2; yf32 = a.y2_f32; c0 -= a.split_c; }     // two-output form (conv_args.h)
   const size_t off = pix * a.ldY + c0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -153,7 +153,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int 
       }
     }
   }
-  if (a.y_f32) {
+  if (yf32) {
     float* yp = reinterpret_cast<float*>(Yp) + off;
     if (accu) {
 #pragma unroll

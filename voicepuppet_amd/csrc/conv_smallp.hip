@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
   const int pt = tile % npt, cls = (tile / npt) % a.nclass, ct = tile / (npt * a.nclass);
   const int ks = blockIdx.y, nks = a.splitk;
   const int ntiles = gridDim.x;
+  // two-output launch (IgemmArgs::split_c; both data gradients of a decoder): the channel tiles of the SECOND output take the plain
+  // epilogue whatever MODE says - that tensor still has a contribution to come, only the first one's batch-norm backward runs here
+  const bool plain2 = MODE != SP_PLAIN && a.split_c > 0 && ct * SP_CT >= a.split_c;
 
   if (tid == 0) {
     int n = 0;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
     for (int e = 0; e < 8; ++e) z[e] = 0.f;
     if (ot >= 0) {
       const size_t off = (size_t)(ot >> 8) + c0;
-      if (MODE == SP_PLAIN) {
+      if (MODE == SP_PLAIN || plain2) {
         epi_store8<T>(a, ot, c0, off, v);
       } else {
         // SP_FWD_BN: the raw output (a bias in front of a batch-norm cancels; no activation).  SP_BWD_BN: act'(ref) product and the
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
           for (int e = 0; e < 8; ++e) v[e] = round_as_stored(v[e], (T*)nullptr);
         }
       }
-      if (MODE == SP_BWD_BN) {
+      if (MODE == SP_BWD_BN && !plain2) {
         float y[8];
         if (hi) load8<float>(reinterpret_cast<const float*>(s.bn_y) + off, y);
         else load8<T>(reinterpret_cast<const T*>(s.bn_y) + off, y);
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
-    if (MODE != SP_PLAIN) {
+    if (MODE != SP_PLAIN && !plain2) {
       *reinterpret_cast<float4*>(red + (p * SP_PITCH + cg * 8)) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(red + (p * SP_PITCH + cg * 8 + 4)) = make_float4(v[4], v[5], v[6], v[7]);
       if (MODE == SP_BWD_BN) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
       }
     }
   }
-  if (MODE == SP_PLAIN) return;
+  if (MODE == SP_PLAIN || plain2) return;
 
   // ---- per-tile column sums (pixel order), then the channel group's last tile finishes the batch-norm ----------------------------
   __syncthreads();

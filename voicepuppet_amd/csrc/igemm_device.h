@@ -89,9 +89,9 @@ template <typename T>
 __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int c0, size_t off, float (&v)[8]) {
   void* Yp = a.Y;
   const void* refp = a.ref;
-  int accu = a.accumulate;
+  int accu = a.accumulate, yf32 = a.y_f32;
   if (a.split_c && c0 >= a.split_c) {      // second output of the two-output form (uniform per 8-channel group; per block in practice)
-    Yp = a.Y2; refp = a.ref2; accu = a.accumulate2;
+    Yp = a.Y2; refp = a.ref2; accu = a.accumulate2; yf32 = a.y2_f32;
     c0 -= a.split_c; off -= (size_t)a.split_c;
   }
   if (a.bias) {
@@ -118,7 +118,7 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= act_grad(a.ref_act, z[e]);
   }
-  if (a.y_f32 || sizeof(T) == 4) {
+  if (yf32 || sizeof(T) == 4) {
     float* yp = reinterpret_cast<float*>(Yp) + off;
     if (accu) {
       const float4 e0 = reinterpret_cast<const float4*>(yp)[0], e1 = reinterpret_cast<const float4*>(yp)[1];

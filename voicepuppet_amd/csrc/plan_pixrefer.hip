@@ -105,6 +105,7 @@ struct Layer {
   void* tap_dyS = nullptr;   // [N,Hin,Win,16] T
   unsigned* sp_cnt_fwd = nullptr;               // few-pixel kernel (conv_smallp.hip): arrival counters of this layer's launches
   unsigned* sp_cnt_bwd[2] = {nullptr, nullptr};
+  unsigned* sp_cnt_pair = nullptr;
 };
 
 struct ParamInfo { std::string name; size_t off; int ndim; int64_t shape[4]; };
@@ -385,12 +386,20 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       static const bool pair_on = !getenv("VP_NO_BWD_PAIR");
       const int c0 = n.t[L.src[0]].C, c1 = L.nsrc > 1 ? n.t[L.src[1]].C : 0;
       if (pair_on && L.nsrc == 2 && n.groups == 1 && alt_batch == 0 && L.need_bwd[0] && L.need_bwd[1] && c0 == c1 && !n.t[L.src[0]].is_input &&
-          !n.t[L.src[1]].is_input && L.bwd[0].a.patch == 0 && L.bwd[1].a.patch == 0 && L.g.Cin_real == c0 + c1) {
+          !n.t[L.src[1]].is_input && L.bwd[0].a.patch == L.bwd[1].a.patch && (L.bwd[0].a.patch == 0 || L.bwd[0].a.patch == 3) &&
+          L.g.Cin_real == c0 + c1) {
         L.bwd_pair = plan_bwd_data(L.g, L.w_off, 0, c0 + c1, c0 + c1, c0, bf16);
-        L.bwd_pair.a.split_c = c0;
-        take(L.bwd_pair);
-        L.pk_bwd_pair = L.bwd_pair.pack.dst_off;
-        L.has_pair = true;
+        bool ok = true;
+        if (L.bwd[0].a.patch == 3) {      // few-pixel layers: the pair runs on the few-pixel kernel too (first output with its batch-norm backward)
+          ok = plan_smallp_eligible(L.bwd_pair, c0 + c1, bf16, L.g.CoutT, 0);
+          if (ok) plan_make_smallp(L.bwd_pair, c0 + c1, bf16);
+        }
+        if (ok) {
+          L.bwd_pair.a.split_c = c0;
+          take(L.bwd_pair);
+          L.pk_bwd_pair = L.bwd_pair.pack.dst_off;
+          L.has_pair = true;
+        }
       }
     }
     if (want_wgrad) {
@@ -423,6 +432,7 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       n.t[L.src[s]].n_bwd_consumers++;
       if (L.bwd[s].a.patch == 3) n.sp_cnt_n += smallp_counters(L.bwd[s].a);
     }
+    if (training && L.has_pair && L.bwd_pair.a.patch == 3) n.sp_cnt_n += smallp_counters(L.bwd_pair.a);
   }
 }
 
@@ -457,6 +467,7 @@ static void carve_net(Net& n, Arena& ar, int es, bool training) {
       if (L.fwd.a.patch == 3) { L.sp_cnt_fwd = c; c += c ? smallp_counters(L.fwd.a) : 0; }
       for (int s = 0; s < L.nsrc && training; ++s)
         if (L.need_bwd[s] && L.bwd[s].a.patch == 3) { L.sp_cnt_bwd[s] = c; c += c ? smallp_counters(L.bwd[s].a) : 0; }
+      if (training && L.has_pair && L.bwd_pair.a.patch == 3) { L.sp_cnt_pair = c; c += c ? smallp_counters(L.bwd_pair.a) : 0; }
     }
   }
 }
@@ -754,10 +765,45 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
     }
   }
-  if (L.has_pair && (parts & 6) == 6 && !alt && !gpass) {
+  // few-pixel pairs: only the usual case - this launch is the LAST contribution to the first tensor (its batch-norm backward runs in
+  // the launch) and NOT the last one to the second (the skip tensor's own encoder consumer comes later)
+  const bool pair_sp = L.has_pair && L.bwd_pair.a.patch == 3;
+  const bool pair_sp_ok = pair_sp && n.t[L.src[0]].has_bn && n.t[L.src[0]].dz_writes + 1 == n.t[L.src[0]].n_bwd_consumers &&
+                          n.t[L.src[1]].dz_writes + 1 < n.t[L.src[1]].n_bwd_consumers;
+  if (L.has_pair && (parts & 6) == 6 && !alt && !gpass && (!pair_sp || pair_sp_ok)) {
     // both sources' data gradients in one two-output launch (Layer::bwd_pair)
     Tens &t0 = n.t[L.src[0]], &t1 = n.t[L.src[1]];
     IgemmArgs a = L.bwd_pair.a;
+    if (pair_sp) {
+      set_single_src(a.x, dy, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
+      a.Wp = n.packed + L.pk_bwd_pair * es;
+      a.partial = (float*)scratch;
+      a.zeros = h->zeros;
+      a.ref = (const char*)t0.xa[L.in_act] + (size_t)sample0 * t0.H * t0.W * t0.C * es;
+      a.ref2 = (const char*)t1.xa[L.in_act] + (size_t)sample0 * t1.H * t1.W * t1.C * es;
+      a.ref_act = L.in_act;
+      a.ref_group_n = group_n;
+      a.Y = t0.hi ? t0.dz32 : t0.dz; a.accumulate = t0.dz_written ? 1 : 0;
+      a.Y2 = t1.hi ? t1.dz32 : t1.dz; a.accumulate2 = t1.dz_written ? 1 : 0; a.y2_f32 = t1.hi ? 1 : 0;
+      t0.dz_written = t1.dz_written = true;
+      t0.dz_writes++; t1.dz_writes++;
+      SmallPArgs sp;
+      memset(&sp, 0, sizeof(sp));
+      a.sp_cnt = L.sp_cnt_pair;
+      sp.g = a;
+      for (int c = 0; c < 4; ++c) sp.tap_mask[c] = a.sp_mask[c];
+      sp.slab = a.partial; sp.cnt = a.sp_cnt; sp.part = bn_partial;
+      const Layer& Lp = n.l[t0.producer];
+      sp.mode = SP_BWD_BN;
+      if (t0.hi) { sp.hi = 1; sp.dy_out = t0.dz; }
+      sp.bn_y = t0.y; sp.bn_mu = t0.bn.mu; sp.bn_rstd = t0.bn.rstd; sp.bn_gamma = n.params + Lp.gamma_off;
+      sp.c1 = t0.bn.c1; sp.c2 = t0.bn.c2;
+      sp.dgamma = n.grads + Lp.gamma_off; sp.dbeta = n.grads + Lp.beta_off; sp.dbias_zero = n.grads + Lp.b_off;
+      t0.bn_bwd_done = true;
+      profile_tag((L.scope + ":bwd").c_str());
+      VP_HIP_CHECK(launch_smallp_fused(sp, h->bf16, st));
+      return VP_OK;
+    }
     set_single_src(a.x, dy, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
     a.Wp = n.packed + L.pk_bwd_pair * es;
     a.partial = (float*)scratch;
@@ -1586,7 +1632,9 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
       VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
       forked = true;
       // (the data gradient of a decoder's skip-connection source on the branch stream too was measured slower - EXPERIMENTS.md - and
-      // raced with the fourth stream: removed)
+      // raced with the fourth stream: removed.  Stage 0's weight gradients alternating between `branch` and the then idle `branch2`:
+      // +0.01 .. 0.05 ms at batch 4 / 8 / 32 - the weight gradients, the optimiser and the weight-streaming layers share HBM, a second
+      // stream adds contention, not throughput; EXPERIMENTS.md 0.2)
       if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, h->branch, 2, false, 1))) return rc;
       if ((rc = run_layer_bwd(h, G, L, to.dz, true, false, 0, N, 0, st, 0, false, 6))) return rc;
     } else {
