@@ -119,7 +119,7 @@ __device__ __forceinline__ uint4 load_pix_piece(const PixSrc& x, int n, int ih, 
 // ------------------------------------------------------------------------------------------------
 // epilogue shared by igemm_kernel and splitk_reduce_kernel: 4 consecutive output channels of one pixel
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool DUAL = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int pidx, int c0, float v[4]) {
   if (c0 >= a.Cout) return;
   const int hw = a.Hg * a.Wg;
@@ -132,7 +132,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, int cls, int 
   void* Yp = a.Y;
   const void* refp = a.ref;
   int accu = a.accumulate, yf32 = a.y_f32;
-  if (a.split_c && c0 >= a.split_c) { Yp = a.Y2; refp = a.ref2; accu = a.accumulate2; yf32 = a.y2_f32; c0 -= a.split_c; }     // two-output form (conv_args.h)
+  if constexpr (DUAL) {
+    if (c0 >= a.split_c) { Yp = a.Y2; refp = a.ref2; accu = a.accumulate2; yf32 = a.y2_f32; c0 -= a.split_c; }     // two-output form (conv_args.h)
+  }
   const size_t off = pix * a.ldY + c0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 // (rb_swz) so that global reads are coalesced AND ds_read_b128 stays conflict-free.  Padding / ragged
 // pixels read a 16-byte zero page instead (LDS-DMA cannot zero-fill).  One barrier per K chunk.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int WC, int WP, int TC, int TP, bool STAGED, bool STATS = false>
+template <typename T, int WC, int WP, int TC, int TP, bool STAGED, bool STATS = false, bool DUAL = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NW = WC * WP, NT = NW * 64;             // 4 waves (256 threads) or 8 waves (512 threads: 128x256 / 256x256 tiles)
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
   if (STAGED) {
     constexpr int RINGB = NST * BUF * 16;
     constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
-    staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
+    staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS, 0, DUAL>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
     return;
   }
 #pragma unroll
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
         float* pp = a.partial + (((size_t)(cls * a.splitk + split) * P + pidx) * a.CoutPad + c0);
         *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
-        igemm_epilogue<T>(a, cls, pidx, c0, v);
+        igemm_epilogue<T, DUAL>(a, cls, pidx, c0, v);
       }
     }
   }
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
 //   consumer kc: barrier kc -> fragments + MFMAs of chunk kc
 // fastk operands only (scalar K stepping, hardware zero fill); epilogue = the staged 16-byte row stores, all waves storing.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int WC, int WP, int TC, int TP, int NST, bool STATS = false>
+template <typename T, int WC, int WP, int TC, int TP, int NST, bool STATS = false, bool DUAL = false>
 __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NPW = 4;
@@ -710,7 +712,7 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
 #endif
   constexpr int RINGB = NST * BUF * 16;
   constexpr int NPASS = epi_passes(BC, BP, WP, RINGB);
-  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
+  staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS, 0, DUAL>(a, LinearPix{a, cls, p_base, P}, c_base, blkA0, blkB0, acc, smem, pt, cls);
 }
 
 
@@ -1225,7 +1227,7 @@ __global__ __launch_bounds__(256) void deconv_cout8_tile_kernel(const IgemmArgs 
 }
 
 // sums the split-K slabs in a fixed order (deterministic) and applies the igemm epilogue
-template <typename T>
+template <typename T, bool DUAL = false>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArgs a) {
   const int P = a.N * a.Hg * a.Wg;
   const int cq = a.CoutPad >> 2;
@@ -1250,7 +1252,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArg
         v[0] += x[u].x; v[1] += x[u].y; v[2] += x[u].z; v[3] += x[u].w;
       }
     }
-    igemm_epilogue<T>(a, cls, pidx, c0, v);
+    igemm_epilogue<T, DUAL>(a, cls, pidx, c0, v);
   }
 }
 
@@ -1708,17 +1710,21 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         if (se > sm) sm = se;
         g_prof_family = "ws";
         if (b.bn_part) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, true>), grid, dim3((NW + 4) * 64), sm, st, b);
+        else if (b.split_c) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, false, true>), grid, dim3((NW + 4) * 64), sm, st, b);
         else hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, false>), grid, dim3((NW + 4) * 64), sm, st, b);
         return hipGetLastError();
       }
     }
     g_prof_family = "dma";
     if (b.vec_epi && b.bn_part) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, true>), grid, dim3(NW * 64), smem, st, b);
+    else if (b.vec_epi && b.split_c) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, false, true>), grid, dim3(NW * 64), smem, st, b);
     else if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
+    else if (b.split_c) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false, false, true>), grid, dim3(NW * 64), smem, st, b);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(NW * 64), smem, st, b);
     return hipGetLastError();
   }
   g_prof_family = "reg";
+  if (a.split_c) return hipErrorInvalidValue;        // the two-output form exists on the LDS-DMA kernels only
   if constexpr (NW == 4) hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), 2 * 4 * (BC + BP) * 16 + 64, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
@@ -1858,7 +1864,8 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     const size_t total = (size_t)a.nclass * a.N * a.Hg * a.Wg * (a.CoutPad / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((igemm_splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, a);
+    if (a.split_c) hipLaunchKernelGGL((igemm_splitk_reduce_kernel<T, true>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, a);
     e = hipGetLastError();
   }
   return e;

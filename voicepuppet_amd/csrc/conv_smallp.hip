@@ -86,7 +86,7 @@ __device__ __forceinline__ bool publish_and_ticket(unsigned* cnt, unsigned last,
   return *flag_lds != 0;
 }
 
-template <typename T, int NPT, int MODE>
+template <typename T, int NPT, int MODE, bool DUAL = false>
 __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
   constexpr int E = Elem<T>::E, KC = 4 * E;            // elements per 16-byte piece / per 64-byte K chunk
   constexpr int PT = NPT * 16;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
   const int ntiles = gridDim.x;
   // two-output launch (IgemmArgs::split_c; both data gradients of a decoder): the channel tiles of the SECOND output take the plain
   // epilogue whatever MODE says - that tensor still has a contribution to come, only the first one's batch-norm backward runs here
-  const bool plain2 = MODE != SP_PLAIN && a.split_c > 0 && ct * SP_CT >= a.split_c;
+  const bool plain2 = DUAL && MODE != SP_PLAIN && ct * SP_CT >= a.split_c;
 
   if (tid == 0) {
     int n = 0;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void smallp_kernel(const SmallPArgs s) {
     if (ot >= 0) {
       const size_t off = (size_t)(ot >> 8) + c0;
       if (MODE == SP_PLAIN || plain2) {
-        epi_store8<T>(a, ot, c0, off, v);
+        epi_store8<T, DUAL>(a, ot, c0, off, v);
       } else {
         // SP_FWD_BN: the raw output (a bias in front of a batch-norm cancels; no activation).  SP_BWD_BN: act'(ref) product and the
         // accumulation over the tensor's consumers, as epi_store8.  Stored write-through: the channel group's last tile reads it back.
@@ -399,7 +399,10 @@ static hipError_t launch_smallp_t(const SmallPArgs& s, dim3 grid, hipStream_t st
   switch (s.mode) {
     case SP_PLAIN: hipLaunchKernelGGL((smallp_kernel<T, NPT, SP_PLAIN>), grid, dim3(256), sm, st, s); break;
     case SP_FWD_BN: hipLaunchKernelGGL((smallp_kernel<T, NPT, SP_FWD_BN>), grid, dim3(256), sm, st, s); break;
-    case SP_BWD_BN: hipLaunchKernelGGL((smallp_kernel<T, NPT, SP_BWD_BN>), grid, dim3(256), sm, st, s); break;
+    case SP_BWD_BN:
+      if (s.g.split_c) hipLaunchKernelGGL((smallp_kernel<T, NPT, SP_BWD_BN, true>), grid, dim3(256), sm, st, s);       // paired data gradients
+      else hipLaunchKernelGGL((smallp_kernel<T, NPT, SP_BWD_BN>), grid, dim3(256), sm, st, s);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -412,6 +415,7 @@ hipError_t launch_smallp(const SmallPArgs& s, int is_bf16, hipStream_t st) {
   const int npt = (Pc + PT - 1) / PT;
   if (a.CoutPad % SP_CT || !s.cnt || !a.zeros || (a.splitk > 1 && !s.slab) || (s.mode != SP_PLAIN && !s.part)) return hipErrorInvalidValue;
   if (s.hi && (!is_bf16 || s.mode == SP_PLAIN || (s.mode == SP_BWD_BN && !s.dy_out))) return hipErrorInvalidValue;
+  if (a.split_c && s.mode != SP_BWD_BN) return hipErrorInvalidValue;       // the two-output form: first output with its batch-norm backward
   dim3 grid((a.CoutPad / SP_CT) * a.nclass * npt, a.splitk, 1);
   if (is_bf16) {
     if (npt_t == 1) return launch_smallp_t<bf16, 1>(s, grid, st);

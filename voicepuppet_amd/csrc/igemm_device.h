@@ -85,14 +85,18 @@ constexpr int epi_passes16(int BC, int BP, int WP, int ring_bytes) {
 
 // finish 8 consecutive channels c0..c0+7 of one output pixel (offset `off`, BN group in the low byte of `ot`): bias, activation,
 // act'(ref) product, accumulate, one 16-byte store (two for f32)
-template <typename T>
+// DUAL: the two-output form (IgemmArgs::split_c) is compiled only into the kernels that are launched with it - as a run-time test in
+// EVERY epilogue it cost the 128-register tiles 4 % of the whole step (batch 32: 8.2 -> 8.6 ms, EXPERIMENTS.md 0.2)
+template <typename T, bool DUAL = false>
 __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int c0, size_t off, float (&v)[8]) {
   void* Yp = a.Y;
   const void* refp = a.ref;
   int accu = a.accumulate, yf32 = a.y_f32;
-  if (a.split_c && c0 >= a.split_c) {      // second output of the two-output form (uniform per 8-channel group; per block in practice)
-    Yp = a.Y2; refp = a.ref2; accu = a.accumulate2; yf32 = a.y2_f32;
-    c0 -= a.split_c; off -= (size_t)a.split_c;
+  if constexpr (DUAL) {
+    if (c0 >= a.split_c) {                 // second output (uniform per 8-channel group; per block in practice)
+      Yp = a.Y2; refp = a.ref2; accu = a.accumulate2; yf32 = a.y2_f32;
+      c0 -= a.split_c; off -= (size_t)a.split_c;
+    }
   }
   if (a.bias) {
 #pragma unroll
@@ -158,11 +162,11 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
 // product, no accumulation and a bf16 output, bias + activation + rounding are applied in the lane's own registers - the same
 // operations in the same order, so the stored bits are the same - and the tile is staged as bf16: half the LDS bytes, NPASS16
 // passes instead of NPASS, the store loop a plain copy; the fused max pool takes the maximum of the rounded values (rounding is monotonic).
-template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, bool STATS = false, int NPASS16 = 0, typename PixFn>
+template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, bool STATS = false, int NPASS16 = 0, bool DUAL = false, typename PixFn>
 __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn& pixfn, int c_base, int blkA0, int blkB0,
                                                 f32x4 (&acc)[TC][TP], char* smem, int pt = 0, int cls = 0) {
   if constexpr (NPASS16 > 0 && sizeof(T) == 2 && !STATS) {
-    if (!a.ref && !a.accumulate && !a.y_f32 && !a.split_c && (a.out_act == ACT_NONE || a.out_act == ACT_RELU)) {
+    if (!a.ref && !a.accumulate && !a.y_f32 && (a.out_act == ACT_NONE || a.out_act == ACT_RELU)) {
       constexpr int PITCHB = BC * 2 + 16, CGB = BC / 8, RPB = BP / NPASS16;
       static_assert(RPB % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
       const int tid = threadIdx.x, lane = tid & 63;
@@ -291,7 +295,7 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
         const float4 v1 = *reinterpret_cast<const float4*>(smem + p * PITCH + cgp * 32 + 16);
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
       }
-      epi_store8<T>(a, ot, c0, off, v);
+      epi_store8<T, DUAL>(a, ot, c0, off, v);
     }
     // fused 2x2 / stride-2 max pool of the tile (VGG conv1_2 / conv2_2: slim max_pool2d, vgg_simple.py:141,144): the pass holds
     // whole pairs of 16-pixel tile rows; bias + (monotonic) activation + rounding commute with the max, so this equals pooling the
