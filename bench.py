@@ -294,6 +294,9 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
   if profile and rank == 0:
     # per-kernel launch durations, HIP events on the launch stream, over a few extra steps (outside the timed region)
     eng.profile(True)
+    eng.train_step(*batch, lr=lr, group=None)       # one untimed step in the profiling (single-stream) schedule: its first pass can carry a
+    torch.cuda.synchronize()                        # one-off stall (seen: one 1.7 ms launch of a 0.33 ms kernel) that would reorder the classes
+    eng.profile_collect()
     psteps = 3
     for _ in range(psteps):
       eng.train_step(*batch, lr=lr, group=None)
