@@ -254,10 +254,14 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
 
   # rank liveness: a peer that dies inside a collective leaves this rank's streams spinning; the watchdog ends the process non-zero
   from voicepuppet_amd.parallel import StepWatchdog
-  dog = StepWatchdog(rank=rank) if world > 1 else None
+  dog = StepWatchdog(rank=rank, device=device.index if hasattr(device, "index") else None) if world > 1 else None
 
   def step():
     eng.train_step(*batch, lr=lr, group=group)
+
+  def beat():
+    # one event behind a whole phase (warm-up, timed loop), recorded OUTSIDE the timed region: the single-GPU loop carries no such
+    # host work, so the multi-GPU loop must not either; a phase lasts seconds, the watchdog's horizon is minutes
     if dog is not None:
       ev = torch.cuda.Event()
       ev.record()
@@ -265,12 +269,14 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
 
   for _ in range(warmup):
     step()
+  beat()
   sync()
   t0 = time.perf_counter()
   for _ in range(steps):
     step()
   sync()
   dt = time.perf_counter() - t0
+  beat()
   if world > 1:
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)

@@ -289,6 +289,52 @@ def test_decoder_1_four_channel_kernel_in_situ():
 
 
 @pytest.mark.gpu
+def test_conv1_2_register_resident_weights_kernel_in_situ():
+  """VGG conv1_2 (64 -> 64 channels, 3x3) runs on conv_c64.hip in every bf16 training plan: forward + bias + relu, the fused 2x2 max
+  pool (`pool1`), and the backward-data pass with the relu'(conv1_1 output) product - each against the float64 convolution of the SAME
+  bf16 tensors the device fed the kernel (teacher forcing; bound 4e-3 = bf16 rounding of the stored result), and against the unrolled
+  patch kernel the layer ran on before (vp_tune("c64", 0): different K-sum order, same rounding points)."""
+  from oracle import nn_ops as ops
+  from voicepuppet_amd import _lib
+  L = _lib.lib()
+  n = 2
+  got = {}
+  for on in (1, 0):
+    L.vp_tune(b"c64", on)
+    try:
+      eng = PixReferEngine(n, 256, 8, 8, dtype="bf16", training=True)
+      eng.load_params(eng.random_params(5))
+      g = torch.Generator(device="cpu").manual_seed(9)
+      batch = [torch.rand(n, 256, 256, c, generator=g).cuda() for c in (6, 6, 3, 3)]
+      eng.profile(1)
+      eng.forward(*batch); eng.backward()
+      torch.cuda.synchronize()
+      classes = {r["name"] for r in eng.profile_collect()}
+      eng.profile(0)
+      assert any(c.startswith("c64_") for c in classes) == bool(on), classes
+      got[on] = {k: eng.tensor(k).float().cpu().numpy() for k in ("v/conv1/conv1_1", "v/conv1/conv1_2", "v/pool1", "v/conv1/conv1_2:dy", "v/conv1/conv1_1:dy")}
+      if on:
+        w = gu.rounded(eng.get_params(2)["vgg_16/conv1/conv1_2/weights"], "bf16")
+        b = eng.get_params(2)["vgg_16/conv1/conv1_2/biases"].astype(np.float64)
+      del eng
+    finally:
+      L.vp_tune(b"c64", 1)
+  t = got[1]
+  x = t["v/conv1/conv1_1"].astype(np.float64)                          # [2N] relu outputs, as stored (bf16)
+  want = ops.relu(ops.conv2d_fwd(x[n:], w, b, 1, 1))                   # the fake half (the profiled step runs on one stream and stores both)
+  assert gu.rel_l2(t["v/conv1/conv1_2"][n:], want) < 4e-3, gu.rel_l2(t["v/conv1/conv1_2"][n:], want)
+  y = t["v/conv1/conv1_2"]
+  pool = y.reshape(2 * n, 128, 2, 128, 2, 64).max(axis=(2, 4))
+  assert np.array_equal(t["v/pool1"], pool)                            # the fused pool is the pool of the stored tensor, bit for bit
+  # backward-data (fake half only: dy tensors hold N images): dX = conv_bwd(dY, W) * relu'(conv1_1 output of the fake half)
+  dy = t["v/conv1/conv1_2:dy"].astype(np.float64)
+  dx = ops.conv2d_bwd(x[n:n + 1], w, dy[:1], 1, 1, need_dw=False)[0] * (x[n:n + 1] > 0)
+  assert gu.rel_l2(t["v/conv1/conv1_1:dy"][:1], dx) < 4e-3, gu.rel_l2(t["v/conv1/conv1_1:dy"][:1], dx)
+  for k in ("v/conv1/conv1_2", "v/pool1", "v/conv1/conv1_1:dy"):
+    assert gu.rel_l2(got[1][k], got[0][k]) < 3e-3, (k, gu.rel_l2(got[1][k], got[0][k]))
+
+
+@pytest.mark.gpu
 def test_forward_is_hipgraph_capturable():
   """The library's launch sequence is fixed, allocates nothing and never synchronises: one inference forward captured
   into a hipGraph replays to the identical output (the claim of DESIGN.md section 2)."""

@@ -1837,6 +1837,14 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
                    es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
     return launch_igemm_smallp(a, sizeof(T) == 2, st);
   }
+  if constexpr (sizeof(T) == 2) {
+    // 3x3 stride-1 conv from 64 to 64 channels (VGG conv1_2 forward / backward-data): weights resident in registers (conv_c64.hip)
+    if (c64_knob() && conv_c64_eligible(a, 1)) {
+      ProfScope prof("c64", true, 64, 128, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+      return launch_conv_c64(a, st);
+    }
+  }
   if (a.patch) {   // stride-1 convs with the input patch staged once per channel chunk (conv_patch.hip)
     // class name per kernel template: patch2 (parity classes, conv_patch2.hip), patch3 (unrolled 3x3, conv_patch3.hip), patch (generic)
     const char* pk = a.patch == 2 ? "patch2" : (patch3_knob() && patch3_eligible(a, sizeof(T) == 2) ? "patch3" : "patch");

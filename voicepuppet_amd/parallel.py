@@ -49,7 +49,11 @@ class StepWatchdog(object):
   destructors: the communicator may be wedged); torch.distributed.run sees the non-zero status and stops the remaining ranks.
   timeout_s <= 0 disables it.  on_timeout(info) replaces the exit (tests)."""
 
-  def __init__(self, timeout_s=None, rank=0, on_timeout=None, poll_s=0.25):
+  def __init__(self, timeout_s=None, rank=0, on_timeout=None, poll_s=0.25, device=None):
+    # device: the CUDA device index whose events the thread queries (an Event.query() from a thread that never selected a device
+    # would otherwise run against device 0's context on every rank)
+    self.device = device
+    self.paused = 0
     if timeout_s is None:
       timeout_s = float(os.environ.get("VP_WATCHDOG_TIMEOUT_S", "300"))
     self.timeout_s, self.rank, self.on_timeout, self.poll_s = float(timeout_s), rank, on_timeout, poll_s
@@ -71,6 +75,18 @@ class StepWatchdog(object):
       self.last_beat = now
       self.pending.append((now, event, self.steps_enqueued))
 
+  def pause(self):
+    """A long host-side section (checkpoint save, first-step initialisation, an evaluation pass) is not a hung rank: the 'host' condition
+    is suspended until resume(); steps already enqueued keep being watched on the device side."""
+    with self.lock:
+      self.paused += 1
+
+  def resume(self):
+    with self.lock:
+      self.paused = max(0, self.paused - 1)
+      if self.last_beat is not None:
+        self.last_beat = time.monotonic()
+
   def _drain(self):
     with self.lock:
       while self.pending:
@@ -86,12 +102,18 @@ class StepWatchdog(object):
       if self.pending and now - self.pending[0][0] > self.timeout_s:
         return {"why": "device", "rank": self.rank, "age_s": now - self.pending[0][0], "last_finished_step": self.steps_done,
                 "oldest_unfinished_step": self.pending[0][2]}
-      if self.last_beat is not None and now - self.last_beat > self.timeout_s:
+      if not self.paused and self.last_beat is not None and now - self.last_beat > self.timeout_s:
         return {"why": "host", "rank": self.rank, "age_s": now - self.last_beat, "last_finished_step": self.steps_done,
                 "oldest_unfinished_step": self.steps_done + 1}
     return None
 
   def _run(self):
+    if self.device is not None:
+      try:
+        import torch
+        torch.cuda.set_device(self.device)
+      except Exception:          # (CPU-only tests drive the watchdog with event = None)
+        pass
     while not self._stop.wait(self.poll_s):
       info = self._check(time.monotonic())
       if info is None:

@@ -106,12 +106,28 @@ def main(argv=None):
   train_nodes = vid2vidnet.build_train_op(*train_iter.get_next())
   if use_device_pipeline:
     vid2vidnet.engine.use_streams(3)      # the input prefetcher's stream is the fourth busy one (include/vp_hip.h vp_pixrefer_use_streams)
-  if opts.resume or (params.get('amd') or {}).get('resume', False):
+  # --resume / amd: {resume: true}: continue from the latest checkpoint of save_dir.  `epochs` stays the TOTAL number of iterations of
+  # the run (the learning-rate schedule is a function of global_step, which the checkpoint restores), so a run restarted at
+  # global_step 120000 of 200000 trains the remaining 40000 iterations, not another 100000.  The data pipeline is NOT part of a
+  # checkpoint (nor is it in the reference: tf.data's shuffle state is not saved by its Saver): a resumed run draws fresh shuffles,
+  # i.e. it continues the optimisation, not the bit-exact sample sequence of the interrupted run.
+  resumed_step = 0
+  resume_flag = opts.resume or (params.get('amd') or {}).get('resume', False)
+  if resume_flag:
     from voicepuppet_amd.utils import tf_checkpoint
     latest = tf_checkpoint.latest_checkpoint(params.save_dir) if os.path.isdir(params.save_dir) else None
-    if latest is not None:
+    if latest is not None and not os.path.exists(latest + '.index'):
+      logger.error('resume: %s/checkpoint names %s, which does not exist', params.save_dir, latest)
+      exit(1)
+    if latest is None:
+      if opts.resume:          # asked for on the command line: starting from scratch silently would discard a run
+        logger.error('resume: no checkpoint state in %s', params.save_dir)
+        exit(1)
+      logger.warning('resume: no checkpoint in %s, starting from the initial weights', params.save_dir)
+    else:
       vid2vidnet.restore(latest)
-      logger.info('resumed from %s (global_step %d)', latest, vid2vidnet.global_step)
+      resumed_step = vid2vidnet.global_step
+      logger.info('resumed from %s (global_step %d)', latest, resumed_step)
   if world > 1:   # identical initial weights on every replica
     for a in (vid2vidnet.engine.params_g, vid2vidnet.engine.params_d, vid2vidnet.engine.params_vgg):
       dist.broadcast(a, 0)
@@ -120,10 +136,15 @@ def main(argv=None):
   # rank liveness: losses are read only on summary steps, so a peer lost inside a collective shows up as a device
   # stream that stops finishing steps; the watchdog then ends this rank non-zero and torch.distributed.run stops the others
   from voicepuppet_amd.parallel import StepWatchdog
-  dog = StepWatchdog(rank=rank) if world > 1 else None
+  dog = StepWatchdog(rank=rank, device=torch.cuda.current_device()) if world > 1 else None
+  # Saver(max_to_keep) also counts the checkpoints an earlier process of this run left in save_dir
   saved = []
+  if rank == 0 and resume_flag:
+    from voicepuppet_amd.utils import tf_checkpoint
+    saved = tf_checkpoint.list_checkpoints(params.save_dir, params.save_name)
   t0 = time.time()
-  for i in range(epochs):
+  remaining = max(0, epochs - resumed_step // 2)      # both optimisers bump global_step: 2 per iteration
+  for i in range(remaining):
     ### Run training
     # the reference fetches the three losses every step and prints them every summary_step (train_pixrefer.py:134-143).  Reading a
     # loss waits for the step, and a host that waits every step cannot enqueue the next one under it: the losses are fetched on the
@@ -151,8 +172,13 @@ def main(argv=None):
     ### Save checkpoint
     if (global_step % params.save_step == 0 and rank == 0):
       # train_pixrefer.py:150: Saver(max_to_keep).save(sess, 'ckpt_pixrefer/pixrefernet', global_step) - a TensorFlow V2 checkpoint
+      if dog is not None:
+        dog.pause()                     # a long host-side save is not a hung rank
       path = vid2vidnet.save(os.path.join(params.save_dir, '%s-%d' % (params.save_name, global_step)))
-      saved.append(path)
+      if dog is not None:
+        dog.resume()
+      if path not in saved:
+        saved.append(path)
       while len(saved) > params.max_to_keep:
         old = saved.pop(0)
         for suffix in ('.index', '.data-00000-of-00001'):

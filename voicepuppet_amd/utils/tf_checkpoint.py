@@ -500,12 +500,17 @@ def is_tf_checkpoint(path):
 
 def write_checkpoint(prefix, tensors, update_state=True):
   """tf.train.Saver().save(sess, prefix) for {name: array}: <prefix>.index + <prefix>.data-00000-of-00001 (+ the `checkpoint`
-  state file of the directory), readable by tf.train.load_checkpoint / Saver.restore."""
+  state file of the directory), readable by tf.train.load_checkpoint / Saver.restore.
+  Every file is written under a temporary name and renamed into place (os.replace), the state file last: a process stopped in the
+  middle of a save (torchrun ends every rank when one dies) leaves the previous checkpoint and its state file intact, never a
+  truncated one that a restart would trust."""
   d = os.path.dirname(prefix)
   if d:
     os.makedirs(d, exist_ok=True)
   items, offset = [], 0
-  with open(prefix + ".data-00000-of-00001", "wb") as f:
+  tmp = ".tmp-%d" % os.getpid()
+  data, index = prefix + ".data-00000-of-00001", prefix + ".index"
+  with open(data + tmp, "wb") as f:
     for name in sorted(tensors, key=lambda s: s.encode()):
       a = np.ascontiguousarray(tensors[name])
       if a.dtype not in _DT_OF:
@@ -516,12 +521,37 @@ def write_checkpoint(prefix, tensors, update_state=True):
       items.append((name.encode(), _entry_proto(_DT_OF[a.dtype], a.shape, 0, offset, len(raw), crc)))
       offset += len(raw)
   header = b"\x08\x01" + b"\x1a\x02\x08\x01"      # num_shards = 1, (endianness LITTLE = default 0 omitted), version {producer = 1}
-  write_table(prefix + ".index", [(b"", header)] + items)
+  write_table(index + tmp, [(b"", header)] + items)
+  os.replace(data + tmp, data)
+  os.replace(index + tmp, index)
   if update_state and d:
-    with open(os.path.join(d, "checkpoint"), "w") as f:
-      base = os.path.basename(prefix)
-      f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
+    update_checkpoint_state(d, prefix)
   return prefix
+
+
+def update_checkpoint_state(directory, prefix, all_prefixes=None):
+  """The `checkpoint` state file of a directory (tf.train.update_checkpoint_state), replaced atomically."""
+  base = os.path.basename(prefix)
+  lines = ['model_checkpoint_path: "%s"' % base]
+  for p in (all_prefixes or [prefix]):
+    lines.append('all_model_checkpoint_paths: "%s"' % os.path.basename(p))
+  state = os.path.join(directory, "checkpoint")
+  tmp = state + ".tmp-%d" % os.getpid()
+  with open(tmp, "w") as f:
+    f.write("\n".join(lines) + "\n")
+  os.replace(tmp, state)
+
+
+def list_checkpoints(directory, name):
+  """Prefixes <directory>/<name>-<step> that have both files of a V2 bundle, oldest step first."""
+  out = []
+  if not os.path.isdir(directory):
+    return out
+  for fn in os.listdir(directory):
+    m = re.match(r"^%s-(\d+)\.index$" % re.escape(name), fn)
+    if m and os.path.exists(os.path.join(directory, fn[:-len(".index")] + ".data-00000-of-00001")):
+      out.append((int(m.group(1)), os.path.join(directory, fn[:-len(".index")])))
+  return [p for _, p in sorted(out)]
 
 
 # ---- CRC32C of large buffers: lanes in lockstep (numpy) + GF(2) combination (the zlib crc32_combine construction) ------------
