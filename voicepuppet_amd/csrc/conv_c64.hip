@@ -35,8 +35,7 @@ namespace vp {
 namespace {
 constexpr int TH = 4, TW = 16, PW = TW + 2, PH = TH + 2;
 constexpr int NPATCH = PW * PH;               // 108 patch pixels
-constexpr int PPAD = 128;                     // ... padded to whole DMA rounds of the two waves (2 x 16 pixels)
-constexpr int JP = PPAD / 32;                 // patch DMA instructions per wave and chunk
+constexpr int PPAD = 128;                     // ... padded to whole DMA rounds of the block's waves (NW x 16 pixels; NW = 2, 4)
 constexpr int PBUFB = PPAD * 64;              // bytes of one channel chunk (32 channels) of a patch
 constexpr int BUFB = 2 * PBUFB;               // one patch buffer (both chunks); two buffers per block
 }  // namespace
@@ -65,9 +64,13 @@ __device__ __forceinline__ unsigned dpp_xor1(unsigned v) {       // value of lan
 
 // REF: backward-data (output *= relu'(reference)); RELU: forward activation; POOL: also write the 2x2 max pool (RELU outputs only);
 // STORE: write the full-resolution output (false with POOL: the real half of the perceptual trunk, nobody reads it)
-template <bool REF, bool RELU, bool POOL, bool STORE>
-__global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, const int ntiles) {
+// NW: waves of a block = 32-channel slices of the output (2: 64 channels, VGG conv1_2; 4: 128 channels, conv2_1 forward)
+template <int NW, bool REF, bool RELU, bool POOL, bool STORE>
+__global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a, const int ntiles) {
   static_assert(!POOL || (RELU && !REF), "the packed max pool compares relu outputs");
+  static_assert(NW == 2 || (NW == 4 && !POOL && !REF), "wave layouts of the staged store");
+  constexpr int JP = PPAD / (16 * NW);          // patch DMA instructions per wave and chunk
+  constexpr int CB = NW * 64;                   // bytes of one output pixel (32 * NW channels)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,11 +114,11 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
     const int px = fi + pc;
     tb0[pc] = (px << 6) + (((fg ^ (px >> 1)) & 3) << 4);
   }
-  // patch DMA lanes: instruction j of this wave covers patch pixels (wave + 2j) * 16 .. + 15, lane -> (pixel, slot)
+  // patch DMA lanes: instruction j of this wave covers patch pixels (wave + NW j) * 16 .. + 15, lane -> (pixel, slot)
   int ppy[JP], ppx[JP], prel[JP];
 #pragma unroll
   for (int j = 0; j < JP; ++j) {
-    const int pp = (wave + 2 * j) * 16 + (lane >> 2);
+    const int pp = (wave + NW * j) * 16 + (lane >> 2);
     ppy[j] = pp < NPATCH ? pp / PW : 1 << 20;            // (rows beyond the patch: never inside the image)
     ppx[j] = pp % PW;
     prel[j] = (ppy[j] * a.Win + ppx[j]) * 128 + (((lane & 3) ^ ((ppx[j] >> 1) & 3)) * 8) * (int)sizeof(bf16);
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
       const int ih = y0 + dh0 + ppy[j], iw = x0 + dw0 + ppx[j];
       const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
       const unsigned vo = ok ? (unsigned)(base + prel[j]) : DMA_OOB;
-      uint4* l0 = reinterpret_cast<uint4*>(smem + buf * BUFB) + (wave + 2 * j) * 64;
+      uint4* l0 = reinterpret_cast<uint4*>(smem + buf * BUFB) + (wave + NW * j) * 64;
       dma16_buf(rsX, vo, 0u, l0);
       dma16_buf(rsX, vo, 64u, l0 + PBUFB / 16);
     }
@@ -165,12 +168,12 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
     asm volatile("" ::: "memory");
     const int n = t / tpi, rem = t - n * tpi;
     const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
-    const size_t off00 = ((size_t)(n * a.Hof + y0) * a.Wof + x0 + fi) * 64 + c0;            // elements; tile row r: + r * Wof * 64
+    const size_t off00 = ((size_t)(n * a.Hof + y0) * a.Wof + x0 + fi) * (32 * NW) + c0;     // elements; tile row r: + r * Wof * 32 NW
     // backward-data: the reference rows of the tile, requested BEFORE the next patch so that they return first (loads retire in order)
     uint4 rz[TH];
     if constexpr (REF) {
 #pragma unroll
-      for (int r = 0; r < TH; ++r) rz[r] = *reinterpret_cast<const uint4*>(refp + off00 + (size_t)r * a.Wof * 64);
+      for (int r = 0; r < TH; ++r) rz[r] = *reinterpret_cast<const uint4*>(refp + off00 + (size_t)r * a.Wof * (32 * NW));
     }
     if (t + G < ntiles && (!(C64_ABL & 1) || it < 1)) issue_patch(t + G, buf ^ 1);
     int tb[3];
@@ -233,18 +236,23 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
       // touch sixteen 64-byte half lines.  The tile goes through 8 KB of LDS instead (16-byte slot s of pixel px at slot s ^ (px & 7):
       // conflict-free b128 writes and reads) and wave w stores tile rows 2w, 2w + 1 as whole 128-byte lines, 1 KB contiguous per instruction
       char* stg = smem + 2 * BUFB;
+      constexpr int SPP = CB / 16;                   // 16-byte slots per pixel (8, 16)
 #pragma unroll
       for (int r = 0; r < TH; ++r)
-        *reinterpret_cast<uint4*>(stg + (r * 16 + fi) * 128 + (((4 * wave + fg) ^ (fi & 7)) << 4)) = pk[r];
+        *reinterpret_cast<uint4*>(stg + (r * 16 + fi) * CB + (((4 * wave + fg) ^ (fi & 7)) << 4)) = pk[r];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (a raw s_barrier does not wait for this wave's LDS writes)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (!(C64_ABL & 2) || pk[0].x == 0x12345u) {
+        // TH * 16 pixels x SPP slots = TH * NW / 2 wave-instructions per ... every wave issues TH of them: NW = 2: rows 2w, 2w + 1 in
+        // halves of 8 pixels; NW = 4: row w in quarters of 4 pixels
 #pragma unroll
         for (int j = 0; j < TH; ++j) {
-          const int row = 2 * wave + (j >> 1), px = (j & 1) * 8 + (lane >> 3), sl = lane & 7;
-          const uint4 o = *reinterpret_cast<const uint4*>(stg + (row * 16 + px) * 128 + ((sl ^ (px & 7)) << 4));
-          unsigned* yp = reinterpret_cast<unsigned*>(Yp + ((size_t)(n * a.Hof + y0 + row) * a.Wof + x0 + px) * 64 + sl * 8);
+          constexpr int PPI = 64 / SPP;              // pixels per store instruction (8, 4)
+          const int g = wave * TH + j;               // the block's store instructions, in pixel order
+          const int pi = g * PPI + lane / SPP, row = pi >> 4, px = pi & 15, sl = lane % SPP;
+          const uint4 o = *reinterpret_cast<const uint4*>(stg + (row * 16 + px) * CB + ((sl ^ (px & 7)) << 4));
+          unsigned* yp = reinterpret_cast<unsigned*>(Yp + ((size_t)(n * a.Hof + y0 + row) * a.Wof + x0 + px) * (32 * NW) + sl * 8);
           __builtin_nontemporal_store(o.x, yp); __builtin_nontemporal_store(o.y, yp + 1);
           __builtin_nontemporal_store(o.z, yp + 2); __builtin_nontemporal_store(o.w, yp + 3);
         }
@@ -268,10 +276,12 @@ __global__ __launch_bounds__(128, 2) void conv_c64_kernel(const IgemmArgs a, con
 }
 
 // what the kernel handles: a patch-plan 3x3 (conv_ops.h plan_make_patch: permuted rows, kswap) from one 64-channel tensor to 64 channels,
-// plain store (no batch statistics, no accumulation, no affine on the reference), image sides multiples of the 4 x 16 tile
+// (or 128: forward without pooling only), plain store (no batch statistics, no accumulation, no affine on the reference), image sides
+// multiples of the 4 x 16 tile
 bool conv_c64_eligible(const IgemmArgs& a, int is_bf16) {
   if (!is_bf16 || a.patch != 1 || !patch3_eligible(a, 1)) return false;
-  if (a.Cout != 64 || a.CoutPad != 64 || a.Cin != 64 || a.x.C[0] != 64 || a.ldY != 64 || !a.rowperm || a.splitk != 1) return false;
+  if ((a.Cout != 64 && a.Cout != 128) || a.CoutPad != a.Cout || a.ldY != a.Cout || a.Cin != 64 || a.x.C[0] != 64 || !a.rowperm || a.splitk != 1) return false;
+  if (a.Cout == 128 && (a.ref || a.pool_out)) return false;
   if (a.Hg % TH || a.Wg % TW || a.Hin != a.Hg || a.Win != a.Wg || a.Hof != a.Hg || a.Wof != a.Wg) return false;
   if ((a.out_act != ACT_NONE && a.out_act != ACT_RELU) || (a.ref && (a.ref_act != ACT_RELU || a.out_act != ACT_NONE || a.pool_out))) return false;
   if (a.pool_out && (a.out_act != ACT_RELU || (a.Hg & 1))) return false;
@@ -283,12 +293,15 @@ bool conv_c64_eligible(const IgemmArgs& a, int is_bf16) {
 
 hipError_t launch_conv_c64(const IgemmArgs& a, hipStream_t st) {
   const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);
-  const int grid = ntiles < 1024 ? ntiles : 1024;                  // four two-wave blocks on each of the 256 CUs
   void (*kern)(const IgemmArgs, const int);
-  if (a.ref) kern = conv_c64_kernel<true, false, false, true>;
-  else if (a.pool_out) kern = a.pool_only ? conv_c64_kernel<false, true, true, false> : conv_c64_kernel<false, true, true, true>;
-  else kern = a.out_act == ACT_RELU ? conv_c64_kernel<false, true, false, true> : conv_c64_kernel<false, false, false, true>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(128), 2 * BUFB + TH * 16 * 128, st, a, ntiles);       // two patch buffers + the output staging tile: 40 KB
+  const int nw = a.Cout / 32;
+  if (nw == 4) kern = a.out_act == ACT_RELU ? conv_c64_kernel<4, false, true, false, true> : conv_c64_kernel<4, false, false, false, true>;
+  else if (a.ref) kern = conv_c64_kernel<2, true, false, false, true>;
+  else if (a.pool_out) kern = a.pool_only ? conv_c64_kernel<2, false, true, true, false> : conv_c64_kernel<2, false, true, true, true>;
+  else kern = a.out_act == ACT_RELU ? conv_c64_kernel<2, false, true, false, true> : conv_c64_kernel<2, false, false, false, true>;
+  // LDS: two patch buffers + the output staging tile (40 / 48 KB); blocks per CU: 4 two-wave / 2 four-wave blocks (2 waves per SIMD)
+  const int grid2 = ntiles < 2048 / nw ? ntiles : 2048 / nw;
+  hipLaunchKernelGGL(kern, dim3(grid2), dim3(nw * 64), 2 * BUFB + TH * 16 * nw * 64, st, a, ntiles);
   return hipGetLastError();
 }
 

@@ -1838,9 +1838,10 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     return launch_igemm_smallp(a, sizeof(T) == 2, st);
   }
   if constexpr (sizeof(T) == 2) {
-    // 3x3 stride-1 conv from 64 to 64 channels (VGG conv1_2 forward / backward-data): weights resident in registers (conv_c64.hip)
+    // 3x3 stride-1 conv from 64 to 64 / 128 channels (VGG conv1_2 forward / backward-data, conv2_1 forward): weights resident in
+    // registers, 4 x 16-pixel tiles (conv_c64.hip)
     if (c64_knob() && conv_c64_eligible(a, 1)) {
-      ProfScope prof("c64", true, 64, 128, 2.0 * Pn * a.Cout * kreal,
+      ProfScope prof("c64", true, a.Cout, 64, 2.0 * Pn * a.Cout * kreal,
                      es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
       return launch_conv_c64(a, st);
     }
