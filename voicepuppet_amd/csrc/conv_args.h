@@ -71,6 +71,11 @@ struct IgemmArgs {
   // patch kernel (conv_patch.hip; plan-time decision, the packed weights carry PackDesc::kswap): stride-1 taps on a regular grid,
   // tap t = r * p_kw + c  ->  (dh, dw) = (p_dhf + r * p_dhs, p_dwf + c * p_dws)
   int patch, p_kw, p_dhf, p_dhs, p_dwf, p_dws;
+  // first layers without batch-norm (encoder_1, encoder_fg_1, discriminator layer_1; conv_cin8_kernel only - conv_cin8_eligible): the
+  // epilogue also writes the activations the consumers read - what act_apply would materialise from Y in a pass of its own (Y itself
+  // is still stored: the rounding-aware oracle tests teacher-force on it)
+  void* xa_lrelu;
+  void* xa_relu;
   void* pool_out;           // patch kernel, 16 x 16-pixel tiles: also write the 2x2 max-pooled output [N][Hg/2][Wg/2][ldY] (null: no)
   int pool_only;            // with pool_out: write ONLY the pooled output (nobody reads the full-resolution tensor: the real half of the VGG trunk)
   // few-pixel kernel (conv_smallp.hip; patch == 3, plan-time decision: packed rows unpermuted): 32 channels x sp_npt * 16 pixels per tile,

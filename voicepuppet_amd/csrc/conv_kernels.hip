@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
   __shared__ uint4 otile[4 * 16 * 144 / 16];
   // output rows are dense ([pixel][64]) and the pixel grid is the output grid: a tile's 16 pixels are one 2 KB run
   // (measured: conv1_1, stride 1, 64 images: 0.209 -> 0.178 ms; the stride-2 first layers, a quarter of the output, lose 8 us each)
-  const bool rowrun = a.sh == 1 && a.ldY == 64 && a.Hof == (1 << lgH) && a.Wof == (1 << lgW) && (P & 15) == 0;
+  const bool rowrun = a.sh == 1 && a.ldY == 64 && a.Hof == (1 << lgH) && a.Wof == (1 << lgW) && (P & 15) == 0 && !a.xa_lrelu && !a.xa_relu;
   {
     const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
     for (int idx = threadIdx.x; idx < S * 4 * 64; idx += 256) {
@@ -823,9 +823,32 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
       return;
     }
     const int ow = p & ((1 << lgW) - 1), oh = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
-    bf16* yp = reinterpret_cast<bf16*>(a.Y) + ((size_t)(n * a.Hof + oh) * a.Wof + ow) * a.ldY + 8 * g;
+    const size_t yo = ((size_t)(n * a.Hof + oh) * a.Wof + ow) * a.ldY + 8 * g;
+    bf16* yp = reinterpret_cast<bf16*>(a.Y) + yo;
     reinterpret_cast<uint4*>(yp)[0] = Elem<bf16>::pack(lo);
     reinterpret_cast<uint4*>(yp + 32)[0] = Elem<bf16>::pack(hi);
+    // the consumers' activations of the ROUNDED output (what act_apply computes from the stored tensor: same bits)
+    if (a.xa_lrelu || a.xa_relu) {
+      float rl[8], rh[8];
+      Elem<bf16>::unpack(Elem<bf16>::pack(lo), rl);
+      Elem<bf16>::unpack(Elem<bf16>::pack(hi), rh);
+      if (a.xa_lrelu) {
+        float t0[8], t1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t0[e] = act_apply(ACT_LRELU, rl[e]); t1[e] = act_apply(ACT_LRELU, rh[e]); }
+        bf16* xp = reinterpret_cast<bf16*>(a.xa_lrelu) + yo;
+        reinterpret_cast<uint4*>(xp)[0] = Elem<bf16>::pack(t0);
+        reinterpret_cast<uint4*>(xp + 32)[0] = Elem<bf16>::pack(t1);
+      }
+      if (a.xa_relu) {
+        float t0[8], t1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t0[e] = act_apply(ACT_RELU, rl[e]); t1[e] = act_apply(ACT_RELU, rh[e]); }
+        bf16* xp = reinterpret_cast<bf16*>(a.xa_relu) + yo;
+        reinterpret_cast<uint4*>(xp)[0] = Elem<bf16>::pack(t0);
+        reinterpret_cast<uint4*>(xp + 32)[0] = Elem<bf16>::pack(t1);
+      }
+    }
   };
 
   // three fragment sets: two tiles of loads stay in flight behind the tile being finished
@@ -1731,6 +1754,15 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
 }
 
 
+// 8-channel (padded image) inputs, 64 outputs: what conv_cin8_kernel handles (`zeros` is not looked at: the step executor asks before it
+// has filled the run-time pointers in)
+bool conv_cin8_eligible(const IgemmArgs& a, int is_bf16) {
+  const bool pow2 = (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0;
+  return is_bf16 && a.Cin == 8 && a.x.C[0] == 8 && a.x.C[1] == 0 && a.Cout == 64 && a.ldY == 64 && a.nclass == 1 && a.splitk == 1 && a.os == 1 &&
+         a.Hof == a.Hg && a.Wof == a.Wg && pow2 && !a.ref && !a.accumulate && !a.y_f32 && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
+         a.ntaps <= 16 && (a.Kpad == 96 || a.Kpad == 128) && (size_t)a.N * a.Hin * a.Win * 16 < 0x70000000ull;
+}
+
 template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int cfg, hipStream_t st) {
   hipError_t e;
   int pbc, pbp;
@@ -1741,11 +1773,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   const double es = sizeof(T);
   if constexpr (sizeof(T) == 2) {
     // 8-channel (padded image) inputs, 64 outputs: the direct register-resident form (conv_cin8_kernel)
-    static const bool cin8_on = !getenv("VP_NO_CIN8");
-    const bool pow2 = (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0;
-    if (cin8_on && a.zeros && a.Cin == 8 && a.x.C[0] == 8 && a.x.C[1] == 0 && a.Cout == 64 && a.ldY == 64 && a.nclass == 1 && a.splitk == 1 &&
-        a.os == 1 && a.Hof == a.Hg && a.Wof == a.Wg && pow2 && !a.ref && !a.accumulate && !a.y_f32 && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
-        a.ntaps <= 16 && (a.Kpad == 96 || a.Kpad == 128) && (size_t)a.N * a.Hin * a.Win * 16 < 0x70000000ull) {
+    if (a.zeros && conv_cin8_eligible(a, 1)) {
       ProfScope prof("cin8", true, 64, 16, 2.0 * Pn * a.Cout * kreal,
                      es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.Cout + Pn * a.Cout), st);
       const int ntile = (int)((Pn + 15) / 16);

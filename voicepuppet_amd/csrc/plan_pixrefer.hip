@@ -695,6 +695,14 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
   }
   static const bool dbg_stats = getenv("VP_DBG_STATS") != nullptr;
   if (dbg_stats && L.has_bn) fprintf(stderr, "[stats] %s fused=%d splitk=%d cfg=%d nclass=%d groups=%d\n", L.scope.c_str(), (int)fused_stats, a.splitk, L.fwd.cfg, a.nclass, n.groups);
+  // first layers (8-channel image inputs, no batch-norm: encoder_1, encoder_fg_1, discriminator layer_1): the direct kernel's epilogue
+  // writes the consumers' activations itself - no act_apply pass over the (67 .. 201 MB) output
+  bool acts_fused = false;
+  if (h->bf16 && !L.has_bn && !L.tapgemm && (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) && a.out_act == ACT_NONE && conv_cin8_eligible(a, 1)) {
+    a.xa_lrelu = to.need_act[ACT_LRELU] ? to.xa[ACT_LRELU] : nullptr;
+    a.xa_relu = to.need_act[ACT_RELU] ? to.xa[ACT_RELU] : nullptr;
+    acts_fused = true;
+  }
   profile_tag((L.scope + ":fwd").c_str());
   VP_HIP_CHECK(launch_igemm(a, h->bf16, L.fwd.cfg, st));
   if (L.tapgemm) {
@@ -704,7 +712,7 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
     ta.N = L.g.N; ta.Hin = L.g.Hin; ta.Win = L.g.Win; ta.Hout = L.g.Hout; ta.Wout = L.g.Wout; ta.ks = L.g.ks; ta.pad = L.g.pad;
     VP_HIP_CHECK(launch_tap_gather(ta, st));
   }
-  bool acts_done = false;
+  bool acts_done = acts_fused;
   if (L.has_bn) {
     const int rc = run_bn_stats(h, n, L, fused_stats ? stat_chunks : 0, st, ss);
     if (rc < 0) return rc;
