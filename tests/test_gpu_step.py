@@ -337,6 +337,41 @@ def test_conv1_2_register_resident_weights_kernel_in_situ():
 
 
 @pytest.mark.gpu
+def test_transposed_conv_classes_with_register_resident_weights_in_situ():
+  """The backward-data passes of the 64 -> 128 stride-2 convolutions (discriminator layer_2 in both gradient passes, encoder_fg_2,
+  and encoder_2, which ADDS to the gradient decoder_1 wrote into encoder_1's buffer first) run on conv_dc64.hip at ngf = ndf = 64: the
+  gradient tensors they write - the lrelu'(reference) product included - against the unrolled patch kernel they ran on before
+  (vp_tune("dc64", 0): different K-sum order, same rounding points), and the weight gradients downstream of them."""
+  from voicepuppet_amd import _lib
+  L = _lib.lib()
+  n = 2
+  got, grads = {}, {}
+  for on in (1, 0):
+    L.vp_tune(b"dc64", on)
+    try:
+      eng = PixReferEngine(n, 256, 64, 64, dtype="bf16", training=True)
+      eng.load_params(eng.random_params(5))
+      g = torch.Generator(device="cpu").manual_seed(9)
+      batch = [torch.rand(n, 256, 256, c, generator=g).cuda() for c in (6, 6, 3, 3)]
+      eng.profile(1)
+      eng.forward(*batch); eng.backward()
+      torch.cuda.synchronize()
+      classes = {r["name"] for r in eng.profile_collect()}
+      eng.profile(0)
+      assert any(c.startswith("dc64_") for c in classes) == bool(on), classes
+      got[on] = {k: eng.tensor(k).float().cpu().numpy() for k in ("d/layer_1:dy", "g/encoder_fg_1:dy", "g/encoder_1:dy", "d_din")}
+      grads[on] = (eng.grads_d.clone(), eng.grads_g.clone())
+      del eng
+    finally:
+      L.vp_tune(b"dc64", 1)
+  for k in got[1]:
+    assert np.isfinite(got[1][k]).all() and np.abs(got[1][k]).max() > 0, k
+    assert gu.rel_l2(got[1][k], got[0][k]) < 4e-3, (k, gu.rel_l2(got[1][k], got[0][k]))
+  rel = lambda x, y: float((x - y).norm() / y.norm())
+  assert rel(grads[1][0], grads[0][0]) < 4e-3 and rel(grads[1][1], grads[0][1]) < 4e-3, (rel(grads[1][0], grads[0][0]), rel(grads[1][1], grads[0][1]))
+
+
+@pytest.mark.gpu
 def test_forward_is_hipgraph_capturable():
   """The library's launch sequence is fixed, allocates nothing and never synchronises: one inference forward captured
   into a hipGraph replays to the identical output (the claim of DESIGN.md section 2)."""

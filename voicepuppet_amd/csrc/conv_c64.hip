@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
     const int pp = (wave + NW * j) * 16 + (lane >> 2);
     ppy[j] = pp < NPATCH ? pp / PW : 1 << 20;            // (rows beyond the patch: never inside the image)
     ppx[j] = pp % PW;
-    prel[j] = (ppy[j] * a.Win + ppx[j]) * 128 + (((lane & 3) ^ ((ppx[j] >> 1) & 3)) * 8) * (int)sizeof(bf16);
+    prel[j] = pp < NPATCH ? (ppy[j] * a.Win + ppx[j]) * 128 + (((lane & 3) ^ ((ppx[j] >> 1) & 3)) * 8) * (int)sizeof(bf16) : 0;
   }
 
   __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * 64 * sizeof(bf16)));

@@ -1874,6 +1874,15 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       return launch_conv_c64(a, st);
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    // 4x4 stride-2 transposed conv from 128 to 64 channels (backward-data of layer_2 / encoder_2 / encoder_fg_2): weights resident in
+    // registers, two parity classes per block (conv_dc64.hip)
+    if (dc64_knob() && conv_dc64_eligible(a, 1)) {
+      ProfScope prof("dc64", true, 64, 128, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+      return launch_conv_dc64(a, st);
+    }
+  }
   if (a.patch) {   // stride-1 convs with the input patch staged once per channel chunk (conv_patch.hip)
     // class name per kernel template: patch2 (parity classes, conv_patch2.hip), patch3 (unrolled 3x3, conv_patch3.hip), patch (generic)
     const char* pk = a.patch == 2 ? "patch2" : (patch3_knob() && patch3_eligible(a, sizeof(T) == 2) ? "patch3" : "patch");

@@ -126,6 +126,7 @@ inline int& patch_small_knob() { static int v = getenv("VP_PATCH2_SMALL") ? atoi
 inline int& patch_longk_knob() { static int v = getenv("VP_PATCH2_LONGK") ? atoi(getenv("VP_PATCH2_LONGK")) : 1; return v; }      // 1: long-K 512-row layers stay on the 256x256 tile
 inline int& patch3_knob() { static int v = getenv("VP_NO_PATCH3") ? 0 : 1; return v; }   // 3x3 layers on the unrolled patch kernel (conv_patch3.hip)
 inline int& c64_knob() { static int v = 1; return v; }   // 64 -> 64 channel 3x3 layers on the register-resident-weights kernel (conv_c64.hip)
+inline int& dc64_knob() { static int v = 1; return v; }  // 128 -> 64 channel transposed-conv classes on conv_dc64.hip
 inline int& patch_minblk_knob() { static int v = getenv("VP_PATCH2_MINBLK") ? atoi(getenv("VP_PATCH2_MINBLK")) : 384; return v; }
 
 // pixel tile of a patch-kernel plan: bp = 512 -> 16 x 32, 256 -> 16 x 16, 128 -> 8 x 16

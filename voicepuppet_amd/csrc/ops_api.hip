@@ -72,6 +72,7 @@ int vp_tune(const char* key, int value) {
   if (k == "wgrad_tr") { wgrad_tr_knob() = value; return VP_OK; }
   if (k == "patch3") { patch3_knob() = value; return VP_OK; }
   if (k == "c64") { c64_knob() = value; return VP_OK; }
+  if (k == "dc64") { dc64_knob() = value; return VP_OK; }
   if (k == "patch2") { patch2_knob() = value; return VP_OK; }
   if (k == "patch_xcd") { patch_xcd_knob() = value; return VP_OK; }
   if (k == "smallp_max_pixels") { smallp_knob() = value; return VP_OK; }
