@@ -237,11 +237,25 @@ def bfmnet_train_record(device, with_cpu, steps=30, batch=4, frames=24, nver=357
 STEP_ROOFLINE_MS_BS32_256 = {"bf16": 2.65, "f32": 33.6}      # mixed per-layer roofline of the whole step (HBM 6.3 TB/s)
 
 
+# --tune keys that select the step executor's schedule of the benchmark plan: "streams" (vp_pixrefer_desc::streams: 1 = everything on
+# the caller's stream, no executor streams), "overlap" / "d_backward_fork" / "d_beside_vgg" (vp_pixrefer_set_option)
+SCHEDULE_KEYS = ("streams", "overlap", "d_backward_fork", "d_beside_vgg")
+SCHEDULE = {}
+
+
+def make_engine(per_gpu, height, dtype):
+  from voicepuppet_amd.engine import PixReferEngine
+  eng = PixReferEngine(per_gpu, height, 64, 64, dtype=dtype, training=True, streams=SCHEDULE.get("streams", 0))
+  for k in ("overlap", "d_backward_fork", "d_beside_vgg"):
+    if k in SCHEDULE:
+      eng.set_option(k, SCHEDULE[k])
+  return eng
+
+
 def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group, profile, grad_dtype="f32"):
   import torch
   import torch.distributed as dist
-  from voicepuppet_amd.engine import PixReferEngine
-  eng = PixReferEngine(per_gpu, height, 64, 64, dtype=dtype, training=True)
+  eng = make_engine(per_gpu, height, dtype)
   eng.grad_transport = grad_dtype
   eng.load_params(eng.random_params(seed=0))   # the reference's initialisers, identical on every rank
   batch = synth_batch(per_gpu, height, 1000 + rank, device)
@@ -419,7 +433,10 @@ def main():
     from voicepuppet_amd import _lib
     for kv in args.tune:
       k, v = kv.split("=")
-      _lib.check(_lib.lib().vp_tune(k.encode(), int(v)), "vp_tune " + kv)
+      if k in SCHEDULE_KEYS:            # per-plan schedule (vp_pixrefer_desc fields / vp_pixrefer_set_option), not a library knob
+        SCHEDULE[k] = int(v)
+      else:
+        _lib.check(_lib.lib().vp_tune(k.encode(), int(v)), "vp_tune " + kv)
   main_res = run_config(per_gpu_batch(args, args.scaling, world), args.height, args.dtype, args.steps, args.warmup,
                         rank, world, device, group, not args.no_profile, grad_dtype)
   other = None

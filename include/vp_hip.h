@@ -51,6 +51,16 @@ typedef struct vp_pixrefer_desc {
   float gan_weight;
   int per_sample_bn; /* inference only: batch-norm statistics per sample (== running N frames through the
                         reference's batch-1 graph, infer_bfmvid.py:152,198, but batched on the device) */
+  /* Schedule of a training plan, fixed at vp_pixrefer_create (no reference counterpart: the TF graph has one executor).  0 = default
+   * in every field, so a zero-initialised tail keeps the shipped schedule; results are bit-identical under every setting.
+   *   streams          0 / 4: the step is spread over the caller's stream + three of the executor's; 3: three in all (a host with a busy
+   *                    stream of its own, vp_pixrefer_use_streams); 1: the executor creates no stream, everything runs on the caller's
+   *   d_backward_fork  0: default (the discriminator-loss pass starts behind the generator-loss pass through D and the VGG trunk);
+   *                    1 / 2 / 3: fork point 0 (at once) / 1 (behind the pass through D) / 2 (the default)
+   *   d_beside_vgg     0 / 2: discriminator passes on the branch stream beside the VGG passes (default); 1: on the caller's stream */
+  int streams;
+  int d_backward_fork;
+  int d_beside_vgg;
 } vp_pixrefer_desc;
 
 typedef struct vp_pixrefer vp_pixrefer_t;
@@ -108,21 +118,22 @@ int vp_pixrefer_backward_g(vp_pixrefer_t* h, void* stream);
  * owns, forked from and joined into `stream` with events (no host blocking; bit-identical results).  The same for a host with
  * work of its own in between: _fork schedules the discriminator-loss pass (it starts inside stage 0 of the generator backward,
  * behind the generator-loss pass through the discriminator - or at once with vp_pixrefer_set_option(h, "d_backward_fork", 0)), _join makes `stream`
- * wait for it; grads_d is final after the join, which may come after any stage (the later, the more of the pass is hidden).  (VP_NO_OVERLAP=1 in the environment at create time: both run
+ * wait for it; grads_d is final after the join, which may come after any stage (the later, the more of the pass is hidden).  (vp_pixrefer_desc::streams = 1: both run
  * on `stream`, one after the other.) */
 int vp_pixrefer_backward_d_fork(vp_pixrefer_t* h, void* stream);
 int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream);
 /* The executor's own side stream (hipStream_t), for a data-parallel host that issues its collectives there instead of on one more
  * stream of its own (the device has few hardware queues; streams beyond them share one).  Work the host enqueues on it runs behind the
- * discriminator-loss pass of the step.  NULL if the plan runs on a single stream (VP_NO_OVERLAP). */
+ * discriminator-loss pass of the step.  NULL if the plan runs on a single stream (vp_pixrefer_desc::streams = 1). */
 void* vp_pixrefer_side_stream(vp_pixrefer_t* h);
 /* Streams a training step is spread over: 4 (default) or 3.  A host that runs a busy stream of its own beside the step (an input
  * prefetcher) asks for 3: the device has few hardware queues, a fifth busy stream shares one with an executor stream. */
 int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n);
 /* Schedule options of ONE plan (no reference counterpart: the TF graph has one executor): "overlap" 0 / 1 (the whole step on `stream`
  * / spread over the executor's streams, default 1), "d_backward_fork" 0..2 (where vp_pixrefer_backward starts the discriminator-loss
- * pass, default 2), "d_beside_vgg" 0 / 1 (default 1).  Per handle: two plans in one process do not change each other's schedule.  The
- * vp_tune keys of the same names only set the defaults a plan copies at vp_pixrefer_create.  Bit-identical results under every setting. */
+ * pass, default 2), "d_beside_vgg" 0 / 1 (default 1).  Per handle: two plans in one process do not change each other's schedule; the
+ * initial values come from the descriptor (vp_pixrefer_desc::streams / d_backward_fork / d_beside_vgg).  Bit-identical results under
+ * every setting. */
 int vp_pixrefer_set_option(vp_pixrefer_t* h, const char* key, int value);
 /* The same pass in vp_pixrefer_backward_g_stages() = 3 consecutive stages (stage < 0: all).  After stage s a contiguous
  * range of the generator gradient arena is final (0: from generator/merged_decoder_5 to the end; 1: from
@@ -168,8 +179,9 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
  * the call see the new value.  Keys: "patch_tiles" (bit 0 / 1 / 2: allow the 256- / 128- / 64-row tiles of the stride-1 patch
  * kernel, default 7), "patch_min_blocks" (smallest grid that runs on it, default 384), "patch_small_tiles" (bit 0: 16x16-pixel
  * tiles for the 128- / 64-row variants, bit 1: 8x16 for the 256-row variant - two blocks per CU; default 3), "patch_long_k_on_256"
- * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile), "overlap" (default 1; 0: the step
- * executor keeps everything on the caller's stream - needed for per-kernel timing).  No counterpart in the reference. */
+ * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile), "c64" / "dc64" (default 1: the
+ * register-resident-weights kernels conv_c64.hip / conv_dc64.hip; 0: the patch kernels those layers ran on before).  No counterpart in
+ * the reference.  (The step executor's schedule is per plan: vp_pixrefer_desc / vp_pixrefer_set_option.) */
 int vp_tune(const char* key, int value);
 /* Further keys: "smallp_max_pixels" (largest pixel count per parity class that runs on the few-pixel kernel conv_smallp.hip,
  * default 256, 0: off), "phase_marks" (1: the step executor records HIP events on the caller's stream at its phase boundaries).

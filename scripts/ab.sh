@@ -3,7 +3,7 @@
 # Step time of the G+D benchmark step under different settings, two rounds each, on the GPU box:
 #   bash scripts/ab.sh [-b "4 8 32"] SETTING [SETTING ...]
 # a SETTING is a quoted list of environment assignments and / or vp_tune knobs, e.g.
-#   bash scripts/ab.sh "" "VP_SMALLP=0" "tune:patch_tiles=3 VP_NO_WSPLIT=1"
+#   bash scripts/ab.sh "" "tune:smallp_max_pixels=0" "tune:patch_tiles=3 tune:streams=1" "VP_LIB=$PWD/voicepuppet_amd/libvp_r4.so"
 cd "${GRAFT_REPO_ROOT:-.}"
 batches="32"
 if [ "$1" = "-b" ]; then batches="$2"; shift 2; fi

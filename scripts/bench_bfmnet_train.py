@@ -1,4 +1,4 @@
-"""ms per BFMNet training step on one MI355X: `python scripts/bench_bfmnet_train.py [steps] [batch] [nver] [eager|graph|auto]`.
+"""ms per BFMNet training step on one MI355X: `python scripts/bench_bfmnet_train.py [steps] [batch] [nver] [eager|graph|auto] [one]` (one: the eager step on one stream).
 Synthetic clips of 24 frames (the generator's slice length), a random stand-in face model of `nver` vertices (35709 = BFM_model_front),
 dropout on, loss fetched every step as train_bfmnet.py does.  Prints one JSON line."""
 import json
@@ -22,7 +22,8 @@ def main():
   rng = np.random.default_rng(0)
   vm = np.ones((nver, 3), np.float32)
   vm[rng.choice(nver, nver // 20, replace=False)] = 10
-  eng = BFMNetTrainEngine(B, T, {"exBase": rng.normal(0, 0.05, (3 * nver, 64)).astype(np.float32), "vmask": vm.reshape(-1)})
+  eng = BFMNetTrainEngine(B, T, {"exBase": rng.normal(0, 0.05, (3 * nver, 64)).astype(np.float32), "vmask": vm.reshape(-1)},
+                          side_stream=not (len(sys.argv) > 5 and sys.argv[5] == "one"))
   from voicepuppet_amd.bfmnet.bfmnet import random_variables
   eng.load_params(random_variables(0))
   dev = eng.dev

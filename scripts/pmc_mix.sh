@@ -2,9 +2,8 @@
 # instruction mix (VALU / SALU / MFMA / LDS wave-instructions) of every kernel of the training step, single stream
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-export VP_NO_OVERLAP=1
 o=gpurun_out/pmc_mix
 rm -rf $o; mkdir -p $o
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS -d $o/p -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline --no-bfmnet-train > $o/p.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS -d $o/p -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline --no-bfmnet-train --tune streams=1 > $o/p.log 2>&1
 python3 scripts/pmc_mix.py $o/p > $o/mix.txt; head -60 $o/mix.txt
 rm -rf $o/p

@@ -5,10 +5,9 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 o=gpurun_out/r05_base; mkdir -p $o
 bash scripts/ab.sh -b "32 8 4" "" > $o/ab.txt 2>&1
-VP_DBG_STATS=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline --no-bfmnet-train > /dev/null 2> $o/dbg_stats.txt
 timeout 300 python scripts/layer_profile.py 32 256 bf16 > $o/layer_times.txt 2>&1
 timeout 300 python scripts/phases.py > $o/phases.txt 2>&1
 bash scripts/timeline.sh 32 > /dev/null 2>&1
 python3 scripts/timeline.py gpurun_out/timeline/on/on_kernel_trace.csv.gz > $o/timeline.txt 2>&1
 cp gpurun_out/timeline/on/on_kernel_trace.csv.gz $o/trace_bs32.csv.gz; rm -rf gpurun_out/timeline
-cat $o/ab.txt; sort -u $o/dbg_stats.txt | head -40; head -30 $o/timeline.txt
+cat $o/ab.txt; head -30 $o/timeline.txt

@@ -14,6 +14,12 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
+  # No test of this suite runs for minutes: a per-test ceiling (pytest-timeout, when installed) turns a wedged rendezvous or a device
+  # that stops answering into a failure with a traceback instead of a run that sits until the driver's own limit.
+  if config.pluginmanager.hasplugin("timeout"):
+    for item in items:
+      if item.get_closest_marker("timeout") is None:
+        item.add_marker(pytest.mark.timeout(900))
   # GPU tests are selected explicitly with `-m gpu`; skip them when no device is visible.
   import torch
   if torch.cuda.is_available():

@@ -130,17 +130,15 @@ def test_graphed_step_equals_eager_step():
   assert len(losses) == 3 and all(np.isfinite(l) for l in losses)
 
 
-def test_two_stream_step_equals_one_stream_step(monkeypatch):
-  """The eager step runs its weight gradients on a second stream (train_engine._fork); with VP_F4_NO_SIDE=1 everything stays on one.
+def test_two_stream_step_equals_one_stream_step():
+  """The eager step runs its weight gradients on a second stream (train_engine._fork); with side_stream=False everything stays on one.
   Same kernels on the same values: gradients and updated parameters are bit-identical over three steps."""
   B, T, seq = 3, 5, [5, 2, 4]
   p, mf, ears, coeff, model, masks = _case(B, T, seq, 120, 7, True)
   dev = lambda a: torch.tensor(a, device="cuda")
   outs = []
   for one_stream in (False, True):
-    if one_stream:
-      monkeypatch.setenv("VP_F4_NO_SIDE", "1")
-    eng = BFMNetTrainEngine(B, T, model)
+    eng = BFMNetTrainEngine(B, T, model, side_stream=not one_stream)
     assert (eng._side is None) == one_stream
     eng.load_params(p)
     for _ in range(3):

@@ -23,6 +23,19 @@ def _free_port():
   return p
 
 
+def _spawn(fn, args, world, deadline_s=300):
+  """mp.spawn with a deadline: workers that are still running after `deadline_s` are ended and the test fails."""
+  import time
+  ctx = mp.spawn(fn, args=args, nprocs=world, join=False)
+  t0 = time.monotonic()
+  while not ctx.join(timeout=5):
+    if time.monotonic() - t0 > deadline_s:
+      for p in ctx.processes:
+        if p.is_alive():
+          p.kill()
+      pytest.fail("data-parallel workers did not finish within %d s" % deadline_s)
+
+
 def _setup(n):
   from oracle import pixrefer_ref as ref
   params = ref.init_params(NGF, NGF, seed=3, dtype=np.float32)
@@ -32,8 +45,11 @@ def _setup(n):
 
 
 def _worker(rank, world, port, out_dir, transport="f32"):
+  import datetime
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-  dist.init_process_group("gloo", rank=rank, world_size=world)
+  # (a short collective timeout: a rank that dies or a rendezvous that never completes must fail this test in minutes, not hold the
+  # suite for gloo's default half hour)
+  dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
   torch.cuda.set_device(0)
   from voicepuppet_amd.engine import PixReferEngine
   from voicepuppet_amd.parallel import shard_batch
@@ -57,7 +73,7 @@ def test_two_ranks_equal_sequential_microbatches_on_engine_gradients(tmp_path, t
   written back as f32 - the sequential run does exactly that arithmetic on its two micro-batch gradients, so the equality stays
   bit for bit (f32 master parameters and Adam state in both)."""
   world = 2
-  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), transport), nprocs=world, join=True)
+  _spawn(_worker, (world, _free_port(), str(tmp_path), transport), world)
   from voicepuppet_amd.engine import PixReferEngine
   params, batch = _setup(world)
   eng = PixReferEngine(1, 256, NGF, NGF, dtype="f32", training=True)

@@ -63,9 +63,8 @@ def test_fused_update_and_separate_calls_stay_bit_identical():
     assert torch.equal(a.params_g, b.params_g) and torch.equal(a.params_d, b.params_d), "step %d" % s
 
 
-def test_engine_created_without_its_own_streams_matches(monkeypatch):
-  """VP_NO_OVERLAP=1 at create time: no side / branch streams exist at all (what scripts/profile_round.sh uses for the single-stream
-  kernel statistics).  The fused backward + update step must run there - it once recorded an event on the missing side stream - and
+def test_engine_created_without_its_own_streams_matches():
+  """vp_pixrefer_desc::streams = 1: no side / branch streams exist at all.  The fused backward + update step must run there - it once recorded an event on the missing side stream - and
   give the parameters of the default three-stream engine bit for bit."""
   import numpy as np
   dev = torch.device("cuda", 0)
@@ -75,9 +74,7 @@ def test_engine_created_without_its_own_streams_matches(monkeypatch):
   a = PixReferEngine(n, 256, ngf, ngf, dtype="bf16", training=True)
   p = a.random_params(seed=5)
   a.load_params(p)
-  monkeypatch.setenv("VP_NO_OVERLAP", "1")
-  b = PixReferEngine(n, 256, ngf, ngf, dtype="bf16", training=True)
-  monkeypatch.delenv("VP_NO_OVERLAP")
+  b = PixReferEngine(n, 256, ngf, ngf, dtype="bf16", training=True, streams=1)
   b.load_params(p)
   for batch in batches:
     a.train_step(*batch, lr=3e-4)

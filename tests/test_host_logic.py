@@ -304,3 +304,17 @@ def test_host_layer_under_sanitizers():
   r = _run_validate({"VP_LIB": so, "LD_PRELOAD": rt, "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0:exitcode=99", "UBSAN_OPTIONS": "halt_on_error=1:exitcode=98"})
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
   assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+
+
+def test_product_library_reads_no_environment_switches():
+  """Kernel selection and the executor's schedule are arguments (vp_pixrefer_desc, vp_pixrefer_set_option, vp_tune), not environment
+  variables read once per process: no getenv in the library sources."""
+  import glob
+  import re
+  root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "voicepuppet_amd", "csrc")
+  hits = []
+  for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+    for i, line in enumerate(open(f), 1):
+      if re.search(r"\bgetenv\s*\(", line):
+        hits.append("%s:%d" % (os.path.basename(f), i))
+  assert not hits, hits

@@ -12,7 +12,9 @@ ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 class PixReferDesc(ctypes.Structure):
   _fields_ = [("batch", ctypes.c_int), ("height", ctypes.c_int), ("ngf", ctypes.c_int), ("ndf", ctypes.c_int),
               ("dtype", ctypes.c_int), ("training", ctypes.c_int), ("l1_weight", ctypes.c_float),
-              ("gan_weight", ctypes.c_float), ("per_sample_bn", ctypes.c_int)]
+              ("gan_weight", ctypes.c_float), ("per_sample_bn", ctypes.c_int),
+              # schedule of a training plan (0 = default; include/vp_hip.h)
+              ("streams", ctypes.c_int), ("d_backward_fork", ctypes.c_int), ("d_beside_vgg", ctypes.c_int)]
 
 
 class ConvDesc(ctypes.Structure):

@@ -59,7 +59,7 @@ def regularised(name):
 
 
 class BFMNetTrainEngine:
-  def __init__(self, batch, frames, model, lr=1e-4, max_grad_norm=50.0, num_mel_bins=80):
+  def __init__(self, batch, frames, model, lr=1e-4, max_grad_norm=50.0, num_mel_bins=80, side_stream=True):
     """model: dict with exBase [3n,64] and vmask [3n] (the mouth-weighted vertex mask of bfmnet.py:131-134); idBase / meanshape cancel in
     every term of the loss (both face shapes share the identity coefficients) and are not needed on the device."""
     if not torch.cuda.is_available():
@@ -106,8 +106,8 @@ class BFMNetTrainEngine:
     self._gdpad = None
     self._pk, self._pk_pending, self._pk_ready, self._pk_arena, self._packed = {}, {}, False, (None, 0), None
     self._graphs = {}
-    # weight gradients (1x1 / depthwise / dense / GRU) run on a second stream beside the data-gradient chain (VP_F4_NO_SIDE=1: one stream)
-    self._side = None if os.environ.get("VP_F4_NO_SIDE") else torch.cuda.Stream()
+    # weight gradients (1x1 / depthwise / dense / GRU) run on a second stream beside the data-gradient chain (side_stream=False: one stream)
+    self._side = torch.cuda.Stream() if side_stream else None
     self._hold, self._mmkey = [], "mm"
 
   # ---- parameters -----------------------------------------------------------------------------------------------------------

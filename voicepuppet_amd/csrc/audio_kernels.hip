@@ -340,13 +340,12 @@ hipError_t launch_dwconv7x3(const void* x, const float* w, const float* bias, vo
   const int hs = (H + nseg - 1) / nseg;
   nseg = (H + hs - 1) / hs;
   const dim3 grid(nblk(cols * nseg, 8192));
-  static const bool f32x2 = !getenv("VP_DW_F32X4");
   if (is_bf16) hipLaunchKernelGGL((dwconv7x3_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, w, bias, (bf16*)y, B, H, W, C, hs, nseg, rev);
-  else if (f32x2) {
+  else {
     // column pairs x channel pairs: as many threads as the float4 form has for even W
     const size_t th = (size_t)B * nseg * ((W + 1) / 2) * (C / 2);
     hipLaunchKernelGGL(dwconv7x3_f32_kernel, dim3(nblk(th, 16384)), dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C, hs, nseg, rev);
-  } else hipLaunchKernelGGL((dwconv7x3_kernel<float>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)y, B, H, W, C, hs, nseg, rev);
+  }
   return hipGetLastError();
 }
 hipError_t launch_maxpool_same(const void* x, void* y, int in_bf16, int out_bf16, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo, hipStream_t st) {

@@ -1708,19 +1708,17 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   const size_t smem_epi = (size_t)(BP / NPASS) * (BC * 4 + 16) + (BP / NPASS) * 8;
   if (smem_epi > smem) smem = smem_epi;
   const bool plain = a.zeros && !a.x.aff_a[0] && !a.x.aff_a[1] && a.x.act == ACT_NONE;
-  static const int dbg = getenv("VP_DBG") ? atoi(getenv("VP_DBG")) : 0;
   if (plain) {
     IgemmArgs b = a;
-    b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0 && !(dbg & 4)) ? 1 : 0;
+    b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0) ? 1 : 0;
     // register-direct epilogue: measured SLOWER than the LDS-staged one (64-byte store segments vs 256-byte rows): opt-in
     // scalar-stepped loader: every 64-byte K chunk inside one tap and one source tensor, sources below the 2 GiB lane-offset range
     constexpr int KCE = 16 * 4 / (int)sizeof(T);
     const size_t xb0 = (size_t)a.N * a.Hin * a.Win * a.x.C[0] * sizeof(T), xb1 = (size_t)a.N * a.Hin * a.Win * a.x.C[1] * sizeof(T);
-    static const bool fast_on = !getenv("VP_NO_FASTK");
-    b.fastk = (fast_on && a.Cin % KCE == 0 && a.x.C[0] % KCE == 0 && a.x.C[1] % KCE == 0 && a.x.C[0] + a.x.C[1] == a.Cin &&
+    b.fastk = (a.Cin % KCE == 0 && a.x.C[0] % KCE == 0 && a.x.C[1] % KCE == 0 && a.x.C[0] + a.x.C[1] == a.Cin &&
                xb0 < 0x70000000ull && xb1 < 0x70000000ull) ? 1 : 0;
     // wave-specialised kernel, per tile shape (bit = launch_igemm cfg index): measured gains for 128x128 (cfg 0), 64x128 (cfg 1), 256x256 (cfg 7); 128x256 is faster without
-    static const int ws_cfgs = getenv("VP_WS_CFG") ? atoi(getenv("VP_WS_CFG")) : ((1 << 0) | (1 << 1) | (1 << 7));
+    constexpr int ws_cfgs = (1 << 0) | (1 << 1) | (1 << 7);
     constexpr int my_cfg = (BC == 128 && BP == 128) ? 0 : (BC == 64 && BP == 128) ? 1 : (BC == 128 && BP == 256) ? 6 : (BC == 256 && BP == 256) ? 7 :
                            (BC == 64 && BP == 256) ? 8 : (BC == 128 && BP == 512) ? 9 : 31;
     if constexpr (((BC + BP) / 16) % 4 == 0 && NW <= 8) {
@@ -1789,10 +1787,9 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   }
   if constexpr (sizeof(T) == 2) {
     // 3x3 stride-1 conv from 64 to <= 8 channels (conv1_1 backward-data): halo tile staged once (conv3x3_cout8_tile_kernel)
-    static const bool co8_on = !getenv("VP_NO_COUT8");
     bool near = a.ntaps == 9;
     for (int t = 0; near && t < 9; ++t) near = a.taps[0].dh[t] >= -1 && a.taps[0].dh[t] <= 1 && a.taps[0].dw[t] >= -1 && a.taps[0].dw[t] <= 1;
-    if (co8_on && near && a.zeros && a.nclass == 1 && a.sh == 1 && a.sw == 1 && a.os == 1 && a.Cin == 64 && a.x.C[0] == 64 && a.x.C[1] == 0 &&
+    if (near && a.zeros && a.nclass == 1 && a.sh == 1 && a.sw == 1 && a.os == 1 && a.Cin == 64 && a.x.C[0] == 64 && a.x.C[1] == 0 &&
         a.CoutPad == 16 && a.Cout <= 8 && a.ldY == 8 && a.splitk == 1 && !a.rowperm && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
         (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0 && a.Wg >= 16 && a.Hg >= 4 && a.Hof == a.Hg && a.Wof == a.Wg && a.Hin == a.Hg &&
         a.Win == a.Wg && !a.y_f32 && (size_t)a.N * a.Hin * a.Win * 64 * 2 < 0x70000000ull) {
@@ -1809,8 +1806,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   }
   if constexpr (sizeof(T) == 2) {
     // 4x4 stride-2 transposed conv from 64 to <= 8 channels (layer_1 backward-data): deconv_cout8_tile_kernel
-    static const bool dco8_on = !getenv("VP_NO_DCOUT8");
-    if (dco8_on && a.zeros && a.nclass == 4 && a.os == 2 && a.ntaps == 4 && a.Cin == 64 && a.x.C[0] == 64 && a.x.C[1] == 0 && a.CoutPad == 16 && a.Cout <= 8 &&
+    if (a.zeros && a.nclass == 4 && a.os == 2 && a.ntaps == 4 && a.Cin == 64 && a.x.C[0] == 64 && a.x.C[1] == 0 && a.CoutPad == 16 && a.Cout <= 8 &&
         a.ldY == 8 && !a.y_f32 && a.splitk == 1 && !a.rowperm && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE && (a.Wg & (a.Wg - 1)) == 0 &&
         (a.Hg & (a.Hg - 1)) == 0 && a.Wg >= 16 && a.Hg >= 4 && a.Hof == 2 * a.Hg && a.Wof == 2 * a.Wg && a.Hin == a.Hg && a.Win == a.Wg &&
         (size_t)a.N * a.Hin * a.Win * 64 * 2 < 0x70000000ull) {
@@ -1829,10 +1825,9 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   }
   if constexpr (sizeof(T) == 2) {
     // 4-channel f32 transposed conv (decoder_1): the four parity classes x four channels as one MFMA tile (deconv_cout4_kernel)
-    static const bool co4_on = !getenv("VP_NO_COUT4");
     const bool pow2 = (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0;
     const int spt = a.Cin / 32;
-    if (co4_on && a.zeros && a.nclass == 4 && a.os == 2 && a.ntaps == 4 && a.Cout == 4 && a.y_f32 && a.ldY == 4 && a.splitk == 1 && pow2 &&
+    if (a.zeros && a.nclass == 4 && a.os == 2 && a.ntaps == 4 && a.Cout == 4 && a.y_f32 && a.ldY == 4 && a.splitk == 1 && pow2 &&
         a.Cin % 32 == 0 && (spt == 2 || spt == 4) && a.x.C[0] % 32 == 0 && a.x.C[0] + a.x.C[1] == a.Cin && !a.ref && !a.accumulate &&
         a.out_act == ACT_NONE && !a.x.aff_a[0] && !a.x.aff_a[1] && a.x.act == ACT_NONE && a.Hof == 2 * a.Hg && a.Wof == 2 * a.Wg &&
         (size_t)a.N * a.Hin * a.Win * a.Cin * 2 < 0x70000000ull) {
@@ -1845,8 +1840,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       while ((1 << lgW) < a.Wg) ++lgW;
       while ((1 << lgH) < a.Hg) ++lgH;
       const size_t sm = (size_t)9 * spt * 64 * 16;
-      static const bool tile_on = !getenv("VP_NO_COUT4_TILE");
-      if (tile_on && lgW >= 4 && lgH >= 2) {                        // 4 x 16 base-pixel tiles with the halo staged once in LDS
+      if (lgW >= 4 && lgH >= 2) {                        // 4 x 16 base-pixel tiles with the halo staged once in LDS
         const size_t smt = sm + (size_t)6 * 18 * (a.Cin * 2 + 16);
         int tblocks = a.N << (lgW - 4 + lgH - 2);
         if (tblocks > 2048) tblocks = 2048;
@@ -1902,7 +1896,6 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     case 5: e = launch_igemm_cfg<T, 2, 2, 2, 1>(a, st); break;   //  64 ch x  32 px
     case 6: e = launch_igemm_cfg<T, 2, 4, 4, 4>(a, st); break;   // 128 ch x 256 px, 8 waves
     case 7: e = launch_igemm_cfg<T, 2, 4, 8, 4>(a, st); break;   // 256 ch x 256 px, 8 waves
-    case 8: e = launch_igemm_cfg<T, 1, 4, 4, 4>(a, st); break;   //  64 ch x 256 px, 4 waves
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

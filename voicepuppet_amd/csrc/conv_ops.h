@@ -31,19 +31,11 @@ inline int kc_elems(int is_bf16) { return is_bf16 ? 32 : 16; }
 
 // tile choice for an igemm producing `rows` channels over P pixels
 inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
-  static const int big = getenv("VP_BIGTILE") ? atoi(getenv("VP_BIGTILE")) : 3;   // bit 0: 128x256, bit 1: 256x256 (8-wave tiles)
-  static const int force = getenv("VP_FORCE_CFG") ? atoi(getenv("VP_FORCE_CFG")) : -1;   // experiments only
-  if (force >= 0 && P >= 96) {
-    int bc, bp;
-    igemm_tile(force, &bc, &bp);
-    if (rows % bc == 0) return force;
-  }
   if (P >= 96) {
-    // 256x256 runs one block per CU: its prologue / epilogue are exposed, only long K loops amortise them
-    if ((big & 2) && rows % 256 == 0 && P >= 256 * 256 && Kpad >= 4096) return 7;
-    if ((big & 1) && rows % 128 == 0 && P >= 256 * 512) return 6;
+    // 256x256 (8-wave tile) runs one block per CU: its prologue / epilogue are exposed, only long K loops amortise them
+    if (rows % 256 == 0 && P >= 256 * 256 && Kpad >= 4096) return 7;
+    if (rows % 128 == 0 && P >= 256 * 512) return 6;           // 128x256, 8 waves
     if (rows % 128 == 0) return 0;
-    if ((big & 4) && rows % 64 == 0 && P >= 256 * 512) return 8;
     if (rows % 64 == 0) return 1;
     if (rows <= 16) return 2;
     return rows > 64 ? 0 : 1;
@@ -55,9 +47,9 @@ inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
 inline int pick_igemm_splitk(int blocks, int nchunk) {
   // round-2 sweep (scripts/ab.sh with VP_SPLITK_TARGET / _MAX / _MINCHUNK): target 128 / cap 8 / at least 4 chunks per split: 8.79 vs 8.97 ms at batch 32, 2.84 vs 3.00 ms at
   // batch 4 against the round-1 setting 512 / 32 / 2 - the slab reduce and the short blocks cost more than the idle CUs
-  static const int target = getenv("VP_SPLITK_TARGET") ? atoi(getenv("VP_SPLITK_TARGET")) : 128;   // resident blocks aimed at
-  static const int cap = getenv("VP_SPLITK_MAX") ? atoi(getenv("VP_SPLITK_MAX")) : 8;
-  static const int minchunk = getenv("VP_SPLITK_MINCHUNK") ? atoi(getenv("VP_SPLITK_MINCHUNK")) : 4;   // K chunks per split at least
+  constexpr int target = 128;      // resident blocks aimed at
+  constexpr int cap = 8;
+  constexpr int minchunk = 4;      // K chunks per split at least
   if (blocks >= 256) return 1;
   int s = (target + blocks - 1) / blocks;
   if (s > nchunk / minchunk) s = nchunk / minchunk;
@@ -90,7 +82,7 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   // float32 matrix products (one tap: BFMNet's 1x1 convolutions, the DFT): a 128x128 block is 4x the MFMA time of a bf16 one, so a grid
   // of 257-511 blocks costs two full rounds of the 256 CUs.  64x128 tiles (two resident per CU, half the time each) quantise finer:
   // rounds x rows 3 x 64 against 2 x 128 for 300 blocks (scripts/mm_bench.py: 19200 x 1152 x 256 forward 140 -> 109 us)
-  if (!is_bf16 && a.ntaps == 1 && p.cfg == 0 && !getenv("VP_NO_F32_TILE_RULE")) {
+  if (!is_bf16 && a.ntaps == 1 && p.cfg == 0) {
     const long long b128 = (long long)((P + 127) / 128) * (rows / 128), b64 = 2 * b128;
     if (((b64 + 255) / 256) * 64 < ((b128 + 255) / 256) * 128) p.cfg = 1;
   }
@@ -104,9 +96,8 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
   p.partial_bytes = a.splitk > 1 ? (size_t)a.nclass * a.splitk * P * a.CoutPad * sizeof(float) : 0;
   // row permutation inside 64-row blocks (IgemmArgs::rowperm) where the tile's waves own whole 64-row blocks
   {
-    static const bool perm_on = !getenv("VP_NO_ROWPERM");
     const bool tc4 = p.cfg == 0 || p.cfg == 1 || p.cfg == 6 || p.cfg == 7 || p.cfg == 8 || p.cfg == 9;
-    a.rowperm = (perm_on && tc4 && rows % 64 == 0) ? 1 : 0;
+    a.rowperm = (tc4 && rows % 64 == 0) ? 1 : 0;
     p.pack.perm = a.rowperm;
   }
   // packed rows are padded to the largest channel tile so the tile choice may vary with the batch
@@ -121,13 +112,13 @@ inline void finish_igemm(IgemmPlan& p, int rows, int is_bf16) {
 // weights are stored with PackDesc::kswap.  single_src: the layer reads one tensor (no virtual concat).
 // tuning knobs that tests and experiments may change at run time (vp_tune): which patch tiles are allowed (bit 0: 256-row, bit 1:
 // 128-row, bit 2: 64-row) and the smallest grid worth one 8-wave block per CU
-inline int& patch_tiles_knob() { static int v = getenv("VP_PATCH2") ? atoi(getenv("VP_PATCH2")) : 7; return v; }
-inline int& patch_small_knob() { static int v = getenv("VP_PATCH2_SMALL") ? atoi(getenv("VP_PATCH2_SMALL")) : 3; return v; }   // two-blocks-per-CU tiles (see patch_tile_pixels)
-inline int& patch_longk_knob() { static int v = getenv("VP_PATCH2_LONGK") ? atoi(getenv("VP_PATCH2_LONGK")) : 1; return v; }      // 1: long-K 512-row layers stay on the 256x256 tile
-inline int& patch3_knob() { static int v = getenv("VP_NO_PATCH3") ? 0 : 1; return v; }   // 3x3 layers on the unrolled patch kernel (conv_patch3.hip)
+inline int& patch_tiles_knob() { static int v = 7; return v; }
+inline int& patch_small_knob() { static int v = 3; return v; }   // two-blocks-per-CU tiles (see patch_tile_pixels)
+inline int& patch_longk_knob() { static int v = 1; return v; }      // 1: long-K 512-row layers stay on the 256x256 tile
+inline int& patch3_knob() { static int v = 1; return v; }   // 3x3 layers on the unrolled patch kernel (conv_patch3.hip)
 inline int& c64_knob() { static int v = 1; return v; }   // 64 -> 64 channel 3x3 layers on the register-resident-weights kernel (conv_c64.hip)
 inline int& dc64_knob() { static int v = 1; return v; }  // 128 -> 64 channel transposed-conv classes on conv_dc64.hip
-inline int& patch_minblk_knob() { static int v = getenv("VP_PATCH2_MINBLK") ? atoi(getenv("VP_PATCH2_MINBLK")) : 384; return v; }
+inline int& patch_minblk_knob() { static int v = 384; return v; }
 
 // pixel tile of a patch-kernel plan: bp = 512 -> 16 x 32, 256 -> 16 x 16, 128 -> 8 x 16
 inline void patch_tile_hw(int bp, int* th, int* tw) { *th = bp == 128 ? 8 : 16; *tw = bp == 512 ? 32 : 16; }
@@ -195,8 +186,8 @@ inline void plan_make_patch(IgemmPlan& p, int rows, int is_bf16) {
 
 // The four parity classes of a 4x4 stride-2 transposed conv (deconv forward, conv backward-data) on the unrolled 2x2-tap patch
 // kernel (conv_patch2.hip).  c0 / c1: channels of the one or two source tensors of the GEMM's pixel operand.
-inline int& patch_xcd_knob() { static int v = getenv("VP_PATCH_XCD") ? atoi(getenv("VP_PATCH_XCD")) : 0; return v; }
-inline int& patch2_knob() { static int v = getenv("VP_NO_PATCH2") ? 0 : 1; return v; }
+inline int& patch_xcd_knob() { static int v = 0; return v; }
+inline int& patch2_knob() { static int v = 1; return v; }
 inline bool plan_patch2_eligible(const IgemmPlan& p, int rows, int is_bf16, int c0, int c1) {
   const IgemmArgs& a = p.a;
   const int kc = kc_elems(is_bf16);
@@ -228,7 +219,7 @@ inline void plan_make_patch2(IgemmPlan& p, int rows, int is_bf16) {
 // Few-pixel kernel (conv_smallp.hip): layers whose pixel count per parity class is so small that the layer is a stream of weights
 // (the generator's 1x1 .. 16x16 bottleneck).  A plan-time decision: the packed rows are not permuted, the slab / counter sizes differ.
 // c0 / c1: channels of the one or two source tensors.
-inline int& smallp_knob() { static int v = getenv("VP_SMALLP") ? atoi(getenv("VP_SMALLP")) : 256; return v; }   // largest pixel count per class (0: off)
+inline int& smallp_knob() { static int v = 256; return v; }   // largest pixel count per class (0: off)
 inline bool plan_smallp_eligible(const IgemmPlan& p, int rows, int is_bf16, int c0, int c1) {
   const IgemmArgs& a = p.a;
   const int kc = kc_elems(is_bf16);
@@ -272,7 +263,7 @@ inline void plan_make_smallp(IgemmPlan& p, int rows, int is_bf16) {
   // K splits over blocks: aim at >= 384 blocks, keep >= 2 chunks per wave (4 waves per block share a block's K range)
   const int PT = a.sp_npt * 16;
   const int tiles = (a.CoutPad / 32) * a.nclass * ((Pc + PT - 1) / PT);
-  static const int target = getenv("VP_SMALLP_BLOCKS") ? atoi(getenv("VP_SMALLP_BLOCKS")) : 384;
+  constexpr int target = 384;
   int s = (target + tiles - 1) / tiles;
   if (s > minchunks / 8) s = minchunks / 8;
   if (s > 64) s = 64;
@@ -377,7 +368,7 @@ struct WgradPlan {
   size_t partial_bytes;
 };
 
-inline int& wgrad_tr_knob() { static int v = getenv("VP_WGRAD_TR") ? atoi(getenv("VP_WGRAD_TR")) : 3; return v; }   // LDS-DMA + transpose-read weight gradient (wgrad_tr.hip)
+inline int& wgrad_tr_knob() { static int v = 3; return v; }   // LDS-DMA + transpose-read weight gradient (wgrad_tr.hip)
 
 // plain_operands: both tensors are read as stored (no deferred affine / activation): required by the LDS-DMA kernel
 inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands = true) {
@@ -400,16 +391,7 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
   a.gc_mask = a.Gc - 1;
   if (a.ntaps == 1) { a.log2Gc = 30; a.gc_mask = 0x3fffffff; }   // 1x1: rows are channels, any count (BFMNet's 192 .. 1536-wide layers)
   p.cfg = (a.Dc % 128 == 0) ? 0 : (a.Dc % 64 == 0 ? 1 : 2);
-  {
-    // 256-row tiles (half the operand bytes per MAC; one 8-wave block per CU) where the M and N extents allow; bf16 only
-    static const int big = getenv("VP_WGBIG") ? atoi(getenv("VP_WGBIG")) : 0;   // opt-in: measured no faster (one 240-register block per CU)
-    const int M = a.ntaps * a.Gc;
-    const long long Pall = (long long)a.N * a.Hb * a.Wb;
-    if (is_bf16 && M % 256 == 0 && Pall >= 8192) {
-      if ((big & 1) && a.Dc % 256 == 0) p.cfg = 3;
-      else if ((big & 2) && a.Dc % 128 == 0) p.cfg = 4;
-    }
-  }
+  // (256-row 8-wave tiles for the register-transposing kernel measured no faster - one 240-register block per CU, EXPERIMENTS.md 3)
   a.lw = ilog2(a.Wb); a.lh = ilog2(a.Hb);
   const bool tr = is_bf16 && plain_operands && (wgrad_tr_knob() & 1) && (a.ntaps * a.Gc) % 256 == 0 && a.Dc % 128 == 0 &&
                   (((long long)a.N << (a.lw + a.lh)) % 32) == 0;
@@ -424,16 +406,14 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
   a.Dpad = round_up(a.Dc, bn);
   const int kiter = (tr || tr_thin) ? 32 : kc_elems(is_bf16) * (is_bf16 ? 2 : 1);     // pixels per loop iteration of the kernel
   // padded-grid K walk: rows of 2^lw slots, at least one 16-byte pixel group and at most one iteration long
-  static const bool fastw_on = !getenv("VP_NO_FASTW");
-  a.fastw = (fastw_on && !tr && !tr_thin && (1 << a.lw) >= (is_bf16 ? 8 : 4) && (1 << a.lw) <= kiter) ? 1 : 0;
+  a.fastw = (!tr && !tr_thin && (1 << a.lw) >= (is_bf16 ? 8 : 4) && (1 << a.lw) <= kiter) ? 1 : 0;
   const int P = (a.fastw || tr || tr_thin) ? (a.N << (a.lw + a.lh)) : a.N * a.Hb * a.Wb;
   const int nchunk = (P + kiter - 1) / kiter;
   const int tiles = (a.Mpad / bm) * (a.Dpad / bn);
   // K split: minimise (rounds of the ~512 resident blocks) x (iterations per block + fixed per-block cost),
   // plus a small penalty per slab for the reduce pass
   int s = 1;
-  static const double wg_fixed = getenv("VP_WG_FIXED") ? atof(getenv("VP_WG_FIXED")) : 8.0;
-  static const double wg_slab = getenv("VP_WG_SLAB") ? atof(getenv("VP_WG_SLAB")) : 0.15;
+  constexpr double wg_fixed = 8.0, wg_slab = 0.15;
   {
     const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
     double best = 1e30;

@@ -252,12 +252,11 @@ hipError_t launch_igemm_patch3(const IgemmArgs& a, int is_bf16, int bc, int bp, 
   (is_bf16 ? launch_patch3_t<bf16, WC, WP, TC, TP, TH, TW, OCC>(b, st) : launch_patch3_t<float, WC, WP, TC, TP, TH, TW, OCC>(b, st))
 #define VP_PATCH3_GO6(WC, WP, TC, TP, TH, TW, OCC) \
   (is_bf16 ? launch_patch3_t<bf16, WC, WP, TC, TP, TH, TW, OCC, 6>(b, st) : launch_patch3_t<float, WC, WP, TC, TP, TH, TW, OCC, 6>(b, st))
-  // 64-row tiles of 16 x 16 pixels: six weight stages (73 KB of LDS, still two blocks per CU); VP_PATCH3_RING=3: the three-stage form
-  static const int ring = getenv("VP_PATCH3_RING") ? atoi(getenv("VP_PATCH3_RING")) : 6;
+  // 64-row tiles of 16 x 16 pixels: six weight stages (73 KB of LDS, still two blocks per CU; the three-stage form: EXPERIMENTS.md 6 (5))
   if (bc == 256) return bp == 128 ? VP_PATCH3_GO(2, 4, 8, 2, 8, 16, 4) : VP_PATCH3_GO(2, 4, 8, 4, 16, 16, 2);
   if (bc == 128) return bp == 512 ? VP_PATCH3_GO(1, 8, 8, 4, 16, 32, 2) : VP_PATCH3_GO(2, 4, 4, 4, 16, 16, 4);
   if (bp == 512) return VP_PATCH3_GO(1, 8, 4, 4, 16, 32, 2);
-  return ring == 6 ? VP_PATCH3_GO6(2, 4, 2, 4, 16, 16, 4) : VP_PATCH3_GO(2, 4, 2, 4, 16, 16, 4);
+  return VP_PATCH3_GO6(2, 4, 2, 4, 16, 16, 4);
 #undef VP_PATCH3_GO6
 #undef VP_PATCH3_GO
 }

@@ -54,9 +54,6 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
   return VP_OK;
 }
 
-extern "C" void vp_overlap_enable(int on);   // plan_pixrefer.hip
-extern "C" void vp_dfork_point(int p);       // plan_pixrefer.hip
-extern "C" void vp_dsplit_enable(int on);    // plan_pixrefer.hip
 extern "C" void vp_phase_marks_enable(int on);   // plan_pixrefer.hip
 
 int vp_tune(const char* key, int value) {
@@ -66,9 +63,6 @@ int vp_tune(const char* key, int value) {
   if (k == "patch_min_blocks") { patch_minblk_knob() = value; return VP_OK; }
   if (k == "patch_small_tiles") { patch_small_knob() = value; return VP_OK; }
   if (k == "patch_long_k_on_256") { patch_longk_knob() = value; return VP_OK; }
-  if (k == "overlap") { vp_overlap_enable(value); return VP_OK; }
-  if (k == "d_backward_fork") { vp_dfork_point(value); return VP_OK; }
-  if (k == "d_beside_vgg") { vp_dsplit_enable(value); return VP_OK; }
   if (k == "wgrad_tr") { wgrad_tr_knob() = value; return VP_OK; }
   if (k == "patch3") { patch3_knob() = value; return VP_OK; }
   if (k == "c64") { c64_knob() = value; return VP_OK; }

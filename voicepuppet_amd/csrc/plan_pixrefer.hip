@@ -149,7 +149,7 @@ struct vp_pixrefer {
   double* bn_partial4;
   hipStream_t side, branch;
   hipStream_t branch2;             // backward: the foreground encoder chain, so that it does not queue behind the weight-gradient backlog of `branch`
-                                   // (== branch when VP_NO_FG_STREAM is set: a data-parallel host that brings streams of its own may want three)
+                                   // (== branch with vp_pixrefer_desc::streams = 3 / vp_pixrefer_use_streams(h, 3): a host that brings streams of its own wants three)
   hipEvent_t ev_b2join;
   bool use_b2;                     // vp_pixrefer_use_streams: false = the backward pass keeps to three streams (the host runs a stream of its own)
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
@@ -297,10 +297,9 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
     n.descs.push_back(p.pack);
     if (p.partial_bytes > *scratch_max) *scratch_max = p.partial_bytes;
   };
-  static const bool tap_on = !getenv("VP_NO_TAPGEMM");
   for (Layer& L : n.l) {
     L.desc0 = n.descs.size();
-    L.tapgemm = tap_on && training && L.g.kind == 0 && L.g.stride == 1 && L.g.ks == 4 && L.g.Cout == 1 && L.nsrc == 1 && !L.has_bn &&
+    L.tapgemm = training && L.g.kind == 0 && L.g.stride == 1 && L.g.ks == 4 && L.g.Cout == 1 && L.nsrc == 1 && !L.has_bn &&
                 L.g.Cin == L.g.Cin_real;
     if (L.tapgemm) {
       // S = x . W^T as a 1x1 conv with 16 output channels: row t of the packed matrix is W[kh,kw,:,0] (HWIO, Cout = 1)
@@ -383,9 +382,8 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       row0 += rows;
     }
     {
-      static const bool pair_on = !getenv("VP_NO_BWD_PAIR");
       const int c0 = n.t[L.src[0]].C, c1 = L.nsrc > 1 ? n.t[L.src[1]].C : 0;
-      if (pair_on && L.nsrc == 2 && n.groups == 1 && alt_batch == 0 && L.need_bwd[0] && L.need_bwd[1] && c0 == c1 && !n.t[L.src[0]].is_input &&
+      if (L.nsrc == 2 && n.groups == 1 && alt_batch == 0 && L.need_bwd[0] && L.need_bwd[1] && c0 == c1 && !n.t[L.src[0]].is_input &&
           !n.t[L.src[1]].is_input && L.bwd[0].a.patch == L.bwd[1].a.patch && (L.bwd[0].a.patch == 0 || L.bwd[0].a.patch == 3) &&
           L.g.Cin_real == c0 + c1) {
         L.bwd_pair = plan_bwd_data(L.g, L.w_off, 0, c0 + c1, c0 + c1, c0, bf16);
@@ -415,8 +413,7 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
   }
   n.packed_elems = pk;
   {
-    static const bool hi_on = !getenv("VP_NO_F32_FEWPIXEL");
-    for (Tens& t : n.t) t.hi = hi_on && bf16 && t.has_bn && n.groups == 1 && alt_batch == 0 && t.producer >= 0 && n.l[t.producer].fwd.a.patch == 3;
+    for (Tens& t : n.t) t.hi = bf16 && t.has_bn && n.groups == 1 && alt_batch == 0 && t.producer >= 0 && n.l[t.producer].fwd.a.patch == 3;
     if (training)
       for (Layer& L : n.l)
         for (int s = 0; s < L.nsrc; ++s)
@@ -555,6 +552,11 @@ static bool valid_desc(const vp_pixrefer_desc* d) {
   if (d->ngf > 64 || d->ndf > 64) { set_err("pixrefer descriptor: ngf %d / ndf %d > 64 exceed the batch-norm workspace (512 channels)", d->ngf, d->ndf); return false; }
   if (!d->training && d->per_sample_bn && d->batch > 1024) { set_err("pixrefer descriptor: per-sample batch-norm supports at most 1024 frames per call (got %d)", d->batch); return false; }
   if (d->dtype != VP_F32 && d->dtype != VP_BF16) { set_err("pixrefer descriptor: dtype %d", d->dtype); return false; }
+  if ((d->streams != 0 && d->streams != 1 && d->streams != 3 && d->streams != 4) || d->d_backward_fork < 0 || d->d_backward_fork > 3 || d->d_beside_vgg < 0 ||
+      d->d_beside_vgg > 2) {
+    set_err("pixrefer descriptor: schedule fields streams %d / d_backward_fork %d / d_beside_vgg %d", d->streams, d->d_backward_fork, d->d_beside_vgg);
+    return false;
+  }
   return true;
 }
 
@@ -676,8 +678,7 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
   // batch statistics from the conv epilogue (no re-read of the output) when every pixel tile lies inside one BN group
   bool fused_stats = false;
   int stat_chunks = 0;
-  static const bool fuse_on = !getenv("VP_NO_BNFUSE");
-  if (fuse_on && L.has_bn && a.splitk == 1 && L.g.Cout % 8 == 0 && a.ldY % 8 == 0 && !a.y_f32) {
+  if (L.has_bn && a.splitk == 1 && L.g.Cout % 8 == 0 && a.ldY % 8 == 0 && !a.y_f32) {
     int bc, bp;
     igemm_tile(L.fwd.cfg, &bc, &bp);
     const int pg = (n.batch / n.groups) * a.Hg * a.Wg;            // pixels of one group, per class
@@ -693,8 +694,6 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
       }
     }
   }
-  static const bool dbg_stats = getenv("VP_DBG_STATS") != nullptr;
-  if (dbg_stats && L.has_bn) fprintf(stderr, "[stats] %s fused=%d splitk=%d cfg=%d nclass=%d groups=%d\n", L.scope.c_str(), (int)fused_stats, a.splitk, L.fwd.cfg, a.nclass, n.groups);
   // first layers (8-channel image inputs, no batch-norm: encoder_1, encoder_fg_1, discriminator layer_1): the direct kernel's epilogue
   // writes the consumers' activations itself - no act_apply pass over the (67 .. 201 MB) output
   bool acts_fused = false;
@@ -868,10 +867,9 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       sp.g = a;
       for (int c = 0; c < 4; ++c) sp.tap_mask[c] = a.sp_mask[c];
       sp.slab = a.partial; sp.cnt = a.sp_cnt; sp.part = bn_partial;
-      static const bool fuse_bn = !getenv("VP_SMALLP_NO_BNBWD");
       const bool last = !ts.is_input && !gpass && ts.has_bn && ts.producer >= 0 && ts.dz_writes == ts.n_bwd_consumers && n.groups == 1;
       if (ts.hi && !last && ts.dz_writes == ts.n_bwd_consumers) { set_err("%s: float32 tensor %s needs its batch-norm backward in the launch", L.scope.c_str(), ts.name.c_str()); return VP_ERR_STATE; }
-      if ((fuse_bn || ts.hi) && last) {
+      if (last) {
         const Layer& Lp = n.l[ts.producer];
         sp.mode = SP_BWD_BN;
         if (ts.hi) { sp.hi = 1; sp.dy_out = ts.dz; sp.g.y_f32 = 0; }      // dz32 / y in float32, dL/dy out as T into dz
@@ -950,17 +948,6 @@ int vp_pixrefer_phase_ms(vp_pixrefer_t* h, float* ms, int cap) {
   }
   return n;
 }
-// Schedule options are PER HANDLE (vp_pixrefer_set_option); the three vp_tune keys below only set the defaults a handle copies when it
-// is created, so an experiment can still say `bench.py --tune overlap=0` before any plan exists.
-static bool g_overlap_default = true;     // "overlap" 0 / 1: per-kernel timing (bench.py's profile pass) needs one stream
-void vp_overlap_enable(int on) { g_overlap_default = on != 0; }
-// where vp_pixrefer_backward starts the discriminator-loss pass on the side stream: 0 = at once, 1 = behind the generator-loss pass
-// through the discriminator, 2 = behind its pass through the VGG trunk as well (i.e. under the generator's own backward)
-static int g_dfork_default = 2;
-void vp_dfork_point(int p) { g_dfork_default = p < 0 ? 0 : (p > 2 ? 2 : p); }
-static bool g_dsplit_default = true;      // discriminator fwd / generator-loss bwd through it on the branch stream, beside the VGG passes
-void vp_dsplit_enable(int on) { g_dsplit_default = on != 0; }
-
 int vp_version(void) { return 100; }
 const char* vp_last_error(void) { return g_err; }
 
@@ -1122,8 +1109,9 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
   }
   VP_HIP_CHECK(hipStreamSynchronize(st));   // descs are host vectors owned by the handle; copy is complete
   h->overlap = false; h->forked = false;
-  h->ov_on = g_overlap_default; h->dfork_point = g_dfork_default; h->dsplit_on = g_dsplit_default;
-  if (d->training && !getenv("VP_NO_OVERLAP")) {
+  // the schedule of this plan (vp_pixrefer_desc; vp_pixrefer_set_option changes it later)
+  h->ov_on = true; h->dfork_point = d->d_backward_fork ? d->d_backward_fork - 1 : 2; h->dsplit_on = d->d_beside_vgg != 1;
+  if (d->training && d->streams != 1) {
     // lowest priority: the side stream only fills the CUs the main stream's (longer, critical-path) passes leave idle
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -1134,7 +1122,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
     // the fourth stream is created on first use (the backward pass of a handle that still wants four streams): hardware queues are
     // handed out as streams are created, and a host stream created later (an input prefetcher's) must not be pushed onto a shared one
     h->branch2 = nullptr;
-    h->use_b2 = !getenv("VP_NO_FG_STREAM");
+    h->use_b2 = d->streams != 3;
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_b2join, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bfork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bjoin, hipEventDisableTiming));
@@ -1217,8 +1205,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
       const bool pooled = L.scope == "conv1/conv1_2" || L.scope == "conv2/conv2_2";
       const bool fuse = pooled && plan_can_pool(L.fwd_half);
       // the real half has no backward pass: of conv1_2 / conv2_2 only the pooled image is ever read, the full-resolution store is skipped
-      static const bool pool_only = !getenv("VP_NO_POOL_ONLY");
-      if ((rc = run_layer_fwd_half(h, Vs, L, 0, h->side, fuse ? Vs.t[L.out + 1].y : nullptr, pool_only))) return rc;
+      if ((rc = run_layer_fwd_half(h, Vs, L, 0, h->side, fuse ? Vs.t[L.out + 1].y : nullptr, true))) return rc;
       if (pooled && !fuse) {
         const Tens& ti = Vs.t[L.out];
         Tens& tp = Vs.t[L.out + 1];
@@ -1465,7 +1452,7 @@ void* vp_pixrefer_side_stream(vp_pixrefer_t* h) { return (h && h->overlap) ? (vo
 // PCIe-fed step 8.5 -> 11.4 ms with five busy streams).  Takes effect from the next backward pass.
 int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n) {
   if (!h || (n != 3 && n != 4)) { set_err("vp_pixrefer_use_streams: 3 or 4"); return VP_ERR_ARG; }
-  h->use_b2 = (n == 4) && h->overlap && !getenv("VP_NO_FG_STREAM");
+  h->use_b2 = (n == 4) && h->overlap;
   return VP_OK;
 }
 
@@ -1610,7 +1597,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   // (d) generator, last layer first.  Below merged_encoder_2 the two encoder branches are independent again: the foreground
   // branch (encoder_fg_4 .. encoder_fg_1) runs on the branch stream, joined before this call returns control of `st`
   const bool split_enc = h->overlap && h->ov_on && l_lo == 0;
-  const bool wsplit = h->overlap && h->ov_on && !getenv("VP_NO_WSPLIT");
+  const bool wsplit = h->overlap && h->ov_on;
   bool forked = false, fg_forked = false;
   bool b2_used = false;            // something of this call runs on the second branch stream (joined wherever `branch` is)
   for (int i = l_hi; i >= l_lo; --i) {
@@ -1655,8 +1642,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
       const int l0 = i, l1 = i == i_md5 ? (int)G.l.size() - 1 : (i == i_me2 ? i_md5 - 1 : i_me2 - 1);
       const size_t off0 = G.l[l0].w_off, off1 = l1 + 1 < (int)G.l.size() ? G.l[l1 + 1].w_off : G.nparams;
       hipStream_t su = st;
-      static const bool upd_on_side = !getenv("VP_UPDATE_ON_BRANCH");
-      const bool on_side = upd_on_side && h->overlap && h->ov_on && h->dfork_pending == 0 && h->dfork_point >= 0;
+      const bool on_side = h->overlap && h->ov_on && h->dfork_pending == 0 && h->dfork_point >= 0;
       if (h->overlap && h->ov_on && on_side) {
         // the (HBM-bound) optimiser + re-pack of the bucket go to the SIDE stream, behind the discriminator-loss pass that runs there:
         // on the branch stream they sat between the weight gradients of the layers still to come and delayed the end of the step.

@@ -888,9 +888,7 @@ hipError_t launch_bn_stats(const BnArgs& a, int is_bf16, hipStream_t st) {
 }
 
 bool bn_small(const BnArgs& a) {
-  static const bool on = !getenv("VP_NO_BNSMALL");
-  static const int lim = getenv("VP_BNSMALL_PG") ? atoi(getenv("VP_BNSMALL_PG")) : 2048;
-  return on && a.Pg <= lim;
+  return a.Pg <= 2048;          // (4096 .. 16384 pixels per group measured slower: EXPERIMENTS.md 0.2)
 }
 
 hipError_t launch_bn_small_fwd(const BnArgs& a, void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st) {

@@ -230,10 +230,8 @@ static bool mm_plain(const WgradArgs& a) {
   return a.ntaps == 1 && a.s == 1 && a.taps.dh[0] == 0 && a.taps.dw[0] == 0 && !a.g.C[1] && !a.d.C[1] && a.Hgin == a.Hb && a.Wgin == a.Wb;
 }
 bool wgrad_mm_eligible(const WgradArgs& a, int cfg) {
-  static const int on = getenv("VP_WGRAD_MM") ? atoi(getenv("VP_WGRAD_MM")) : 3;      // bit 0: one-tap products, bit 1: convolutions with taps
   if (!mm_common(a, cfg)) return false;
-  if (mm_plain(a)) return (on & 1) != 0;
-  if (!(on & 2)) return false;
+  if (mm_plain(a)) return true;
   const int bn = cfg == 0 ? 128 : 64;
   // a 16-byte piece inside one tap, a 128-row tile inside one source: Gc a multiple of 4; with two sources the boundary on a tile edge
   if (a.ntaps > 1 && (a.Gc & (a.Gc - 1))) return false;            // rows decode as (m >> log2Gc, m & gc_mask)

@@ -287,15 +287,13 @@ static hipError_t launch_wgrad_tr_t(const WgradArgs& a, hipStream_t st, const ch
   const size_t smem = (size_t)NST * 32 * (BM / 8 + BN / 8) * 16;
   dim3 grid(a.Mpad / BM, a.Dpad / BN, a.splitk);
   WgradArgs b = a;
-  static const bool fast_on = !getenv("VP_NO_FAST_TR");
   const size_t gbytes = (size_t)a.N * a.Hgin * a.Wgin * (a.g.C[0] > a.g.C[1] ? a.g.C[0] : a.g.C[1]) * 2;
   const size_t dbytes = (size_t)a.N * a.Hb * a.Wb * (a.d.C[0] > a.d.C[1] ? a.d.C[0] : a.d.C[1]) * 2;
-  bool fast = fast_on && gbytes < 0x60000000ull && dbytes < 0x60000000ull && a.lw + a.lh >= 5;     // a 32-slot chunk stays inside one image
+  bool fast = gbytes < 0x60000000ull && dbytes < 0x60000000ull && a.lw + a.lh >= 5;     // a 32-slot chunk stays inside one image
   if (a.g.C[1] > 0) fast = fast && a.Gc >= BM && a.g.C[0] % BM == 0;                                // an operand tile never straddles a virtual concat
   if (a.d.C[1] > 0) fast = fast && a.d.C[0] % BN == 0;
   b.fast_tr = fast ? 1 : 0;
-  static const bool xcd_on = !getenv("VP_NO_XCD_REMAP");
-  b.xcd_remap = xcd_on ? 1 : 0;
+  b.xcd_remap = 1;
   const bool exact = fast && a.Hb == (1 << a.lh) && a.Wb == (1 << a.lw);
   if (variant) *variant = exact ? "tr_exact" : fast ? "tr_fast" : "tr";      // the template instance, for the profile's class names
   auto kern = exact ? wgrad_tr_kernel<WM, WN, TC, TP, NST, true, true> : fast ? wgrad_tr_kernel<WM, WN, TC, TP, NST, true> : wgrad_tr_kernel<WM, WN, TC, TP, NST, false>;

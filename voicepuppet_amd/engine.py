@@ -40,13 +40,14 @@ class PixReferEngine:
   """One replica of the PixReferNet graph (pixrefer.py:356-438) on the current device."""
 
   def __init__(self, batch, height, ngf=64, ndf=64, dtype="bf16", training=True, l1_weight=500.0, gan_weight=1.0,
-               device=None, per_sample_bn=False):
+               device=None, per_sample_bn=False, streams=0, d_backward_fork=0, d_beside_vgg=0):
     if not torch.cuda.is_available():
       raise RuntimeError("PixReferEngine needs an MI355X (no CPU fallback)")
     self.L = _lib.lib()
     self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
     self.desc = PixReferDesc(batch, height, ngf, ndf, VP_BF16 if dtype == "bf16" else VP_F32, 1 if training else 0,
-                             l1_weight, gan_weight, 1 if (per_sample_bn and not training) else 0)
+                             l1_weight, gan_weight, 1 if (per_sample_bn and not training) else 0,
+                             int(streams), int(d_backward_fork), int(d_beside_vgg))   # schedule fields: 0 = default (include/vp_hip.h)
     self.training = training
     self.compute_dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
     d = ctypes.byref(self.desc)
@@ -62,9 +63,10 @@ class PixReferEngine:
       self.adam = {"g": [z(counts[0]), z(counts[0])], "d": [z(counts[1]), z(counts[1])]}
     self.t_g = self.t_d = 0
     self._dp_streams_set = False
+    self.dp_own_stream = False           # data parallel: the collectives on a stream of the exchange's own instead of the executor's side stream (slower here: DESIGN.md 5)
     self.grad_transport = "f32"          # data parallel: 'bf16' halves the bytes of the gradient all-reduce (parallel.GradExchange)
     self._exchange = None
-    self.fused_update = not os.environ.get("VP_NO_FUSED_UPDATE")      # single-GPU train_step: vp_pixrefer_backward_update (backward + Adam x 2 + re-pack in one call)
+    self.fused_update = True             # single-GPU train_step: vp_pixrefer_backward_update (backward + Adam x 2 + re-pack in one call)
     ws = self.L.vp_pixrefer_workspace_bytes(d)
     if ws == 0:
       raise ValueError("invalid PixReferNet descriptor: %s" % self.L.vp_last_error().decode())
@@ -216,8 +218,8 @@ class PixReferEngine:
       ex = self._exchange
       if ex is None or ex.group is not group or ex.transport != self.grad_transport:
         # the collectives go to the executor's side stream (behind the discriminator-loss pass, where the single-GPU schedule runs its
-        # optimiser): one stream fewer competing for the device's hardware queues.  VP_DP_OWN_STREAM=1: a stream of the exchange's own
-        sp = None if os.environ.get("VP_DP_OWN_STREAM") else self.L.vp_pixrefer_side_stream(self.h)
+        # optimiser): one stream fewer competing for the device's hardware queues.  dp_own_stream: a stream of the exchange's own
+        sp = None if self.dp_own_stream else self.L.vp_pixrefer_side_stream(self.h)
         ex = self._exchange = GradExchange(group, self.grad_transport, torch.cuda.ExternalStream(sp) if sp else None)
       self.t_d += 1
       self.t_g += 1
