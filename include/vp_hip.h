@@ -135,6 +135,11 @@ int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n);
  * initial values come from the descriptor (vp_pixrefer_desc::streams / d_backward_fork / d_beside_vgg).  Bit-identical results under
  * every setting. */
 int vp_pixrefer_set_option(vp_pixrefer_t* h, const char* key, int value);
+/* Node values PixReferNet.execute hands to a caller, formed on the device from the last forward pass into `dst` (device memory,
+ * N * H * H * 3 elements): what = 0 Outputs (float32, (x + 1) / 2: pixrefer.py:424 / :380), 1 the same as uint8 frames (clamp, * 255,
+ * truncate: the bytes infer_bfmvid.py:243 writes), 2 Alphas (float32, three channels: pixrefer.py:284), 3 Outputs_FG as this plan's
+ * graph defines it (build_inference_op: ((Outputs_FG + Alphas - 1) + 1) / 2, pixrefer.py:436; build_train_op: the tensor itself). */
+int vp_pixrefer_fetch(vp_pixrefer_t* h, int what, void* dst, void* stream);
 /* The same pass in vp_pixrefer_backward_g_stages() = 3 consecutive stages (stage < 0: all).  After stage s a contiguous
  * range of the generator gradient arena is final (0: from generator/merged_decoder_5 to the end; 1: from
  * generator/merged_encoder_2 up to merged_decoder_5; 2: the rest), so a data-parallel host can start that bucket's
@@ -408,6 +413,11 @@ int vp_bfm_vertex_loss(const float* d, const float* vmask, const int* seq_len, i
 int vp_sumsq_partials(size_t n);
 int vp_sumsq(const float* x, size_t n, double* partial, void* stream);
 int vp_l2_regulariser(const float* params, const float* mask, float* grads, size_t n, float scale, double* partial, void* stream);
+/* The step's scalars on the device (no framework reduction / sqrt / stack on the path): out[0] = (add ? add[0] : 0) + scale * sum(partial[0..n));
+ * out3 = [loss_data + half_l2 * reg, loss_data, sqrt(sumsq)]; grads *= clip / max(sqrt(sumsq), clip).  All pointers are device memory. */
+int vp_sum_f64(const double* partial, int n, double scale, const double* add, double* out, void* stream);
+int vp_bfm_step_report(const double* loss_data, const double* reg, double half_l2, const double* sumsq, double* out3, void* stream);
+int vp_clip_scale_f32(float* grads, size_t n, const double* sumsq, float clip, void* stream);
 int vp_adam_tf_clipped(float* params, float* grads, float* m, float* v, size_t n, const float* lr_t, const double* sumsq, float clip, float beta1,
                        float beta2, float eps, void* stream);
 int vp_moving_update(float* moving, const float* batch, const float* factor, size_t n, float decay, void* stream);

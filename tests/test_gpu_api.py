@@ -376,3 +376,40 @@ def test_bfmnet_train_cli_on_clip_folders(tmp_path, monkeypatch, capsys):
   assert out.count("Step ") == 2 and out.count("Evaluation >>> Loss=") == 1
   losses = [float(l.split("Loss=")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Step ")]
   assert all(np.isfinite(losses))
+
+
+def test_node_fetches_are_formed_by_the_library_kernel():
+  """PixReferNet.execute's Outputs / Outputs_u8 / Alphas / Outputs_FG values come from vp_pixrefer_fetch (one kernel of the library per
+  fetch): bit-equal to the reference's float32 expressions (pixrefer.py:284, 424, 436) evaluated with torch on the
+  same device buffers, on a training and on an inference plan."""
+  import torch
+  from voicepuppet_amd.engine import PixReferEngine
+  g = torch.Generator(device="cpu").manual_seed(1)
+  for training in (True, False):
+    eng = PixReferEngine(2, 256, 8, 8, dtype="bf16", training=training)
+    eng.load_params(eng.random_params(3))
+    batch = [torch.rand(2, 256, 256, c, generator=g).cuda() for c in ((6, 6, 3, 3) if training else (6, 3, 3))]
+    eng.forward(*batch)
+    torch.cuda.synchronize()
+    raw, fg, o4 = eng.tensor("Outputs_raw"), eng.tensor("Outputs_FG"), eng.tensor("gen_out4")
+    alpha = (o4[..., 3:] + 1) / 2
+    want = {"Outputs": (raw + 1) / 2, "Outputs_u8": ((raw + 1) / 2).clamp(0, 1).mul(255).to(torch.uint8), "Alphas": alpha.repeat(1, 1, 1, 3),
+            "Outputs_FG": fg if training else ((fg + alpha - 1) + 1) / 2}
+    for k, w in want.items():
+      got = eng.fetch(k)
+      assert got.dtype == w.dtype and got.shape == w.shape, k
+      assert torch.equal(got, w), (k, training, float((got.float() - w.float()).abs().max()))
+
+
+def test_host_fetch_path_holds_no_framework_arithmetic():
+  """The per-frame fetch path of infer_bfmvid (PixReferNet.execute) and the scalar tail of the BFMNet training step hold no torch
+  elementwise / reduction call any more: source-level guard next to test_training_step_holds_no_vendor_gemm."""
+  import re
+  root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "voicepuppet_amd")
+  src = open(os.path.join(root, "pixrefer", "pixrefer.py")).read()
+  body = src[src.index("  def execute(self, names, feed_dict):"):src.index("  # ---- checkpoints")]
+  for pat in (r"\+ 1\) / 2", r"\.clamp", r"\.repeat\(", r"\.mul_\("):
+    assert not re.search(pat, body), pat
+  eng = open(os.path.join(root, "bfmnet", "train_engine.py")).read()
+  for pat in (r"part\.sum\(\)", r"torch\.stack\(", r"torch\.sqrt\(ss\)", r"grads\.mul_\(", r"torch\.clamp\("):
+    assert not re.search(pat, eng), pat

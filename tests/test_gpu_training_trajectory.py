@@ -22,8 +22,9 @@ pytestmark = pytest.mark.gpu
 
 STEPS = 200
 # relative band of the bf16 window mean around the float32 window mean, per checkpoint step
-BAND_L1 = {10: 0.05, 50: 0.10, 100: 0.10, 200: 0.10}          # Gen_loss_L1 and Perceptual_loss (smooth, monotone terms)
-ABS_GAN = 1.5                                                   # Discrim_loss / Gen_loss_GAN window means: absolute band (nats)
+# measured (profiles/r05_train_curves.json): Gen_loss_L1 0.4 / 0.0 / 2.8 / 2.4 %, Perceptual_loss <= 2 %, GAN terms <= 0.57 nats apart
+BAND_L1 = {10: 0.05, 50: 0.05, 100: 0.08, 200: 0.08}          # Gen_loss_L1 and Perceptual_loss (smooth, monotone terms)
+ABS_GAN = 1.2                                                   # Discrim_loss / Gen_loss_GAN window means: absolute band (nats)
 
 
 def test_bf16_loss_trajectory_tracks_float32_over_200_steps():

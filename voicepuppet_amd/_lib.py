@@ -68,6 +68,7 @@ _SIGNATURES = {
     "vp_pixrefer_side_stream": (ctypes.c_void_p, [_P]),
     "vp_pixrefer_use_streams": (ctypes.c_int, [_P, ctypes.c_int]),
     "vp_pixrefer_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
+    "vp_pixrefer_fetch": (ctypes.c_int, [_P, ctypes.c_int, _P, _P]),
     "vp_crc32c": (ctypes.c_uint, [_P, ctypes.c_size_t, ctypes.c_uint]),
     "vp_pixrefer_phase_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     "vp_grad_pack_bf16": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),
@@ -157,6 +158,9 @@ _SIGNATURES = {
     "vp_vertex_loss_partials": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "vp_bfm_vertex_loss": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "vp_sumsq_partials": (ctypes.c_int, [ctypes.c_size_t]),
+    "vp_sum_f64": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_double, _P, _P, _P]),
+    "vp_bfm_step_report": (ctypes.c_int, [_P, _P, ctypes.c_double, _P, _P, _P]),
+    "vp_clip_scale_f32": (ctypes.c_int, [_P, ctypes.c_size_t, _P, ctypes.c_float, _P]),
     "vp_sumsq": (ctypes.c_int, [_P, ctypes.c_size_t, _P, _P]),
     "vp_bn_bwd": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -347,7 +347,13 @@ class BFMNetTrainEngine:
     n = self.L.vp_sumsq_partials(x.numel())
     part = torch.empty(n, dtype=torch.float64, device=self.dev)
     _lib.check(self.L.vp_sumsq(_ptr(x), x.numel(), _ptr(part), _stream()), "vp_sumsq")
-    return part.sum()
+    return self._sum64(part)
+
+  def _sum64(self, part, scale=1.0, add=None):
+    """Float64 device scalar = (add or 0) + scale * sum(part), by the library's one-block kernel (no framework reduction on the path)."""
+    out = torch.empty((), dtype=torch.float64, device=self.dev)
+    _lib.check(self.L.vp_sum_f64(_ptr(part), part.numel(), float(scale), _ptr(add) if add is not None else None, _ptr(out), _stream()), "vp_sum_f64")
+    return out
 
   # ---- conv + batch-norm + activation, forward / backward -----------------------------------------------------------------------
   def _cba_fwd(self, x, kernel, bn_scope, act, tape, add=None):
@@ -583,7 +589,7 @@ class BFMNetTrainEngine:
     # ---- regulariser, clip_by_global_norm, Adam, moving averages ------------------------------------------------------------------------
     part = torch.empty(L.vp_sumsq_partials(self.ntrain), dtype=torch.float64, device=self.dev)
     _lib.check(L.vp_l2_regulariser(_ptr(self.arena), _ptr(self.l2mask), _ptr(self.grads), self.ntrain, L2_SCALE, _ptr(part), _stream()), "vp_l2_regulariser")
-    loss = loss_data + 0.5 * L2_SCALE * part.sum()
+    reg = self._sum64(part)
     ss = self._sumsq(self.grads)
     self._last_ss = ss
     if apply:
@@ -592,11 +598,12 @@ class BFMNetTrainEngine:
       _lib.check(L.vp_moving_update(_ptr(self.arena[self.ntrain:]), _ptr(self.bstats), _ptr(self._moving_factor()), self.bstats.numel(), BN_DECAY,
                                     _stream()), "vp_moving_update")
     else:
-      gn = torch.sqrt(ss)
-      self.grads.mul_((self.clip / torch.clamp(gn, min=self.clip)).to(torch.float32))
+      _lib.check(L.vp_clip_scale_f32(_ptr(self.grads), self.ntrain, _ptr(ss), self.clip, _stream()), "vp_clip_scale_f32")
     if self._pk_pending and not torch.cuda.is_current_stream_capturing():
       self._build_pack_table()                                                       # after the first eager step: the products are known
-    return torch.stack([loss, loss_data, torch.sqrt(ss)])
+    rep = torch.empty(3, dtype=torch.float64, device=self.dev)
+    _lib.check(L.vp_bfm_step_report(_ptr(loss_data), _ptr(reg), 0.5 * L2_SCALE, _ptr(ss), _ptr(rep), _stream()), "vp_bfm_step_report")
+    return rep
 
   def _vertex_loss(self, o, bfm_coeffs, seq):
     """add_cost_function (bfmnet.py:229-271): both face shapes share the identity coefficients, so their difference is
@@ -614,21 +621,23 @@ class BFMNetTrainEngine:
     if gp is None or gp.shape[0] != B * T:
       gp = self._gdpad = torch.zeros(B * T, -(-J // 16) * 16, dtype=torch.float32, device=self.dev)
     gp[:, :J].copy_(gD)
-    return part.sum(), -self._mm_dx(gp, self.exbase, w_t=True, n=J)
+    return self._sum64(part), -self._mm_dx(gp, self.exbase, w_t=True, n=J)
 
   def regulariser(self):
-    reg = torch.zeros((), dtype=torch.float64, device=self.dev)
+    reg = None
     for n in self.p:
       if regularised(n):
-        reg = reg + self._sumsq(self.p[n])
-    return 0.5 * L2_SCALE * reg
+        part = torch.empty(self.L.vp_sumsq_partials(self.p[n].numel()), dtype=torch.float64, device=self.dev)
+        _lib.check(self.L.vp_sumsq(_ptr(self.p[n]), self.p[n].numel(), _ptr(part), _stream()), "vp_sumsq")
+        reg = self._sum64(part, add=reg)
+    return float(reg) * 0.5 * L2_SCALE if reg is not None else 0.0
 
   def eval_loss(self, coeff, bfm_coeffs, seq_len):
     """The Loss node of build_eval_op (bfmnet.py:273-289): the same cost on coefficients predicted in inference mode."""
     seq = torch.as_tensor(seq_len, dtype=torch.int32, device=self.dev).contiguous()
     o = coeff.to(self.dev, torch.float32).reshape(self.B * self.T, 64).contiguous()
     ld, _ = self._vertex_loss(o, bfm_coeffs.to(self.dev, torch.float32), seq)
-    return float(ld + self.regulariser())
+    return float(ld) + self.regulariser()
 
   def draw_masks(self, drop_rate, inner_rate=0.25, generator=None):
     """One draw of the four dropout masks: keep with probability 1-rate, kept entries scaled by 1/(1-rate).  `drop_rate` is

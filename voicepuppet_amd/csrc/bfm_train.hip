@@ -6,7 +6,8 @@
 //   the 9x5 stem as im2col, the GRU recurrence forward (with saved gates) and backward through time, the vertex-space loss with
 //   its gradient, sums of squares (regulariser, global-norm clipping).
 // The matrix products themselves (1x1 convolutions, dense layers, GRU input / recurrent weight gradients, the [B*T,64] x [64,3n]
-// face-shape products) are plain GEMMs and go to rocBLAS through torch.mm in voicepuppet_amd/bfmnet/train_engine.py.
+// face-shape products) run on the repo's own float32-MFMA kernels (mm_api.hip: igemm / wgrad_mm; no vendor GEMM since round 3); the
+// step's scalar arithmetic (partial sums, the reported losses, the clip factor) are the small kernels at the end of this file.
 #include <math.h>
 
 #include "audio_args.h"
@@ -463,6 +464,33 @@ __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ p
 
 using namespace vp;
 
+// Scalars of a training step, on the device and in a fixed order (the framework's reductions / sqrt / stack used to do this):
+//   sum_f64: out[0] = (add ? add[0] : 0) + scale * sum(partial[0 .. n)), one 256-thread block, float64
+__global__ __launch_bounds__(256) void sum_f64_kernel(const double* __restrict__ partial, int n, double scale, const double* __restrict__ add, double* __restrict__ out) {
+  __shared__ double sm[256];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (add ? add[0] : 0.0) + scale * sm[0];
+}
+//   step_report: out3 = [loss_data + half_l2 * reg, loss_data, sqrt(sumsq)]  (the Loss / data loss / global norm a step returns)
+__global__ void step_report_kernel(const double* loss_data, const double* reg, double half_l2, const double* sumsq, double* out3) {
+  out3[0] = loss_data[0] + half_l2 * reg[0];
+  out3[1] = loss_data[0];
+  out3[2] = sqrt(sumsq[0]);
+}
+//   clip_scale: g *= clip / max(sqrt(sumsq), clip)  (tf.clip_by_global_norm without the optimiser: the gradient-only step)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, size_t n, const double* __restrict__ sumsq, float clip) {
+  const double gn = sqrt(sumsq[0]);
+  const float sc = (float)((double)clip / (gn > (double)clip ? gn : (double)clip));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] *= sc;
+}
+
 extern "C" {
 
 // launch shape of chan_sums_kernel for a [pixels, c] tensor: ql = log2 of the lanes across channel quads, nchunk row chunks
@@ -734,6 +762,26 @@ int vp_moving_update(float* moving, const float* batch, const float* factor, siz
 int vp_l2_regulariser(const float* params, const float* mask, float* grads, size_t n, float scale, double* partial, void* stream) {
   if (!params || !mask || !grads || !partial || n < 1) { set_err("vp_l2_regulariser: bad argument"); return VP_ERR_ARG; }
   hipLaunchKernelGGL(l2_reg_kernel, dim3(tblk(n, 1024)), dim3(256), 0, (hipStream_t)stream, params, mask, grads, n, scale, partial);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+
+// the step's scalar arithmetic (see the kernels): all arguments are device pointers, nothing synchronises
+int vp_sum_f64(const double* partial, int n, double scale, const double* add, double* out, void* stream) {
+  if (!partial || !out || n < 1) { set_err("vp_sum_f64: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, scale, add, out);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+int vp_bfm_step_report(const double* loss_data, const double* reg, double half_l2, const double* sumsq, double* out3, void* stream) {
+  if (!loss_data || !reg || !sumsq || !out3) { set_err("vp_bfm_step_report: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(step_report_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, loss_data, reg, half_l2, sumsq, out3);
+  VP_HIP_CHECK(hipGetLastError());
+  return VP_OK;
+}
+int vp_clip_scale_f32(float* grads, size_t n, const double* sumsq, float clip, void* stream) {
+  if (!grads || !sumsq || n < 1 || !(clip > 0)) { set_err("vp_clip_scale_f32: bad argument"); return VP_ERR_ARG; }
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(tblk(n, 1024)), dim3(256), 0, (hipStream_t)stream, grads, n, sumsq, clip);
   VP_HIP_CHECK(hipGetLastError());
   return VP_OK;
 }

@@ -59,6 +59,7 @@ hipError_t launch_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C
 hipError_t launch_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int is_bf16, hipStream_t st);
 hipError_t launch_relu_bwd(const void* y, void* d, size_t n, int is_bf16, hipStream_t st);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t st);
+hipError_t launch_fetch(const FetchArgs& a, hipStream_t st);
 hipError_t launch_grad_pack_bf16(const float* src, void* dst, size_t n, hipStream_t st);
 hipError_t launch_grad_unpack_bf16(const void* src, float* dst, size_t n, float scale, hipStream_t st);
 

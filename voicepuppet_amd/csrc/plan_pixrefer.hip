@@ -1731,6 +1731,26 @@ int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t s
   return VP_ERR_ARG;
 }
 
+// One of the reference's node values formed on the device from the last forward pass, into a caller-owned device buffer of N * H * H * 3
+// elements: what = 0 Outputs (float32, deprocessed: (x + 1) / 2, pixrefer.py:424), 1 the same as uint8 frames (clamped, * 255, truncated:
+// what infer_bfmvid.py:243 writes out), 2 Alphas (float32, tiled to three channels, pixrefer.py:284), 3 Outputs_FG as the graph of this
+// plan defines it - build_train_op: the composite's tensor; build_inference_op: deprocess(Outputs_FG + Alphas - 1), the quirk of
+// pixrefer.py:436.  No framework kernel, no synchronisation.
+int vp_pixrefer_fetch(vp_pixrefer_t* h, int what, void* dst, void* stream) {
+  if (!h || !dst || what < 0 || what > 3) { set_err("vp_pixrefer_fetch: bad argument"); return VP_ERR_ARG; }
+  FetchArgs f;
+  memset(&f, 0, sizeof(f));
+  f.raw3 = h->outputs; f.fg3 = h->outputs_fg; f.o4 = h->o4; f.dst = dst;
+  f.npix = (size_t)h->d.batch * h->d.height * h->d.height;
+  f.mode = what;
+  if (what == 3 && h->d.training) {          // the training graph's Outputs_FG is the stored tensor itself
+    VP_HIP_CHECK(hipMemcpyAsync(dst, h->outputs_fg, f.npix * 3 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VP_OK;
+  }
+  VP_HIP_CHECK(launch_fetch(f, (hipStream_t)stream));
+  return VP_OK;
+}
+
 // bf16 transport of a gradient bucket: f32 range -> bf16 communication buffer, and back with the 1 / world scale (both need 32-byte
 // aligned pointers: arena offsets of whole variables are, torch allocations are)
 int vp_grad_pack_bf16(const float* src, void* dst_bf16, size_t n, void* stream) {

@@ -857,6 +857,39 @@ static inline int nblocks(size_t work, int cap = 2048) {
     else hipLaunchKernelGGL((KERNEL<float>), grid, block, 0, stream, __VA_ARGS__);       \
   } while (0)
 
+// ------------------------------------------------------------------------------------------------
+// node fetches of PixReferNet.execute (deprocess, the uint8 frame, Alphas, the :436 quirk of build_inference_op): one thread per
+// pixel, every float operation rounded on its own (no contraction) in the order the reference's graph applies them
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fetch_kernel(const FetchArgs a) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < a.npix; p += (size_t)gridDim.x * 256) {
+    float v[3];
+    if (a.mode == 0 || a.mode == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = __fmul_rn(__fadd_rn(a.raw3[p * 3 + c], 1.f), 0.5f);
+    } else {
+      const float al = __fmul_rn(__fadd_rn(a.o4[p * 4 + 3], 1.f), 0.5f);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        v[c] = a.mode == 2 ? al : __fmul_rn(__fadd_rn(__fsub_rn(__fadd_rn(a.fg3[p * 3 + c], al), 1.f), 1.f), 0.5f);
+    }
+    if (a.mode == 1) {
+      unsigned char* o = reinterpret_cast<unsigned char*>(a.dst) + p * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = (unsigned char)(int)__fmul_rn(fminf(fmaxf(v[c], 0.f), 1.f), 255.f);
+    } else {
+      float* o = reinterpret_cast<float*>(a.dst) + p * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = v[c];
+    }
+  }
+}
+
+hipError_t launch_fetch(const FetchArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(fetch_kernel, dim3(nblocks(a.npix, 4096)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_weights(const PackDesc* d_descs, int ndesc, const float* master, void* packed, int is_bf16, hipStream_t st) {
   dim3 grid(512, ndesc);
   if (is_bf16) hipLaunchKernelGGL((pack_weights_kernel<bf16>), grid, dim3(256), 0, st, d_descs, master, (bf16*)packed);

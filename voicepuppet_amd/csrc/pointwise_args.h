@@ -22,6 +22,17 @@ struct PackDesc {
   int8_t kw[4][16];
 };
 
+// what PixReferNet.execute fetches from a finished forward pass (pixrefer.py:279-290, 414-438), formed on the device in one launch
+struct FetchArgs {
+  const float* raw3;     // Outputs in [-1, 1], [npix][3]
+  const float* fg3;      // Outputs_FG, [npix][3]
+  const float* o4;       // generator output after tanh, [npix][4] (channel 3 = alpha in [-1, 1])
+  void* dst;             // [npix][3] float32 (uint8 for mode 1)
+  size_t npix;
+  int mode;              // 0 Outputs = (raw + 1) / 2; 1 the same as uint8 (clamp, * 255, truncate); 2 Alphas = (alpha + 1) / 2 tiled x 3;
+                         // 3 Outputs_FG of build_inference_op: ((fg + (alpha + 1) / 2 - 1) + 1) / 2 (pixrefer.py:436)
+};
+
 struct BnArgs {
   const void* y;            // [G*Pg][C] raw conv output
   const void* dz;           // bwd: gradient w.r.t. the normalised tensor

@@ -266,6 +266,17 @@ class PixReferEngine:
     assert 0 <= off and off + nbytes <= self.workspace.numel(), name
     return self.workspace[off:off + nbytes].view(tdt).view(shape)
 
+  FETCH = {"Outputs": 0, "Outputs_u8": 1, "Alphas": 2, "Outputs_FG": 3}
+
+  def fetch(self, name):
+    """A node value of the reference's graphs formed on the device from the last forward pass (vp_pixrefer_fetch): 'Outputs' (deprocessed
+    float32), 'Outputs_u8' (the uint8 frames infer_bfmvid.py:243 writes), 'Alphas' (three channels), 'Outputs_FG' (with the
+    pixrefer.py:436 quirk on an inference plan).  [N, H, H, 3] device tensor."""
+    n, hgt = self.desc.batch, self.desc.height
+    out = torch.empty((n, hgt, hgt, 3), dtype=torch.uint8 if name == "Outputs_u8" else torch.float32, device=self.device)
+    _lib.check(self.L.vp_pixrefer_fetch(self.h, self.FETCH[name], _ptr(out), _stream()), "vp_pixrefer_fetch(%s)" % name)
+    return out
+
   def profile(self, on):
     """Per-launch HIP-event timing of the conv kernels; while it is on the executor keeps every kernel on one stream (timing a
     kernel that shares the GPU with another stream's kernels measures the sharing, not the kernel)."""

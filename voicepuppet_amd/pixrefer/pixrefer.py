@@ -173,20 +173,12 @@ class PixReferNet(ModelBuilder):
     for n in names:
       if n in ('Inputs', 'FGInputs', 'Targets', 'Masks'):
         out[n] = v[n].cpu().numpy()
-      elif n == 'Outputs':
-        out[n] = ((eng.tensor('Outputs_raw') + 1) / 2).cpu().numpy()                      # deprocess
-      elif n == 'Outputs_u8':
-        # not a node of the reference: (Outputs * 255).astype(uint8) formed on the device, for callers that only write the frames out
-        # (infer_bfmvid.py:243) - a quarter of the device-to-host bytes of 'Outputs' and no host pass; same float32 arithmetic, same bytes
-        import torch
-        out[n] = ((eng.tensor('Outputs_raw') + 1) / 2).clamp_(0, 1).mul_(255).to(torch.uint8).cpu().numpy()
-      elif n == 'Alphas':
-        out[n] = ((eng.tensor('gen_out4')[..., 3:] + 1) / 2).repeat(1, 1, 1, 3).cpu().numpy()
-      elif n == 'Outputs_FG':
-        fg = eng.tensor('Outputs_FG')
-        if not eng.training:   # build_inference_op quirk: deprocess(Outputs_FG + Alphas - 1)  (pixrefer.py:436)
-          fg = ((fg + (eng.tensor('gen_out4')[..., 3:] + 1) / 2 - 1) + 1) / 2
-        out[n] = fg.cpu().numpy()
+      elif n in ('Outputs', 'Outputs_u8', 'Alphas', 'Outputs_FG'):
+        # formed on the device by one kernel of the library (vp_pixrefer_fetch): deprocess (pixrefer.py:424); 'Outputs_u8' - not a node of the
+        # reference - is (Outputs * 255).astype(uint8) for callers that only write the frames out (infer_bfmvid.py:243): a quarter of the
+        # device-to-host bytes, same float32 arithmetic, same bytes; 'Alphas' tiled to three channels (pixrefer.py:284); 'Outputs_FG' with
+        # the quirk of build_inference_op on an inference plan: deprocess(Outputs_FG + Alphas - 1) (pixrefer.py:436)
+        out[n] = eng.fetch(n).cpu().numpy()
       elif n in ('Predict_real', 'Predict_fake'):
         p = eng.tensor('Predict')
         out[n] = p[0 if n == 'Predict_real' else 1].unsqueeze(-1).cpu().numpy()
