@@ -5,6 +5,9 @@
 
 namespace vp {
 hipError_t launch_frame_window(const float* pcm, const float* window, float* frames, int B, int L, int F, int win, int hop, hipStream_t st);
+// 512-sample frames, <= 80 mel bins: the whole log-mel front-end in one launch (FFT form)
+hipError_t launch_logmel512(const float* pcm, const float* window, const float* w256, const float* w512, const float* mel, float* out, int B, int L, int F, int hop,
+                            int nmel, hipStream_t st);
 hipError_t launch_mag_mel_log(const float* spec, int ld, int nb, const float* mel, int nmel, float* out, int nframes, hipStream_t st);
 hipError_t launch_conv_first(const float* x, const float* w, const float* bias, void* y, int out_bf16, int B, int H, int W, int Wo, int Cout, int pt, int pl, hipStream_t st);
 hipError_t launch_dwconv7x3(const void* x, const float* w, const float* bias, void* y, int is_bf16, int B, int H, int W, int C, hipStream_t st, int rev = 0);

@@ -40,6 +40,103 @@ __global__ __launch_bounds__(128) void mag_mel_log_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// log-mel in ONE launch (DataGenerator.extract_mfcc, generator/generator.py:60-80; round 5) for the reference's frame length 512:
+// framing, periodic Hann window, the 512-point real DFT as a 256-point complex FFT (z[n] = x[2n] + i x[2n+1]; Stockham radix 4,
+// four stages, one wave per frame: a lane is one radix-4 butterfly per stage, stages exchanged through 2 KB of wave-private LDS) and
+// the untangling step X[k] = (Z[k] + conj Z[256-k]) / 2 + W512^k (Z[k] - conj Z[256-k]) / 2i, |X|, the 257 x nmel mel matrix and
+// log(. + 1e-6).  24 KFLOP per frame instead of the 526 KFLOP of the dense DFT matrix product it replaces (three launches, two
+// round trips of the frames / spectra through HBM).  Twiddles come from tables computed in float64 on the host.
+//   block = FPB frames (consecutive over the whole batch), 5 waves; wave w transforms frames w, w + 5, ...; then thread (mel bin m,
+//   frame group g) accumulates its mel bin for FPB / 4 frames over the 257 magnitudes (matrix row k read once per block from L2, the
+//   magnitudes broadcast from LDS).
+// ------------------------------------------------------------------------------------------------
+constexpr int LM_FPB = 32, LM_NB = 257, LM_MAGP = 260;
+__global__ __launch_bounds__(320) void logmel512_kernel(const float* __restrict__ pcm, const float* __restrict__ window, const float2* __restrict__ w256,
+                                                         const float2* __restrict__ w512, const float* __restrict__ mel, float* __restrict__ out,
+                                                         int L, int F, int hop, int nmel, int nframes) {
+  __shared__ float2 s_w256[256];
+  __shared__ float2 s_w512[LM_NB];
+  __shared__ float s_win[512];
+  __shared__ float2 s_fft[5][256];
+  __shared__ float s_mag[LM_FPB][LM_MAGP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 256; i += 320) s_w256[i] = w256[i];
+  for (int i = tid; i < LM_NB; i += 320) s_w512[i] = w512[i];
+  for (int i = tid; i < 512; i += 320) s_win[i] = window[i];
+  __syncthreads();
+  const int f0 = blockIdx.x * LM_FPB;
+  auto cmul = [](float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); };
+  float2* buf = s_fft[wave];
+  for (int fl = wave; fl < LM_FPB; fl += 5) {
+    const int f = f0 + fl;
+    if (f >= nframes) break;                                  // (wave-uniform)
+    const float* x = pcm + (size_t)(f / F) * L + (size_t)(f % F) * hop;
+    float2 u[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n2 = 2 * (lane + 64 * t);
+      u[t] = make_float2(x[n2] * s_win[n2], x[n2 + 1] * s_win[n2 + 1]);
+    }
+    // four radix-4 Stockham stages: p = 1, 4, 16, 64; lane i reads elements i + 64 t, writes j + p t with j = 4 (i - k) + k, k = i mod p
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int p = 1 << (2 * st);
+      const int k = lane & (p - 1), j = ((lane - k) << 2) + k;
+      if (st > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) u[t] = buf[lane + 64 * t];
+        const int q = k * (64 >> (2 * st));                    // W_{4p}^k = W256^(k * 64 / p)
+        u[1] = cmul(u[1], s_w256[q]); u[2] = cmul(u[2], s_w256[2 * q]); u[3] = cmul(u[3], s_w256[3 * q]);
+      }
+      const float2 v0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y), v1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
+      const float2 v2 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y), d = make_float2(u[1].x - u[3].x, u[1].y - u[3].y);
+      const float2 v3 = make_float2(d.y, -d.x);                 // (u1 - u3) * (-i)
+      __builtin_amdgcn_wave_barrier();                          // (all lanes have read the previous stage)
+      buf[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
+      buf[j + p] = make_float2(v1.x + v3.x, v1.y + v3.y);
+      buf[j + 2 * p] = make_float2(v0.x - v2.x, v0.y - v2.y);
+      buf[j + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the wave's own LDS writes have landed
+      __builtin_amdgcn_wave_barrier();
+    }
+    // untangle: bins k = lane + 64 t (t = 0..3) and bin 256 (lane 0)
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int k = t < 4 ? lane + 64 * t : 256;
+      if (t == 4 && lane != 0) break;
+      const float2 a = buf[k & 255], b0 = buf[(256 - k) & 255];
+      const float2 b = make_float2(b0.x, -b0.y);
+      const float2 xe = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+      const float2 dd = make_float2(a.x - b.x, a.y - b.y);
+      const float2 xo = make_float2(0.5f * dd.y, -0.5f * dd.x);                    // (a - b) / 2i
+      const float2 w = cmul(s_w512[k], xo);
+      const float re = xe.x + w.x, im = xe.y + w.y;
+      s_mag[fl][k] = sqrtf(re * re + im * im);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // mel + log: thread -> (mel bin m = tid % 80, frame group g = tid / 80), 8 frames each
+  const int m = tid % 80, g = tid / 80;
+  if (m < nmel) {
+    constexpr int FG = LM_FPB / 4;
+    float acc[FG];
+#pragma unroll
+    for (int i = 0; i < FG; ++i) acc[i] = 0.f;
+    for (int k = 0; k < LM_NB; ++k) {
+      const float w = mel[(size_t)k * nmel + m];
+#pragma unroll
+      for (int i = 0; i < FG; ++i) acc[i] = fmaf(s_mag[g * FG + i][k], w, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < FG; ++i) {
+      const int f = f0 + g * FG + i;
+      if (f < nframes) out[(size_t)f * nmel + m] = logf(acc[i] + 1e-6f);
+    }
+  }
+}
+
 // four consecutive channels of an activation tensor stored as float or bf16 (the bf16 trunk of vp_bfmnet: f32 arithmetic, bf16 storage)
 template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
 template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -317,6 +414,13 @@ static inline int nblk(size_t work, int cap = 4096) {
 
 hipError_t launch_frame_window(const float* pcm, const float* window, float* frames, int B, int L, int F, int win, int hop, hipStream_t st) {
   hipLaunchKernelGGL(frame_window_kernel, dim3(nblk((size_t)B * F * win)), dim3(256), 0, st, pcm, window, frames, B, L, F, win, hop);
+  return hipGetLastError();
+}
+hipError_t launch_logmel512(const float* pcm, const float* window, const float* w256, const float* w512, const float* mel, float* out, int B, int L, int F, int hop,
+                            int nmel, hipStream_t st) {
+  const int nframes = B * F;
+  hipLaunchKernelGGL(logmel512_kernel, dim3((nframes + LM_FPB - 1) / LM_FPB), dim3(320), 0, st, pcm, window, reinterpret_cast<const float2*>(w256),
+                     reinterpret_cast<const float2*>(w512), mel, out, L, F, hop, nmel, nframes);
   return hipGetLastError();
 }
 hipError_t launch_mag_mel_log(const float* spec, int ld, int nb, const float* mel, int nmel, float* out, int nframes, hipStream_t st) {

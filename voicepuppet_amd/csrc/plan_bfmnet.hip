@@ -56,6 +56,8 @@ struct vp_logmel {
   vp_logmel_desc d;
   int frames, nb, ncol;
   float *window, *dft, *mel, *frames_buf, *spec;
+  float *w256, *w512;      // FFT twiddles of the one-launch form (audio_kernels.hip logmel512_kernel)
+  bool fused;              // 512-sample frames, <= 80 mel bins: one launch; other shapes: framing + DFT matrix product + mel (three)
   char* packed;
   char* scratch;
   void* zeros;
@@ -72,6 +74,9 @@ static size_t logmel_carve(vp_logmel* h, char* base) {
   h->window = (float*)ar.alloc(d.win_length * sizeof(float));
   h->dft = (float*)ar.alloc((size_t)d.win_length * h->ncol * sizeof(float));
   h->mel = (float*)ar.alloc((size_t)h->nb * d.num_mel_bins * sizeof(float));
+  h->w256 = (float*)ar.alloc(256 * 2 * sizeof(float));
+  h->w512 = (float*)ar.alloc(257 * 2 * sizeof(float));
+  h->fused = d.win_length == 512 && d.num_mel_bins <= 80;
   h->frames_buf = (float*)ar.alloc(P * d.win_length * sizeof(float));
   h->spec = (float*)ar.alloc(P * h->ncol * sizeof(float));
   ConvGeomX g = make_geom(0, 1, 1, 0, 1, (int)P, 1, d.win_length, d.win_length, h->ncol);
@@ -128,6 +133,11 @@ int vp_logmel_create(const vp_logmel_desc* d, void* workspace, size_t bytes, voi
       mel[(size_t)k * d->num_mel_bins + j] = (float)(v > 0 ? v : 0);
     }
   }
+  std::vector<float> t256(512), t512(514);
+  for (int i = 0; i < 256; ++i) { t256[2 * i] = (float)cos(2.0 * PI * i / 256); t256[2 * i + 1] = (float)(-sin(2.0 * PI * i / 256)); }
+  for (int i = 0; i < 257; ++i) { t512[2 * i] = (float)cos(2.0 * PI * i / 512); t512[2 * i + 1] = (float)(-sin(2.0 * PI * i / 512)); }
+  VP_HIP_CHECK(hipMemcpyAsync(h->w256, t256.data(), t256.size() * 4, hipMemcpyHostToDevice, st));
+  VP_HIP_CHECK(hipMemcpyAsync(h->w512, t512.data(), t512.size() * 4, hipMemcpyHostToDevice, st));
   VP_HIP_CHECK(hipMemcpyAsync(h->window, win.data(), win.size() * 4, hipMemcpyHostToDevice, st));
   VP_HIP_CHECK(hipMemcpyAsync(h->dft, dft.data(), dft.size() * 4, hipMemcpyHostToDevice, st));
   VP_HIP_CHECK(hipMemcpyAsync(h->mel, mel.data(), mel.size() * 4, hipMemcpyHostToDevice, st));
@@ -145,6 +155,10 @@ int vp_logmel_forward(vp_logmel_t* h, const float* pcm, float* out, void* stream
   hipStream_t st = (hipStream_t)stream;
   const vp_logmel_desc& d = h->d;
   const int P = d.batch * h->frames;
+  if (h->fused) {
+    VP_HIP_CHECK(launch_logmel512(pcm, h->window, h->w256, h->w512, h->mel, out, d.batch, d.samples, h->frames, d.hop_step, d.num_mel_bins, st));
+    return VP_OK;
+  }
   VP_HIP_CHECK(launch_frame_window(pcm, h->window, h->frames_buf, d.batch, d.samples, h->frames, d.win_length, d.hop_step, st));
   IgemmArgs a = h->plan.a;
   set_single_src(a.x, h->frames_buf, d.win_length, nullptr, nullptr, ACT_NONE, 0);
