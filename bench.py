@@ -49,6 +49,7 @@ def parse_args(argv=None):
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-profile", action="store_true")
   ap.add_argument("--no-f32", action="store_true")
+  ap.add_argument("--no-scaling-ceiling", action="store_true", help="skip the step at global_batch / 8 frames (strong_scaling_ceiling)")
   ap.add_argument("--no-other-scaling", action="store_true")
   ap.add_argument("--no-input-pipeline", action="store_true")
   ap.add_argument("--no-bfmnet-train", action="store_true", help="skip the BFMNet training-step sub-record (SURVEY.md 8f-4)")
@@ -88,6 +89,18 @@ def pmc_traffic(name):
   n = sum(r["launches"] for r in rows)
   src = "replayed from the committed rocprofv3 PMC summary profiles/%s (separate --pmc passes of this command; NOT measured in this run)" % os.path.basename(paths[-1])
   return (sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None), src
+
+
+def pmc_mfma_busy(name):
+  """Matrix-pipe busy fraction of a kernel class from the newest committed counter summary (profiles/r*_pmc_mfma_busy.json, written by
+  scripts/pmc_mix.sh: SQ_VALU_MFMA_BUSY_CYCLES against the kernel's GPU-active cycles, a separate --pmc pass of this command), time-weighted
+  over the template variants of the class; None when not collected.  Replayed, NOT measured in this run."""
+  paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_busy.json")))
+  if not paths:
+    return None, None
+  rows = [r for r in json.load(open(paths[-1])).values() if r.get("class") == name and r.get("ms")]
+  t = sum(r["ms"] for r in rows)
+  return (sum(r["mfma_busy"] * r["ms"] for r in rows) / t if t else None), os.path.basename(paths[-1])
 
 
 def synth_batch(n, h, seed, device):
@@ -331,10 +344,12 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
     peak = BF16_MFMA_PEAK if dtype == "bf16" else F32_MFMA_PEAK
     ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(top["name"]) if dtype == "bf16" else (None, None)
+    busy, busy_src = pmc_mfma_busy(top["name"]) if dtype == "bf16" else (None, None)
     # the whole step against its mixed per-layer roofline, scaled to this rank's batch and image size
     step_roof_ms = STEP_ROOFLINE_MS_BS32_256[dtype] * per_gpu / 32.0 * (height / 256.0) ** 2
     res["roofline"] = {"kernel": top["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                        "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                       "mfma_busy": busy, "mfma_busy_source": busy_src,
                        "step_roofline_ms": step_roof_ms, "step_frac": step_roof_ms / ms,
                        "avg_launch_ms": top["ms"] / top["calls"], "launches_per_step": top["calls"] / psteps,
                        "algorithmic_bytes_per_launch": top["bytes"] / top["calls"],
@@ -452,6 +467,16 @@ def main():
     f32 = {"ms_per_step": r["ms_per_step"], "value": r["frames_per_s"], "unit": "frames/s", "step_tflops": r["step_tflops"],
            "roofline": r.get("roofline"), "tolerance": "generator pixels <= 1e-3 rel-L2 vs the float64 oracle (tests/test_gpu_step.py)"}
 
+  # What strong scaling of the global batch can reach at 8 GPUs before any communication: the single-GPU step at the per-GPU share
+  # (global batch / 8 frames), measured here so that a SCALE record explains itself
+  ceiling = None
+  if world == 1 and not args.no_scaling_ceiling and args.scaling == "strong" and args.global_batch % 8 == 0:
+    share = args.global_batch // 8
+    r = run_config(share, args.height, args.dtype, max(10, args.steps), 5, rank, world, device, group, False)
+    ceiling = {"per_gpu_batch_at_8_gpus": share, "ms_per_step_at_that_batch": r["ms_per_step"],
+               "ceiling_8_gpus": main_res["ms_per_step"] / r["ms_per_step"],
+               "note": "single-GPU step time at the 8-GPU share of the global batch, no gradient exchange: an upper bound of value(8 GPUs) / value(1 GPU)"}
+
   pcie = None
   if world == 1 and not args.no_input_pipeline:
     pcie = run_with_input_pipeline(per_gpu_batch(args, args.scaling, world), args.height, args.dtype, max(5, args.steps // 2), 3, device)
@@ -475,6 +500,8 @@ def main():
       out["distributed"] = dist_info
     if other is not None:
       out["other_scaling"] = other
+    if ceiling is not None:
+      out["strong_scaling_ceiling"] = ceiling
     if f32 is not None:
       out["f32"] = f32
     if pcie is not None:

@@ -4,7 +4,7 @@ o=gpurun_out/quick
 mkdir -p $o
 timeout 1200 python -m pytest tests/test_gpu_step.py tests/test_gpu_fullwidth.py -x -q -m gpu > $o/pytest.log 2>&1
 grep -E "passed|failed|Error" $o/pytest.log | tail -3
-timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-input-pipeline --no-bfmnet-train > $o/bench.json 2> $o/bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-input-pipeline --no-bfmnet-train --no-scaling-ceiling > $o/bench.json 2> $o/bench.err
 python - <<'P'
 import json
 d=json.load(open('gpurun_out/quick/bench.json'))

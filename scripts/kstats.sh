@@ -5,6 +5,6 @@ export TMPDIR=/tmp
 o=gpurun_out/kstats
 rm -rf $o; mkdir -p $o
 one="--tune streams=1"; if [ "$1" = "on" ]; then one=""; fi
-rocprofv3 --kernel-trace --stats -d $o/r -o r --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline --no-bfmnet-train $one > $o/r.log 2>&1
+rocprofv3 --kernel-trace --stats -d $o/r -o r --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline --no-bfmnet-train --no-scaling-ceiling $one > $o/r.log 2>&1
 rm -f $o/r/*kernel_trace.csv
 python3 scripts/kstats_summary.py $o/r/r_kernel_stats.csv 13

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 o=gpurun_out/small
 rm -rf $o; mkdir -p $o
 for gb in 4 8; do
-  rocprofv3 --kernel-trace --stats -d $o/p$gb -o b$gb --output-format csv -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline --no-bfmnet-train --global-batch $gb > $o/p$gb.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $o/p$gb -o b$gb --output-format csv -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-profile --no-f32 --no-input-pipeline --no-bfmnet-train --no-scaling-ceiling --global-batch $gb > $o/p$gb.log 2>&1
   f=$(find $o/p$gb -name "*kernel_trace.csv" | head -1)
   python3 scripts/timeline.py $f 8 > $o/timeline_bs$gb.txt 2>&1
   python3 scripts/timeline.py $f 8 -v >> $o/timeline_bs$gb.txt 2>&1
