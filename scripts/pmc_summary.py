@@ -21,9 +21,9 @@ WGRAD_TILES = {(2, 2, 4, 4): "128x128", (2, 2, 4, 2): "128x64", (4, 1, 2, 1): "1
 def classify(name):
   """'igemm_bf16_128x256' style class of a vp:: conv kernel, from either the mangled name or rocprofv3's (sometimes
   garbled: bf16 'DF16b' confuses its demangler and swallows the first int) demangled one; None for other kernels."""
-  if "conv_c64_kernel" in name:     # conv_c64_kernel<NW, REF, RELU, POOL, STORE>: 32 NW output channels, 4 x 16-pixel tiles
-    m = re.search(r"conv_c64_kernel(?:<|ILi)(\d+)", name)
-    return "c64_bf16_%dx64" % (32 * int(m.group(1)) if m else 64)
+  if "conv_c64_kernel" in name:     # conv_c64_kernel<NCH, TPW, NW, REF, RELU, POOL, STORE>: 16 TPW NW output channels, 4 x 16-pixel tiles
+    m = re.search(r"conv_c64_kernel<(\d+), (\d+), (\d+)", name) or re.search(r"conv_c64_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)
+    return "c64_bf16_%dx64" % (16 * int(m.group(2)) * int(m.group(3)) if m else 64)
   if "conv_dc64_kernel" in name:
     return "dc64_bf16_64x128"
   if "conv_cin8_kernel" in name:

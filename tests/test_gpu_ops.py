@@ -28,6 +28,8 @@ FWD_CASES = [
     (0, 2, 32, 48, 64, 64, 3, 1, 1, 0, 2, False),     # VGG conv1_2 geometry (sides multiples of 8 x 16): register-resident weights (conv_c64.hip); bwd-data: its flipped form
     (0, 1, 8, 16, 64, 64, 3, 1, 1, 0, 0, False),      # ... two tiles: almost every patch row / column outside the image is padding
     (0, 2, 32, 48, 64, 128, 3, 1, 1, 0, 2, False),    # VGG conv2_1 geometry: the four-wave form of the same kernel (128 output channels)
+    (0, 2, 32, 48, 128, 128, 3, 1, 1, 0, 2, False),   # VGG conv2_2 geometry: 128 input channels, eight waves of 16 output channels
+    (0, 1, 16, 32, 128, 64, 3, 1, 1, 0, 0, False),    # 128 -> 64 (the shape of conv2_1's backward-data), four waves of 16 channels
     (0, 2, 2, 2, 512, 256, 4, 2, 1, 1, 0, True),      # bottleneck: 2 pixels, split-K
     (0, 5, 4, 4, 256, 128, 4, 2, 1, 1, 0, True),      # 20 pixels: 32-pixel tile
     (1, 2, 4, 4, 32, 16, 4, 2, 1, 2, 0, True),        # deconv

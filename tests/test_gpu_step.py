@@ -312,7 +312,8 @@ def test_conv1_2_register_resident_weights_kernel_in_situ():
       classes = {r["name"] for r in eng.profile_collect()}
       eng.profile(0)
       assert any(c.startswith("c64_") for c in classes) == bool(on), classes
-      got[on] = {k: eng.tensor(k).float().cpu().numpy() for k in ("v/conv1/conv1_1", "v/conv1/conv1_2", "v/pool1", "v/conv1/conv1_2:dy", "v/conv1/conv1_1:dy")}
+      got[on] = {k: eng.tensor(k).float().cpu().numpy() for k in ("v/conv1/conv1_1", "v/conv1/conv1_2", "v/pool1", "v/conv1/conv1_2:dy", "v/conv1/conv1_1:dy",
+                                                                  "v/conv2/conv2_1", "v/conv2/conv2_2", "v/pool2", "v/conv2/conv2_1:dy", "v/pool1:dy")}
       if on:
         w = gu.rounded(eng.get_params(2)["vgg_16/conv1/conv1_2/weights"], "bf16")
         b = eng.get_params(2)["vgg_16/conv1/conv1_2/biases"].astype(np.float64)
@@ -332,7 +333,12 @@ def test_conv1_2_register_resident_weights_kernel_in_situ():
   assert gu.rel_l2(t["v/conv1/conv1_1:dy"][:1], dx) < 4e-3, gu.rel_l2(t["v/conv1/conv1_1:dy"][:1], dx)
   # (the gradient tensors of the two runs also differ by what a handful of flipped bf16 roundings of the forward output do to the pool's
   # argmax and the relu masks upstream: bound 3e-2 there, 3e-3 on the forward tensors)
-  for k, tol in (("v/conv1/conv1_2", 3e-3), ("v/pool1", 3e-3), ("v/conv1/conv1_1:dy", 3e-2)):
+  # the 128-channel layers of the same kernel family (conv2_1 forward: four waves of 32 channels; conv2_2 both passes and conv2_1
+  # backward-data: waves of 16 channels, 128 input channels): the fused pool again bit for bit, everything against the patch kernels
+  y2 = t["v/conv2/conv2_2"]
+  assert np.array_equal(t["v/pool2"], y2.reshape(2 * n, 64, 2, 64, 2, 128).max(axis=(2, 4)))
+  for k, tol in (("v/conv1/conv1_2", 3e-3), ("v/pool1", 3e-3), ("v/conv1/conv1_1:dy", 3e-2), ("v/conv2/conv2_1", 3e-3), ("v/conv2/conv2_2", 4e-3),
+                 ("v/pool2", 4e-3), ("v/conv2/conv2_1:dy", 3e-2), ("v/pool1:dy", 3e-2)):
     assert gu.rel_l2(got[1][k], got[0][k]) < tol, (k, gu.rel_l2(got[1][k], got[0][k]))
 
 

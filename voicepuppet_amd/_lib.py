@@ -177,7 +177,12 @@ def lib():
                          "or `make -C voicepuppet_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
     l = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
-      fn = getattr(l, name)
+      try:
+        fn = getattr(l, name)
+      except AttributeError:
+        if "VP_LIB" not in os.environ:       # the shipped library exports everything include/vp_hip.h declares (tests/test_host_logic.py)
+          raise
+        continue                             # an A/B build of an older tree (scripts/ab.sh): entry points added since are simply absent
       fn.restype = res
       fn.argtypes = args
     _lib = l

@@ -36,8 +36,7 @@ namespace {
 constexpr int TH = 4, TW = 16, PW = TW + 2, PH = TH + 2;
 constexpr int NPATCH = PW * PH;               // 108 patch pixels
 constexpr int PPAD = 128;                     // ... padded to whole DMA rounds of the block's waves (NW x 16 pixels; NW = 2, 4)
-constexpr int PBUFB = PPAD * 64;              // bytes of one channel chunk (32 channels) of a patch
-constexpr int BUFB = 2 * PBUFB;               // one patch buffer (both chunks); two buffers per block
+constexpr int PBUFB = PPAD * 64;              // bytes of one channel chunk (32 channels) of a patch; a patch buffer is NCH of them
 }  // namespace
 
 // packed-bf16 helpers (two values per register).  A bf16 bit pattern read as a signed 16-bit integer orders like the float for
@@ -64,13 +63,22 @@ __device__ __forceinline__ unsigned dpp_xor1(unsigned v) {       // value of lan
 
 // REF: backward-data (output *= relu'(reference)); RELU: forward activation; POOL: also write the 2x2 max pool (RELU outputs only);
 // STORE: write the full-resolution output (false with POOL: the real half of the perceptual trunk, nobody reads it)
-// NW: waves of a block = 32-channel slices of the output (2: 64 channels, VGG conv1_2; 4: 128 channels, conv2_1 forward)
-template <int NW, bool REF, bool RELU, bool POOL, bool STORE>
+// NCH: 64-byte channel chunks of the input (2: 64 channels, 4: 128); TPW: 16-channel MFMA tiles per wave - 36 NCH TPW weight registers:
+//   NCH 2, TPW 2: 64 -> 64 (NW 2: VGG conv1_2 both passes) and 64 -> 128 (NW 4: conv2_1 forward);
+//   NCH 4, TPW 1: 128 -> 128 (NW 8: conv2_2 both passes) and 128 -> 64 (NW 4: conv2_1 backward-data) - a fragment read then feeds half
+//   the MFMAs, still 72 reads for 144 MFMAs per wave and tile
+// NW: waves of a block; the block's output channels are 16 TPW NW
+template <int NCH, int TPW, int NW, bool REF, bool RELU, bool POOL, bool STORE>
 __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a, const int ntiles) {
   static_assert(!POOL || (RELU && !REF), "the packed max pool compares relu outputs");
-  static_assert(NW == 2 || (NW == 4 && !POOL && !REF), "wave layouts of the staged store");
+  static_assert((NCH == 2 && TPW == 2) || (NCH == 4 && TPW == 1), "36 NCH TPW <= 144 weight registers");
   constexpr int JP = PPAD / (16 * NW);          // patch DMA instructions per wave and chunk
-  constexpr int CB = NW * 64;                   // bytes of one output pixel (32 * NW channels)
+  constexpr int CW = 16 * TPW;                  // output channels of a wave
+  constexpr int COUT = CW * NW, CIN = 32 * NCH;
+  constexpr int CB = COUT * 2;                  // bytes of one output pixel
+  constexpr int BUFB = NCH * PBUFB;             // one patch buffer; two per block
+  constexpr int KS = 9 * NCH;                   // (patch position, chunk) steps of the K loop
+  static_assert(PPAD % (16 * NW) == 0, "whole DMA rounds per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,27 +90,30 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
 
   // this wave's weights: MFMA tiles 2 * wave, 2 * wave + 1 of the 64-row block (channels 32 * wave + 8 q + 4 t + e at row 4 q + e of tile
   // t: IgemmArgs::rowperm), one 16-byte fragment per (patch position, chunk, tile): piece fg of packed row fi
-  uint4 W[18][2];
+  uint4 W[KS][TPW];
   {
     const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
 #pragma unroll
-    for (int U = 0; U < 18; ++U) {
+    for (int U = 0; U < KS; ++U) {
       const int cc = U / 9, u = U % 9;
       const int tap = flip ? 8 - u : u;
-      const size_t chunk_row0 = (size_t)(tap * 2 + cc) * a.wp_rows;
+      const size_t chunk_row0 = (size_t)(tap * NCH + cc) * a.wp_rows;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const uint4 w = *reinterpret_cast<const uint4*>(wp + (chunk_row0 + (2 * wave + t) * 16 + fi) * 32 + fg * 8);
+      for (int t = 0; t < TPW; ++t) {
+        const uint4 w = *reinterpret_cast<const uint4*>(wp + (chunk_row0 + (TPW * wave + t) * 16 + fi) * 32 + fg * 8);
         // the patch plan packs odd 16-byte k pieces with their halves swapped (PackDesc::kswap, for conv_patch3.hip's 8-byte fragment
         // reads); this kernel reads whole pieces: natural order
         W[U][t] = (fg & 1) ? make_uint4(w.z, w.w, w.x, w.y) : w;
       }
     }
   }
-  const int c0 = 32 * wave + 8 * fg;            // the 8 consecutive output channels this lane finishes for pixel fi of a 16-pixel row
-  float bia[8];
+  // the 4 TPW consecutive output channels this lane finishes for pixel fi of a 16-pixel row (row permutation of the packed weights:
+  // tile T of a 64-row block, accumulator rows 4 fg .. 4 fg + 3 -> channels 32 (T >> 1) + 8 fg + 4 (T & 1) + e)
+  const int c0 = TPW == 2 ? 32 * wave + 8 * fg : 64 * (wave >> 2) + 32 * ((wave >> 1) & 1) + 8 * fg + 4 * (wave & 1);
+  constexpr int NV = 4 * TPW;                   // values per lane and pixel; NV / 2 packed registers
+  float bia[NV];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bia[e] = a.bias ? a.bias[c0 + e] : 0.f;
+  for (int e = 0; e < NV; ++e) bia[e] = a.bias ? a.bias[c0 + e] : 0.f;
 
   // B fragment lane offsets per column shift pc.  A patch pixel is 64 bytes per chunk; piece p of patch column px lies in slot
   // p ^ ((px >> 1) & 3): with that swizzle the 16 lanes of every ds_read_b128 service group ({0-3, 12-15, 20-27}, ...) hit 16 distinct
@@ -121,15 +132,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
     const int pp = (wave + NW * j) * 16 + (lane >> 2);
     ppy[j] = pp < NPATCH ? pp / PW : 1 << 20;            // (rows beyond the patch: never inside the image)
     ppx[j] = pp % PW;
-    prel[j] = pp < NPATCH ? (ppy[j] * a.Win + ppx[j]) * 128 + (((lane & 3) ^ ((ppx[j] >> 1) & 3)) * 8) * (int)sizeof(bf16) : 0;
+    prel[j] = pp < NPATCH ? (ppy[j] * a.Win + ppx[j]) * (CIN * 2) + (((lane & 3) ^ ((ppx[j] >> 1) & 3)) * 8) * (int)sizeof(bf16) : 0;
   }
 
-  __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * 64 * sizeof(bf16)));
+  __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * CIN * sizeof(bf16)));
   const int tiles_x = a.Wg / TW, tpi = tiles_x * (a.Hg / TH);
   const bf16* refp = reinterpret_cast<const bf16*>(a.ref);
   bf16* Yp = reinterpret_cast<bf16*>(a.Y);
   bf16* Pp = reinterpret_cast<bf16*>(a.pool_out);
-  constexpr int NST = (STORE ? TH : 0) + (POOL ? TH / 2 : 0);       // store instructions per tile and wave
+  constexpr int NSTY = TH * 16 * CB / 1024 / NW;                     // 1 KB store instructions of the staged tile per wave (2 TPW)
+  constexpr int NST = (STORE ? NSTY : 0) + (POOL ? TH / 2 : 0);      // store instructions per tile and wave
 
   // XCD-aware tile order: blocks go round-robin over the 8 XCDs, so each XCD takes a contiguous run of every round's tiles and the
   // halo rows / columns of neighbouring tiles meet in one L2
@@ -142,15 +154,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
   auto issue_patch = [&](int t, int buf) {
     const int n = t / tpi, rem = t - n * tpi;
     const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
-    const int base = ((n * a.Hin + y0 + dh0) * a.Win + x0 + dw0) * 64 * (int)sizeof(bf16);
+    const int base = ((n * a.Hin + y0 + dh0) * a.Win + x0 + dw0) * CIN * (int)sizeof(bf16);
 #pragma unroll
     for (int j = 0; j < JP; ++j) {
       const int ih = y0 + dh0 + ppy[j], iw = x0 + dw0 + ppx[j];
       const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
       const unsigned vo = ok ? (unsigned)(base + prel[j]) : DMA_OOB;
       uint4* l0 = reinterpret_cast<uint4*>(smem + buf * BUFB) + (wave + NW * j) * 64;
-      dma16_buf(rsX, vo, 0u, l0);
-      dma16_buf(rsX, vo, 64u, l0 + PBUFB / 16);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) dma16_buf(rsX, vo, (unsigned)(c * 64), l0 + c * (PBUFB / 16));
     }
   };
 
@@ -168,12 +180,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
     asm volatile("" ::: "memory");
     const int n = t / tpi, rem = t - n * tpi;
     const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
-    const size_t off00 = ((size_t)(n * a.Hof + y0) * a.Wof + x0 + fi) * (32 * NW) + c0;     // elements; tile row r: + r * Wof * 32 NW
+    const size_t off00 = ((size_t)(n * a.Hof + y0) * a.Wof + x0 + fi) * COUT + c0;          // elements; tile row r: + r * Wof * COUT
     // backward-data: the reference rows of the tile, requested BEFORE the next patch so that they return first (loads retire in order)
-    uint4 rz[TH];
+    unsigned rz[TH][NV / 2];
     if constexpr (REF) {
 #pragma unroll
-      for (int r = 0; r < TH; ++r) rz[r] = *reinterpret_cast<const uint4*>(refp + off00 + (size_t)r * a.Wof * (32 * NW));
+      for (int r = 0; r < TH; ++r) {
+        if constexpr (NV == 8) {
+          const uint4 z = *reinterpret_cast<const uint4*>(refp + off00 + (size_t)r * a.Wof * COUT);
+          rz[r][0] = z.x; rz[r][1] = z.y; rz[r][NV / 2 - 2] = z.z; rz[r][NV / 2 - 1] = z.w;
+        } else {
+          const uint2 z = *reinterpret_cast<const uint2*>(refp + off00 + (size_t)r * a.Wof * COUT);
+          rz[r][0] = z.x; rz[r][1] = z.y;
+        }
+      }
     }
     if (t + G < ntiles && (!(C64_ABL & 1) || it < 1)) issue_patch(t + G, buf ^ 1);
     int tb[3];
@@ -183,12 +203,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
     // ---- the MFMAs of the tile: 36 fragment steps.  Step (cc, pc, R) reads ONE B fragment - patch row R, column shift pc, chunk cc - and
     // feeds it to every tile row r it belongs to (patch position pr = R - r in 0..2): 2 .. 6 MFMAs per read, 144 per tile and wave,
     // 36 fragment reads instead of the 72 of a row-by-row schedule.  Fragments are read LA steps ahead (LA + 1 register sets) ----
-    f32x4 acc[TH][2];
+    f32x4 acc[TH][TPW];
 #pragma unroll
     for (int r = 0; r < TH; ++r)
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) acc[r][tt] = (f32x4){bia[4 * tt], bia[4 * tt + 1], bia[4 * tt + 2], bia[4 * tt + 3]};
-    constexpr int LA = C64_LA, NS = LA + 1, NSTEP = 2 * 3 * PH;
+      for (int tt = 0; tt < TPW; ++tt) acc[r][tt] = (f32x4){bia[4 * tt], bia[4 * tt + 1], bia[4 * tt + 2], bia[4 * tt + 3]};
+    constexpr int LA = C64_LA, NS = LA + 1, NSTEP = NCH * 3 * PH;
     u32x4 rb[NS];
     auto rd = [&](auto sc) {
       constexpr int S = decltype(sc)::value, cc = S / (3 * PH), pc = (S / PH) % 3, R = S % PH;
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
         if constexpr (r >= 0 && r < TH) {
           constexpr int U = cc * 9 + (R - r) * 3 + pc;
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) { if (!(C64_ABL & 4)) acc[r][tt] = mma16<bf16>(W[U][tt], fb, acc[r][tt]); else acc[r][tt][0] += __uint_as_float(fb.x ^ W[U][tt].x); }
+          for (int tt = 0; tt < TPW; ++tt) { if (!(C64_ABL & 4)) acc[r][tt] = mma16<bf16>(W[U][tt], fb, acc[r][tt]); else acc[r][tt][0] += __uint_as_float(fb.x ^ W[U][tt].x); }
         }
       }, std::make_integer_sequence<int, 3>{});
       __builtin_amdgcn_sched_barrier(0);
@@ -217,42 +237,41 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
 
     // ---- epilogue: (the bias is in the accumulators) rounding, relu, relu'(reference), one 16-byte store per lane and row, 2x2 max pool -
     // on PACKED bf16 pairs: 4 registers per row ----
-    uint4 pk[TH];
+    unsigned pk[TH][NV / 2];
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
-      float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = acc[r][e >> 2][e & 3];
-      pk[r] = Elem<bf16>::pack(v);
-      if constexpr (RELU) { pk[r].x = pk_max_i16(pk[r].x, 0u); pk[r].y = pk_max_i16(pk[r].y, 0u); pk[r].z = pk_max_i16(pk[r].z, 0u); pk[r].w = pk_max_i16(pk[r].w, 0u); }
-      if constexpr (REF) {
+      for (int e = 0; e < NV / 2; ++e) {
+        unsigned o = Elem<bf16>::pack2(acc[r][(2 * e) >> 2][(2 * e) & 3], acc[r][(2 * e + 1) >> 2][(2 * e + 1) & 3]);
+        if constexpr (RELU) o = pk_max_i16(o, 0u);
         // relu'(reference) per 16-bit half: min(max(ref as int16, 0), 1) is 1 exactly for a positive bf16; times the output's bits
-        auto mask = [](unsigned o, unsigned z) { return pk_mul_lo_u16(o, pk_min_u16(pk_max_i16(z, 0u), 0x00010001u)); };
-        pk[r].x = mask(pk[r].x, rz[r].x); pk[r].y = mask(pk[r].y, rz[r].y); pk[r].z = mask(pk[r].z, rz[r].z); pk[r].w = mask(pk[r].w, rz[r].w);
+        if constexpr (REF) o = pk_mul_lo_u16(o, pk_min_u16(pk_max_i16(rz[r][e], 0u), 0x00010001u));
+        pk[r][e] = o;
       }
     }
     if constexpr (STORE) {
-      // The two waves of a block hold the two 64-byte halves of every output pixel; written from the registers a store instruction would
-      // touch sixteen 64-byte half lines.  The tile goes through 8 KB of LDS instead (16-byte slot s of pixel px at slot s ^ (px & 7):
-      // conflict-free b128 writes and reads) and wave w stores tile rows 2w, 2w + 1 as whole 128-byte lines, 1 KB contiguous per instruction
+      // The waves of a block hold 32-byte (TPW 1: 8-byte ...) slices of every output pixel; written from the registers a store instruction
+      // would touch sixteen partial lines.  The tile goes through LDS instead (16-byte slot s of pixel px at slot s ^ (px & 7):
+      // conflict-free writes and b128 reads) and leaves as whole pixels, 1 KB contiguous per store instruction
       char* stg = smem + 2 * BUFB;
       constexpr int SPP = CB / 16;                   // 16-byte slots per pixel (8, 16)
 #pragma unroll
-      for (int r = 0; r < TH; ++r)
-        *reinterpret_cast<uint4*>(stg + (r * 16 + fi) * CB + (((4 * wave + fg) ^ (fi & 7)) << 4)) = pk[r];
+      for (int r = 0; r < TH; ++r) {
+        char* q = stg + (r * 16 + fi) * CB + ((((c0 * 2) >> 4) ^ (fi & 7)) << 4) + ((c0 * 2) & 15);
+        if constexpr (NV == 8) *reinterpret_cast<uint4*>(q) = make_uint4(pk[r][0], pk[r][1], pk[r][NV / 2 - 2], pk[r][NV / 2 - 1]);
+        else *reinterpret_cast<uint2*>(q) = make_uint2(pk[r][0], pk[r][1]);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (a raw s_barrier does not wait for this wave's LDS writes)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (!(C64_ABL & 2) || pk[0].x == 0x12345u) {
-        // TH * 16 pixels x SPP slots = TH * NW / 2 wave-instructions per ... every wave issues TH of them: NW = 2: rows 2w, 2w + 1 in
-        // halves of 8 pixels; NW = 4: row w in quarters of 4 pixels
+      if (!(C64_ABL & 2) || pk[0][0] == 0x12345u) {
 #pragma unroll
-        for (int j = 0; j < TH; ++j) {
+        for (int j = 0; j < NSTY; ++j) {
           constexpr int PPI = 64 / SPP;              // pixels per store instruction (8, 4)
-          const int g = wave * TH + j;               // the block's store instructions, in pixel order
+          const int g = wave * NSTY + j;             // the block's store instructions, in pixel order
           const int pi = g * PPI + lane / SPP, row = pi >> 4, px = pi & 15, sl = lane % SPP;
           const uint4 o = *reinterpret_cast<const uint4*>(stg + (row * 16 + px) * CB + ((sl ^ (px & 7)) << 4));
-          unsigned* yp = reinterpret_cast<unsigned*>(Yp + ((size_t)(n * a.Hof + y0 + row) * a.Wof + x0 + px) * (32 * NW) + sl * 8);
+          unsigned* yp = reinterpret_cast<unsigned*>(Yp + ((size_t)(n * a.Hof + y0 + row) * a.Wof + x0 + px) * COUT + sl * 8);
           __builtin_nontemporal_store(o.x, yp); __builtin_nontemporal_store(o.y, yp + 1);
           __builtin_nontemporal_store(o.z, yp + 2); __builtin_nontemporal_store(o.w, yp + 3);
         }
@@ -261,48 +280,56 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_c64_kernel(const IgemmArgs a,
     if constexpr (POOL) {
 #pragma unroll
       for (int q = 0; q < TH; q += 2) {
-        uint4 m;
-        m.x = pk_max_i16(pk[q].x, pk[q + 1].x); m.y = pk_max_i16(pk[q].y, pk[q + 1].y);
-        m.z = pk_max_i16(pk[q].z, pk[q + 1].z); m.w = pk_max_i16(pk[q].w, pk[q + 1].w);
-        m.x = pk_max_i16(m.x, dpp_xor1(m.x)); m.y = pk_max_i16(m.y, dpp_xor1(m.y));
-        m.z = pk_max_i16(m.z, dpp_xor1(m.z)); m.w = pk_max_i16(m.w, dpp_xor1(m.w));
+        unsigned m[NV / 2];
+#pragma unroll
+        for (int e = 0; e < NV / 2; ++e) {
+          m[e] = pk_max_i16(pk[q][e], pk[q + 1][e]);
+          m[e] = pk_max_i16(m[e], dpp_xor1(m[e]));
+        }
         if (!(fi & 1)) {
-          const size_t po = ((size_t)(n * (a.Hg >> 1) + ((y0 + q) >> 1)) * (a.Wg >> 1) + ((x0 + fi) >> 1)) * 64 + c0;
-          *reinterpret_cast<uint4*>(Pp + po) = m;
+          const size_t po = ((size_t)(n * (a.Hg >> 1) + ((y0 + q) >> 1)) * (a.Wg >> 1) + ((x0 + fi) >> 1)) * COUT + c0;
+          if constexpr (NV == 8) *reinterpret_cast<uint4*>(Pp + po) = make_uint4(m[0], m[1], m[NV / 2 - 2], m[NV / 2 - 1]);
+          else *reinterpret_cast<uint2*>(Pp + po) = make_uint2(m[0], m[1]);
         }
       }
     }
   }
 }
 
-// what the kernel handles: a patch-plan 3x3 (conv_ops.h plan_make_patch: permuted rows, kswap) from one 64-channel tensor to 64 channels,
-// (or 128: forward without pooling only), plain store (no batch statistics, no accumulation, no affine on the reference), image sides
-// multiples of the 4 x 16 tile
+// what the kernel handles: a patch-plan 3x3 (conv_ops.h plan_make_patch: permuted rows, kswap) from ONE tensor of 64 channels to 64 / 128 or
+// of 128 channels to 64 / 128, plain store (no batch statistics, no accumulation, no affine on the reference), relu / no activation,
+// optional fused 2x2 max pool of relu outputs, optional relu'(reference) product, image sides multiples of the 4 x 16 tile
 bool conv_c64_eligible(const IgemmArgs& a, int is_bf16) {
   if (!is_bf16 || a.patch != 1 || !patch3_eligible(a, 1)) return false;
-  if ((a.Cout != 64 && a.Cout != 128) || a.CoutPad != a.Cout || a.ldY != a.Cout || a.Cin != 64 || a.x.C[0] != 64 || !a.rowperm || a.splitk != 1) return false;
-  if (a.Cout == 128 && (a.ref || a.pool_out)) return false;
+  if ((a.Cin != 64 && a.Cin != 128) || a.x.C[0] != a.Cin || (a.Cout != 64 && a.Cout != 128)) return false;
+  if (a.CoutPad != a.Cout || a.ldY != a.Cout || !a.rowperm || a.splitk != 1) return false;
   if (a.Hg % TH || a.Wg % TW || a.Hin != a.Hg || a.Win != a.Wg || a.Hof != a.Hg || a.Wof != a.Wg) return false;
   if ((a.out_act != ACT_NONE && a.out_act != ACT_RELU) || (a.ref && (a.ref_act != ACT_RELU || a.out_act != ACT_NONE || a.pool_out))) return false;
   if (a.pool_out && (a.out_act != ACT_RELU || (a.Hg & 1))) return false;
   if (a.pool_only && !a.pool_out) return false;
   if (a.bn_part || a.accumulate || a.y_f32 || a.ref_a || a.split_c || a.x.aff_a[0] || a.x.act != ACT_NONE) return false;
   if (a.p_dhs != a.p_dws || a.p_dhf != a.p_dwf || a.p_dhf != (a.p_dhs > 0 ? -1 : 1)) return false;          // pad 1
-  return true;
+  return (size_t)a.N * a.Hin * a.Win * a.Cin * 2 < 0x70000000ull;
+}
+
+template <int NCH, int TPW, int NW>
+static hipError_t launch_c64_t(const IgemmArgs& a, hipStream_t st) {
+  const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);
+  void (*kern)(const IgemmArgs, const int);
+  if (a.ref) kern = conv_c64_kernel<NCH, TPW, NW, true, false, false, true>;
+  else if (a.pool_out) kern = a.pool_only ? conv_c64_kernel<NCH, TPW, NW, false, true, true, false> : conv_c64_kernel<NCH, TPW, NW, false, true, true, true>;
+  else kern = a.out_act == ACT_RELU ? conv_c64_kernel<NCH, TPW, NW, false, true, false, true> : conv_c64_kernel<NCH, TPW, NW, false, false, false, true>;
+  // LDS: two patch buffers + the output staging tile; blocks per CU: 8 / NW (two waves per SIMD) - all of them fit (40 .. 80 KB each)
+  const int smem = 2 * NCH * PBUFB + TH * 16 * (16 * TPW * NW * 2);
+  const int blocks = 256 * (8 / NW);
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipLaunchKernelGGL(kern, dim3(ntiles < blocks ? ntiles : blocks), dim3(NW * 64), smem, st, a, ntiles);
+  return hipGetLastError();
 }
 
 hipError_t launch_conv_c64(const IgemmArgs& a, hipStream_t st) {
-  const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);
-  void (*kern)(const IgemmArgs, const int);
-  const int nw = a.Cout / 32;
-  if (nw == 4) kern = a.out_act == ACT_RELU ? conv_c64_kernel<4, false, true, false, true> : conv_c64_kernel<4, false, false, false, true>;
-  else if (a.ref) kern = conv_c64_kernel<2, true, false, false, true>;
-  else if (a.pool_out) kern = a.pool_only ? conv_c64_kernel<2, false, true, true, false> : conv_c64_kernel<2, false, true, true, true>;
-  else kern = a.out_act == ACT_RELU ? conv_c64_kernel<2, false, true, false, true> : conv_c64_kernel<2, false, false, false, true>;
-  // LDS: two patch buffers + the output staging tile (40 / 48 KB); blocks per CU: 4 two-wave / 2 four-wave blocks (2 waves per SIMD)
-  const int grid2 = ntiles < 2048 / nw ? ntiles : 2048 / nw;
-  hipLaunchKernelGGL(kern, dim3(grid2), dim3(nw * 64), 2 * BUFB + TH * 16 * nw * 64, st, a, ntiles);
-  return hipGetLastError();
+  if (a.Cin == 64) return a.Cout == 64 ? launch_c64_t<2, 2, 2>(a, st) : launch_c64_t<2, 2, 4>(a, st);
+  return a.Cout == 64 ? launch_c64_t<4, 1, 4>(a, st) : launch_c64_t<4, 1, 8>(a, st);
 }
 
 }  // namespace vp
