@@ -24,7 +24,7 @@ for n, h in ((8, 256), (8, 512), (2, 512)):
 for n, h in ((1, 512), (8, 512), (1, 256)):
   eng = PixReferEngine(n, h, 64, 64, dtype="bf16", training=False, per_sample_bn=True); eng.load_params(eng.random_params(0))
   b = bench.synth_batch(n, h, 1, torch.device("cuda"))
-  dt = timed(lambda: eng.forward(b[0], b[1], b[2]), 10, 30)
+  dt = timed(lambda: eng.forward(b[0], b[1], b[2]), 50, 30)      # (the first calls of a process load the code objects of kernels no earlier config used: a one-off of milliseconds)
   print(json.dumps({"config": "generator inference bf16 bs=%d %dx%d" % (n, h, h), "ms": dt * 1e3, "frames_per_s": n / dt}))
   del eng; torch.cuda.empty_cache()
 B, T = 64, 25
