@@ -67,6 +67,7 @@ CLASS_CASES = [
     (384, (0, 8, 96, 96, 256, 512, 4, 1, 1, 0, 0, False)),    # 72200 px x 512 ch, K = 4096 (D layer_4 forward): igemm_ws 256x256; its backward-data: patch 256x128
     (1, (0, 2, 64, 64, 128, 128, 4, 2, 1, 0, 0, False)),      # backward-data of a 128 -> 128 stride-2 conv (layer_3 geometry): patch2 128x256
     (384, (0, 2, 8, 8, 64, 128, 4, 2, 1, 0, 0, False)),       # 4 x 4 output grid (fewer than 32 K slots per image): the generic wgrad_tr 256x128
+    (384, (0, 8, 128, 128, 64, 128, 4, 2, 1, 0, 0, False)),   # 512 tiles of 4 x 16 pixels (layer_2 / encoder_2 forward from 8 frames): register-resident weights, conv_s2c64.hip
 ]
 
 
@@ -224,6 +225,21 @@ def _profile_classes(fn):
   finally:
     L.vp_profile_enable(0)
   return {r["name"] for r in json.loads(buf.value.decode())}
+
+
+@pytest.mark.parametrize("case", [(0, 2, 128, 128, 64, 128, 4, 2, 1, 0, 0, False),     # one tile per block, half the CUs
+                                  (0, 3, 32, 64, 64, 128, 4, 2, 1, 0, 0, False),       # 16 x 32 output grid: 24 tiles; image borders in most patches
+                                  (0, 5, 64, 160, 64, 128, 4, 2, 1, 0, 0, False)])     # 400 tiles on 256 blocks: a second trip for some, grid not a multiple of 8 x tiles
+def test_stride2_conv_with_register_resident_weights(case):
+  """conv_s2c64.hip below its default size threshold (vp_tune("s2c64", tiles): the smallest launch it takes): parity with the oracle as
+  test_conv_fwd, and the profile shows it is what ran."""
+  L = _lib.lib()
+  L.vp_tune(b"s2c64", 1)
+  try:
+    classes = _profile_classes(lambda: test_conv_fwd(case, "bf16"))
+  finally:
+    L.vp_tune(b"s2c64", 512)
+  assert any(c.startswith("s2c64_") for c in classes), classes
 
 
 def test_thin_layer_cases_run_on_their_dedicated_kernels():

@@ -378,6 +378,46 @@ def test_transposed_conv_classes_with_register_resident_weights_in_situ():
 
 
 @pytest.mark.gpu
+def test_stride2_convs_with_register_resident_weights_and_block_statistics_in_situ():
+  """The 64 -> 128 stride-2 convolutions in front of a batch-norm (encoder_2, encoder_fg_2, discriminator layer_2 with its three
+  batch-norm groups) on conv_s2c64.hip (forced below its size threshold: vp_tune("s2c64", 1)): raw outputs, and the batch-norm scale /
+  shift / mean / rstd formed from the per-block partial rows - group boundaries inside a block's tile walk, blocks that never see a
+  group - against the generic kernel + its per-tile statistics (vp_tune("s2c64", 0)), and the gradients downstream."""
+  from voicepuppet_amd import _lib
+  L = _lib.lib()
+  n = 2
+  got, grads = {}, {}
+  names = [net + f for net in ("g/encoder_2", "g/encoder_fg_2", "d/layer_2") for f in ("", ":scale", ":shift", ":mean", ":rstd")]
+  for on in (1, 0):
+    L.vp_tune(b"s2c64", on)
+    try:
+      eng = PixReferEngine(n, 256, 64, 64, dtype="bf16", training=True)
+      eng.load_params(eng.random_params(5))
+      g = torch.Generator(device="cpu").manual_seed(9)
+      batch = [torch.rand(n, 256, 256, c, generator=g).cuda() for c in (6, 6, 3, 3)]
+      eng.profile(1)
+      eng.forward(*batch); eng.backward()
+      torch.cuda.synchronize()
+      classes = {r["name"] for r in eng.profile_collect()}
+      eng.profile(0)
+      assert any(c.startswith("s2c64_") for c in classes) == bool(on), classes
+      got[on] = {k: eng.tensor(k).float().cpu().numpy() for k in names}
+      grads[on] = (eng.grads_d.clone(), eng.grads_g.clone())
+      del eng
+    finally:
+      L.vp_tune(b"s2c64", 512)
+  for k in names:
+    assert np.isfinite(got[1][k]).all() and np.abs(got[1][k]).max() > 0, k
+    tol = 4e-3 if ":" not in k else 1e-3
+    assert gu.rel_l2(got[1][k], got[0][k]) < tol, (k, gu.rel_l2(got[1][k], got[0][k]))
+  rel = lambda x, y: float((x - y).norm() / y.norm())
+  # a different K-sum order in three FORWARD layers moves every rounding downstream: the generator's bf16 gradients answer a rounding-level
+  # change of the activations with a few per cent (they sit 0.3-0.4 from the float64 graph whatever is stored how: EXPERIMENTS.md 0.1 of
+  # round 4; measured here 0.058), the discriminator's with < 1 %
+  assert rel(grads[1][0], grads[0][0]) < 2e-2 and rel(grads[1][1], grads[0][1]) < 0.15, (rel(grads[1][0], grads[0][0]), rel(grads[1][1], grads[0][1]))
+
+
+@pytest.mark.gpu
 def test_forward_is_hipgraph_capturable():
   """The library's launch sequence is fixed, allocates nothing and never synchronises: one inference forward captured
   into a hipGraph replays to the identical output (the claim of DESIGN.md section 2)."""

@@ -727,7 +727,7 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
 //     32+8q..32+8q+7 of its pixel: two 16-byte stores per lane, and the four lanes of a pixel write 64 contiguous bytes per store;
 //   * each wave walks 16-pixel tiles with the next tile's pieces in flight (double-buffered fragments).
 // ------------------------------------------------------------------------------------------------
-template <int S>
+template <int S, bool ACTS>   // ACTS: also write the consumers' activations (xa_lrelu / xa_relu) - its own instantiation: the stores' code costs the plain form registers
 __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int lgW, int lgH) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
   __shared__ uint4 otile[4 * 16 * 144 / 16];
   // output rows are dense ([pixel][64]) and the pixel grid is the output grid: a tile's 16 pixels are one 2 KB run
   // (measured: conv1_1, stride 1, 64 images: 0.209 -> 0.178 ms; the stride-2 first layers, a quarter of the output, lose 8 us each)
-  const bool rowrun = a.sh == 1 && a.ldY == 64 && a.Hof == (1 << lgH) && a.Wof == (1 << lgW) && (P & 15) == 0 && !a.xa_lrelu && !a.xa_relu;
+  const bool rowrun = a.sh == 1 && a.ldY == 64 && a.Hof == (1 << lgH) && a.Wof == (1 << lgW) && (P & 15) == 0 && !ACTS;
   {
     const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
     for (int idx = threadIdx.x; idx < S * 4 * 64; idx += 256) {
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
     reinterpret_cast<uint4*>(yp)[0] = Elem<bf16>::pack(lo);
     reinterpret_cast<uint4*>(yp + 32)[0] = Elem<bf16>::pack(hi);
     // the consumers' activations of the ROUNDED output (what act_apply computes from the stored tensor: same bits)
-    if (a.xa_lrelu || a.xa_relu) {
+    if constexpr (ACTS) {
       float rl[8], rh[8];
       Elem<bf16>::unpack(Elem<bf16>::pack(lo), rl);
       Elem<bf16>::unpack(Elem<bf16>::pack(hi), rh);
@@ -1780,8 +1780,14 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       int lgW = 0, lgH = 0;
       while ((1 << lgW) < a.Wg) ++lgW;
       while ((1 << lgH) < a.Hg) ++lgH;
-      if (a.Kpad == 96) hipLaunchKernelGGL((conv_cin8_kernel<3>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
-      else hipLaunchKernelGGL((conv_cin8_kernel<4>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+      const bool acts = a.xa_lrelu || a.xa_relu;
+      if (a.Kpad == 96) {
+        if (acts) hipLaunchKernelGGL((conv_cin8_kernel<3, true>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+        else hipLaunchKernelGGL((conv_cin8_kernel<3, false>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+      } else {
+        if (acts) hipLaunchKernelGGL((conv_cin8_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+        else hipLaunchKernelGGL((conv_cin8_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+      }
       return hipGetLastError();
     }
   }
@@ -1877,6 +1883,17 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       return launch_conv_dc64(a, st);
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    // 4x4 stride-2 conv from 64 to 128 channels in front of a batch-norm (layer_2 / encoder_2 / encoder_fg_2 forward): weights resident
+    // in registers, parity-split input patch, batch statistics per block (conv_s2c64.hip)
+    if (a.patch == 4) {
+      if (!conv_s2c64_eligible(a, 1)) return hipErrorInvalidValue;       // (a plan for this kernel runs on no other: fail loudly)
+      ProfScope prof("s2c64", true, 128, 64, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+      return launch_conv_s2c64(a, st);
+    }
+  }
+  if (a.patch == 4) return hipErrorInvalidValue;
   if (a.patch) {   // stride-1 convs with the input patch staged once per channel chunk (conv_patch.hip)
     // class name per kernel template: patch2 (parity classes, conv_patch2.hip), patch3 (unrolled 3x3, conv_patch3.hip), patch (generic)
     const char* pk = a.patch == 2 ? "patch2" : (patch3_knob() && patch3_eligible(a, sizeof(T) == 2) ? "patch3" : "patch");

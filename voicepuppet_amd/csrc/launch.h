@@ -17,6 +17,10 @@ bool conv_c64_eligible(const IgemmArgs& a, int is_bf16);                        
 hipError_t launch_conv_c64(const IgemmArgs& a, hipStream_t st);
 bool conv_dc64_eligible(const IgemmArgs& a, int is_bf16);                                                           // conv_dc64.hip
 hipError_t launch_conv_dc64(const IgemmArgs& a, hipStream_t st);
+bool conv_s2c64_eligible(const IgemmArgs& a, int is_bf16);                                                          // conv_s2c64.hip
+int conv_s2c64_grid(const IgemmArgs& a);                   // blocks of the launch = partial rows per batch-norm group
+int conv_s2c64_tiles_per_image(const IgemmArgs& a);
+hipError_t launch_conv_s2c64(const IgemmArgs& a, hipStream_t st);
 hipError_t launch_igemm_patch2(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                   // conv_patch2.hip
 hipError_t launch_igemm_smallp(const IgemmArgs& a, int is_bf16, hipStream_t st);                                   // conv_smallp.hip (plain epilogue)
 struct SmallPArgs;

@@ -67,6 +67,7 @@ int vp_tune(const char* key, int value) {
   if (k == "patch3") { patch3_knob() = value; return VP_OK; }
   if (k == "c64") { c64_knob() = value; return VP_OK; }
   if (k == "dc64") { dc64_knob() = value; return VP_OK; }
+  if (k == "s2c64") { s2c64_knob() = value; return VP_OK; }
   if (k == "patch2") { patch2_knob() = value; return VP_OK; }
   if (k == "patch_xcd") { patch_xcd_knob() = value; return VP_OK; }
   if (k == "smallp_max_pixels") { smallp_knob() = value; return VP_OK; }
@@ -124,6 +125,7 @@ int vp_conv_fwd(const vp_conv_desc* d, const void* x, const float* in_scale, con
   if (d->in_act == ACT_NONE && !in_scale && plan_smallp_eligible(p, g.Cout, bf, d->cin, 0)) plan_make_smallp(p, g.Cout, bf);
   else if (d->in_act == ACT_NONE && !in_scale && plan_patch_eligible(p, g.Cout, bf, true)) plan_make_patch(p, g.Cout, bf);
   else if (d->in_act == ACT_NONE && !in_scale && plan_patch2_eligible(p, g.Cout, bf, d->cin, 0)) plan_make_patch2(p, g.Cout, bf);
+  else if (d->in_act == ACT_NONE && !in_scale && d->out_act == ACT_NONE && plan_s2c64_eligible(p, g.Cout, bf, d->cin, 0)) plan_make_s2c64(p);
   char* ws = (char*)workspace;
   VP_HIP_CHECK(launch_pack_weights_one(p.pack, w, ws, bf, st));
   IgemmArgs a = p.a;

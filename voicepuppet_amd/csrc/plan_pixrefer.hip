@@ -313,6 +313,8 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
         plan_make_smallp(L.fwd, L.g.Cout, bf16);
       else if (plan_patch_eligible(L.fwd, L.g.Cout, bf16, L.nsrc == 1 && n.t[L.src[0]].C == L.g.Cin)) plan_make_patch(L.fwd, L.g.Cout, bf16);
       else if (plan_patch2_eligible(L.fwd, L.g.Cout, bf16, n.t[L.src[0]].C, L.nsrc > 1 ? n.t[L.src[1]].C : 0)) plan_make_patch2(L.fwd, L.g.Cout, bf16);
+      else if (L.has_bn && L.out_act == ACT_NONE && !L.tapgemm && plan_s2c64_eligible(L.fwd, L.g.Cout, bf16, n.t[L.src[0]].C, L.nsrc > 1 ? n.t[L.src[1]].C : 0))
+        plan_make_s2c64(L.fwd);
     }
     take(L.fwd);
     L.pk_fwd = L.fwd.pack.dst_off;
@@ -678,7 +680,15 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
   // batch statistics from the conv epilogue (no re-read of the output) when every pixel tile lies inside one BN group
   bool fused_stats = false;
   int stat_chunks = 0;
-  if (L.has_bn && a.splitk == 1 && L.g.Cout % 8 == 0 && a.ldY % 8 == 0 && !a.y_f32) {
+  if (L.has_bn && a.patch == 4) {
+    // conv_s2c64.hip: one partial row per block and group
+    const int grid = conv_s2c64_grid(a);
+    if ((size_t)n.groups * grid * 2 * to.C <= (size_t)1024 * 2 * 512 && n.groups <= 32) {
+      stat_chunks = grid;
+      a.bn_part = bnp_of(h, ss); a.bn_tpg = (n.batch / n.groups) * conv_s2c64_tiles_per_image(a); a.bn_nchunk = grid;
+      fused_stats = true;
+    }
+  } else if (L.has_bn && a.splitk == 1 && L.g.Cout % 8 == 0 && a.ldY % 8 == 0 && !a.y_f32) {
     int bc, bp;
     igemm_tile(L.fwd.cfg, &bc, &bp);
     const int pg = (n.batch / n.groups) * a.Hg * a.Wg;            // pixels of one group, per class
