@@ -132,3 +132,30 @@ def test_background_batch_thread_is_reproducible_and_stops(monkeypatch):
   while names() and time.time() - t0 < 5:
     time.sleep(0.1)
   assert not names()
+
+
+def test_two_iterators_over_one_generator_do_not_share_draws(monkeypatch):
+  """the private random.Random lives on the ITERATOR (not on the shared DataGenerator): a second iterator over the same
+  owner neither inherits nor overwrites the first one's generator, and making an iterator leaves the module-level stream of a caller
+  that seeded it untouched."""
+  import random
+  monkeypatch.setattr(BFMNetDataGenerator, "process_data", lambda self, c, e, p, n: (c, e, p, n))
+  random.seed(7)
+  g = BFMNetDataGenerator(CFG)
+  prm = g.params
+  prm.dataset_path = "/nonexistent/train.txt"
+  prm.batch_size = 2
+  prm.shuffle_bufsize = 1
+  g.set_params(prm)
+  ds = g.get_dataset()
+  state = random.getstate()
+  it1 = ds.make_one_shot_iterator()
+  assert random.getstate() == state                      # no draw from the caller's stream
+  first = it1.next_batch()[0].copy()
+  it2 = ds.make_one_shot_iterator()                      # same module state -> same seed -> the same clips, from its OWN generator
+  second = it2.next_batch()[0].copy()
+  np.testing.assert_array_equal(first, second)
+  assert it1._rand is not it2._rand and not hasattr(g, "_private_random")
+  nxt1, nxt2 = it1.next_batch()[0], it2.next_batch()[0]  # both continue their own sequence
+  np.testing.assert_array_equal(nxt1, nxt2)
+  it1.close(); it2.close()

@@ -387,7 +387,7 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       const int c0 = n.t[L.src[0]].C, c1 = L.nsrc > 1 ? n.t[L.src[1]].C : 0;
       if (L.nsrc == 2 && n.groups == 1 && alt_batch == 0 && L.need_bwd[0] && L.need_bwd[1] && c0 == c1 && !n.t[L.src[0]].is_input &&
           !n.t[L.src[1]].is_input && L.bwd[0].a.patch == L.bwd[1].a.patch && (L.bwd[0].a.patch == 0 || L.bwd[0].a.patch == 3) &&
-          L.g.Cin_real == c0 + c1) {
+          L.g.Cin_real == c0 + c1 && c0 % 32 == 0) {     // (the two-output epilogues split at a 32-channel tile boundary: conv_smallp.hip, epi_store8)
         L.bwd_pair = plan_bwd_data(L.g, L.w_off, 0, c0 + c1, c0 + c1, c0, bf16);
         bool ok = true;
         if (L.bwd[0].a.patch == 3) {      // few-pixel layers: the pair runs on the few-pixel kernel too (first output with its batch-norm backward)
@@ -420,6 +420,11 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       for (Layer& L : n.l)
         for (int s = 0; s < L.nsrc; ++s)
           if (L.need_bwd[s] && L.bwd[s].a.patch != 3) n.t[L.src[s]].hi = false;
+    // a consumer without an input activation reads the tensor's raw storage as T (fill_src): such a tensor stays T (no consumer of a
+    // batch-normalised tensor of the reference's nets does - a plan-time rule instead of a misread at run time)
+    for (Layer& L : n.l)
+      for (int s = 0; s < L.nsrc; ++s)
+        if (L.in_act == ACT_NONE) n.t[L.src[s]].hi = false;
   }
   for (size_t i = 0; i < n.l.size(); ++i) n.l[i].desc1 = i + 1 < n.l.size() ? n.l[i + 1].desc0 : n.descs.size();
   for (Tens& t : n.t) t.n_bwd_consumers = 0;

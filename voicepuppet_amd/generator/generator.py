@@ -170,14 +170,8 @@ class BFMNetDataGenerator(DataGenerator):
         pcm = np.pad(pcm, (0, pcm_start + pcm_length - pcm.shape[0]), 'constant', constant_values=(0))
       yield bfmcoeff_slice, ear_slice.astype(np.float32), pcm[pcm_start: pcm_start + pcm_length].astype(np.float32), bfmcoeff_slice.shape[0]
 
-  def _rand(self):
-    """The source of the order-defining draws (shuffle of the file list, seed of the synthetic clips): the module-level `random`,
-    or - once a background batch thread exists (_MfccIterator) - a private random.Random that was seeded FROM the module-level state
-    on the caller's thread, so the sample order is a function of random.seed() alone, whatever else the main thread draws meanwhile."""
-    return getattr(self, '_private_random', None) or random
-
-  def _synthetic(self):
-    rng = np.random.default_rng(self._rand().randint(0, 2 ** 31))
+  def _synthetic(self, rand=random):
+    rng = np.random.default_rng(rand.randint(0, 2 ** 31))
     T = self.SLICE
     n = self.pcm_length(T)
     t = np.arange(n) / self.sample_rate
@@ -188,15 +182,18 @@ class BFMNetDataGenerator(DataGenerator):
       pcm = (0.3 * np.sin(2 * np.pi * f0 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.02 * rng.normal(size=n)).astype(np.float32)
       yield coeff, rng.uniform(0.6, 0.9, (T, 1)).astype(np.float32), pcm, T
 
-  def iterator(self):
+  def iterator(self, rand=random):
+    """rand: the source of the order-defining draws (shuffle of the file list, seed of the synthetic clips): the module-level `random`
+    as in the reference, or the private random.Random of ONE iterator (_MfccIterator: its background thread must not share a generator
+    with the main thread, nor with another iterator over the same DataGenerator)."""
     if self.data_list is None:
-      for s in self._synthetic():
+      for s in self._synthetic(rand):
         yield s
       return
     bfmcoeff_loader = BFMCoeffLoader()
     landmark_loader = LandmarkLoader(norm_size=1)
     wav_loader = WavLoader(sr=self.sample_rate)
-    self._rand().shuffle(self.data_list)
+    rand.shuffle(self.data_list)
     for line in self.data_list:
       folder, img_count = line.strip().split('|')
       img_count = int(img_count)
@@ -225,7 +222,19 @@ class BFMNetDataGenerator(DataGenerator):
 class _MfccIterator(DatasetIterator):
   def __init__(self, ds):
     DatasetIterator.__init__(self, ds)
-    self._seed = random.getrandbits(64)     # drawn where the iterator is made, on the caller's thread (see _host_batches)
+    # The worker thread's order-defining draws come from a generator of THIS iterator, seeded from the module-level state where the
+    # iterator is made (on the caller's thread) WITHOUT advancing it: the sample order is a function of random.seed() alone, whatever
+    # the main thread or another iterator over the same DataGenerator draws meanwhile, and a caller that seeded `random` keeps its stream
+    self._rand = random.Random(hash(random.getstate()))
+
+  def _samples(self):
+    while True:   # repeat()
+      n = 0
+      for s in self.ds.owner.iterator(self._rand):
+        n += 1
+        yield s
+      if n == 0:
+        raise RuntimeError("the dataset generator yielded nothing")
 
   def get_next(self):
     g, b = self.ds.owner, self.ds.batch_size
@@ -243,8 +252,6 @@ class _MfccIterator(DatasetIterator):
     q = queue.Queue(maxsize=2)
     stop = threading.Event()
     END = object()
-    # the worker's draws come from a generator of its own, seeded from the module-level state when the iterator was made
-    self.ds.owner._private_random = random.Random(self._seed)
     nxt = DatasetIterator.next_batch
     me = weakref.ref(self)                 # the thread must not keep the iterator alive: dropping the iterator stops the thread
 
@@ -388,9 +395,12 @@ class PixReferDataGenerator(DataGenerator):
         return np.concatenate([lo[..., :3], lo[..., 3:] * mask, mask], axis=1).astype(np.float32)
       yield pack_sample(trip(), trip(), S)
 
-  def iterator(self):
+  def iterator(self, rand=random):
+    """rand: the source of the order-defining draws (shuffle of the file list, seed of the synthetic clips): the module-level `random`
+    as in the reference, or the private random.Random of ONE iterator (_MfccIterator: its background thread must not share a generator
+    with the main thread, nor with another iterator over the same DataGenerator)."""
     if self.data_list is None:
-      for s in self._synthetic():
+      for s in self._synthetic(rand):
         yield s
       return
     image_loader = ImageLoader()
