@@ -187,6 +187,7 @@ struct ConvBN {            // conv (or depthwise) + contrib batch_norm
 struct Block {
   int cin, cexp, cout;
   bool pool, shortcut;
+  bool fusable;          // depthwise + projection in one kernel (bfm_dwproj.hip): float32 trunk, mel width <= 20
   ConvBN expand, dw, project, sc;
   Gemm g_expand, g_project, g_sc;
 };
@@ -310,6 +311,8 @@ size_t bfm_carve(vp_bfmnet* h, char* base) {
     const int P = B * h->T5 * W;
     plan_gemm(h, b.g_expand, P, b.cin, b.cexp, 0, b.expand.wf, b.cexp, b.expand.bf, tb);
     plan_gemm(h, b.g_project, P, b.cexp, b.cout, 0, b.project.wf, b.cout, b.project.bf, tb);
+    b.fusable = !tb && dwproj_eligible(W, b.cexp, b.cout);
+    if (b.fusable) { b.g_project.plan.pack.perm = 0; b.g_project.plan.a.rowperm = 0; }     // (the fused kernel reads plain packed rows; the GEMM kernels take either)
     if (b.shortcut) plan_gemm(h, b.g_sc, P, b.cin, b.cout, 0, b.sc.wf, b.cout, b.sc.bf, tb);
     if ((size_t)P * b.cexp > max_exp) max_exp = (size_t)P * b.cexp;
     if ((size_t)P * (b.cin > b.cout ? b.cin : b.cout) > max_net) max_net = (size_t)P * (b.cin > b.cout ? b.cin : b.cout);
@@ -457,13 +460,23 @@ int vp_bfmnet_forward(vp_bfmnet_t* h, const float* ears, const float* mfccs, con
   for (Block& b : m.blocks) {
     const void* xin = operand(cur, b.cin);
     if ((rc = run_gemm(h, b.g_expand, xin, h->ex, ACT_RELU6, 0, st))) return rc;
-    VP_HIP_CHECK(launch_dwconv7x3(h->ex, h->folded + b.dw.wf, h->folded + b.dw.bf, h->dwb, tb, B, H, W, b.cexp, st));
+    // depthwise + projection: one kernel where the block is fusable (the depthwise result never reaches HBM), else two
+    const bool fused = b.fusable && bfm_dwproj_knob();
+    auto dw_project = [&](float* dst) -> int {
+      if (fused) {
+        VP_HIP_CHECK(launch_dwproj(h->ex, h->folded + b.dw.wf, (const float*)(h->packed + b.g_project.pk), b.g_project.plan.a.wp_rows, h->folded + b.project.bf, dst, 1,
+                                   B, H, W, b.cexp, b.cout, st));
+        return VP_OK;
+      }
+      VP_HIP_CHECK(launch_dwconv7x3(h->ex, h->folded + b.dw.wf, h->folded + b.dw.bf, h->dwb, tb, B, H, W, b.cexp, st));
+      return run_gemm(h, b.g_project, h->dwb, dst, ACT_NONE, 1, st, 1);
+    };
     if (b.shortcut) {
       if ((rc = run_gemm(h, b.g_sc, xin, alt, ACT_NONE, 0, st, 1))) return rc;
-      if ((rc = run_gemm(h, b.g_project, h->dwb, alt, ACT_NONE, 1, st, 1))) return rc;
+      if ((rc = dw_project(alt))) return rc;
       float* t = cur; cur = alt; alt = t;
     } else {
-      if ((rc = run_gemm(h, b.g_project, h->dwb, cur, ACT_NONE, 1, st, 1))) return rc;   // residual add in place
+      if ((rc = dw_project(cur))) return rc;   // residual add in place
     }
     if (b.pool) {   // max_pooling2d([2,2], strides [1,2], 'same'): time pad (0,1), mel pad (0, W odd)
       const int Wn = (W + 1) / 2;
