@@ -131,7 +131,9 @@ void* vp_pixrefer_side_stream(vp_pixrefer_t* h);
 int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n);
 /* Schedule options of ONE plan (no reference counterpart: the TF graph has one executor): "overlap" 0 / 1 (the whole step on `stream`
  * / spread over the executor's streams, default 1), "d_backward_fork" 0..2 (where vp_pixrefer_backward starts the discriminator-loss
- * pass, default 2), "d_beside_vgg" 0 / 1 (default 1).  Per handle: two plans in one process do not change each other's schedule; the
+ * pass, default 2), "d_beside_vgg" 0 / 1 (default 1); and "store_first_raw" 0 / 1 (default 0): encoder_1 / encoder_fg_1 / discriminator
+ * layer_1 of a bf16 plan write their consumers' activations from the conv epilogue and skip the raw output nobody reads - 1 stores it
+ * too (vp_pixrefer_tensor refuses "g/encoder_1" ... otherwise).  Per handle: two plans in one process do not change each other's schedule; the
  * initial values come from the descriptor (vp_pixrefer_desc::streams / d_backward_fork / d_beside_vgg).  Bit-identical results under
  * every setting. */
 int vp_pixrefer_set_option(vp_pixrefer_t* h, const char* key, int value);

@@ -48,6 +48,7 @@ def oracle_step():
 def run_engine(o, dtype):
   eng = PixReferEngine(o["n"], o["h"], o["ngf"], o["ndf"], dtype=dtype, training=True)
   eng.load_params(o["params"])
+  eng.set_option("store_first_raw", 1)          # the parity tests read every layer's stored output (a step skips the first layers' raw ones)
   dev = [torch.tensor(b, device="cuda") for b in o["batch"]]
   eng.forward(*dev)
   eng.backward()
@@ -274,6 +275,7 @@ def test_decoder_1_four_channel_kernel_in_situ():
   inputs, fg, tgt = [torch.tensor(rng.uniform(size=(1, 256, 256, c)).astype(np.float32), device="cuda") for c in (6, 3, 3)]
   eng = PixReferEngine(1, 256, ngf, ngf, dtype="bf16", training=False)
   eng.load_params(p)
+  eng.set_option("store_first_raw", 1)          # encoder_1's raw output is read below (a step does not store it)
   eng.forward(inputs, fg, tgt)
   torch.cuda.synchronize()
   c2 = eng.tensor("g/merged2_decoder_2").float()
@@ -415,6 +417,37 @@ def test_stride2_convs_with_register_resident_weights_and_block_statistics_in_si
   # change of the activations with a few per cent (they sit 0.3-0.4 from the float64 graph whatever is stored how: EXPERIMENTS.md 0.1 of
   # round 4; measured here 0.058), the discriminator's with < 1 %
   assert rel(grads[1][0], grads[0][0]) < 2e-2 and rel(grads[1][1], grads[0][1]) < 0.15, (rel(grads[1][0], grads[0][0]), rel(grads[1][1], grads[0][1]))
+
+
+@pytest.mark.gpu
+def test_first_layers_store_their_raw_output_only_on_request():
+  """encoder_1 / encoder_fg_1 / layer_1 (no batch-norm) write the activations their consumers read from the conv epilogue; the raw output
+  is not stored in a step (nobody reads it): vp_pixrefer_tensor refuses it, everything downstream is bit-identical with and without
+  vp_pixrefer_set_option("store_first_raw", 1), and with the option the stored tensor is what the activations were formed from."""
+  n = 2
+  out = {}
+  for keep in (0, 1):
+    eng = PixReferEngine(n, 256, 64, 64, dtype="bf16", training=True)      # (64 output channels: the width the direct first-layer kernel takes)
+    eng.load_params(eng.random_params(3))
+    if keep:
+      eng.set_option("store_first_raw", 1)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    batch = [torch.rand(n, 256, 256, c, generator=g).cuda() for c in (6, 6, 3, 3)]
+    eng.forward(*batch); eng.backward()
+    torch.cuda.synchronize()
+    out[keep] = (eng.tensor("Outputs_raw").clone(), eng.tensor("losses").clone(), eng.grads_g.clone(), eng.grads_d.clone())
+    if keep:
+      for name in ("g/encoder_1", "g/encoder_fg_1", "d/layer_1"):
+        y = eng.tensor(name).float()
+        assert torch.isfinite(y).all() and y.abs().max() > 0
+    else:
+      for name in ("g/encoder_1", "g/encoder_fg_1", "d/layer_1"):
+        with pytest.raises(RuntimeError, match="store_first_raw"):
+          eng.tensor(name)
+      eng.tensor("g/encoder_2")                 # (batch-normalised layers are stored as ever)
+    del eng
+  for a, b in zip(out[0], out[1]):
+    assert torch.equal(a, b)
 
 
 @pytest.mark.gpu

@@ -73,7 +73,7 @@ struct IgemmArgs {
   int patch, p_kw, p_dhf, p_dhs, p_dwf, p_dws;
   // first layers without batch-norm (encoder_1, encoder_fg_1, discriminator layer_1; conv_cin8_kernel only - conv_cin8_eligible): the
   // epilogue also writes the activations the consumers read - what act_apply would materialise from Y in a pass of its own (Y itself
-  // is still stored: the rounding-aware oracle tests teacher-force on it)
+  // is stored only when the caller passes Y != null: the rounding-aware oracle tests teacher-force on it, a step does not read it)
   void* xa_lrelu;
   void* xa_relu;
   void* pool_out;           // patch kernel, 16 x 16-pixel tiles: also write the 2x2 max-pooled output [N][Hg/2][Wg/2][ldY] (null: no)

@@ -824,9 +824,11 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
     }
     const int ow = p & ((1 << lgW) - 1), oh = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
     const size_t yo = ((size_t)(n * a.Hof + oh) * a.Wof + ow) * a.ldY + 8 * g;
-    bf16* yp = reinterpret_cast<bf16*>(a.Y) + yo;
-    reinterpret_cast<uint4*>(yp)[0] = Elem<bf16>::pack(lo);
-    reinterpret_cast<uint4*>(yp + 32)[0] = Elem<bf16>::pack(hi);
+    if (!ACTS || a.Y != nullptr) {      // (ACTS: the raw output is optional - IgemmArgs::xa_lrelu)
+      bf16* yp = reinterpret_cast<bf16*>(a.Y) + yo;
+      reinterpret_cast<uint4*>(yp)[0] = Elem<bf16>::pack(lo);
+      reinterpret_cast<uint4*>(yp + 32)[0] = Elem<bf16>::pack(hi);
+    }
     // the consumers' activations of the ROUNDED output (what act_apply computes from the stored tensor: same bits)
     if constexpr (ACTS) {
       float rl[8], rh[8];

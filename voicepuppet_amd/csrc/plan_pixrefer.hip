@@ -155,6 +155,7 @@ struct vp_pixrefer {
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
   hipEvent_t ev_upd_b, ev_upd_m;   // fused update: a generator bucket's weight gradients (branch stream) / data gradients (caller's stream) are done
   bool overlap, forked;
+  bool store_first_raw;       // vp_pixrefer_set_option("store_first_raw"): the first layers also store their raw output (tests / debugging; see first_layer_acts_fused)
   bool ov_on;                 // vp_pixrefer_set_option("overlap"): spread the step over the executor's streams (false: everything on the caller's)
   int dfork_point;            // ... ("d_backward_fork"): where vp_pixrefer_backward starts the discriminator-loss pass on the side stream (0 / 1 / 2)
   bool dsplit_on;             // ... ("d_beside_vgg"): discriminator passes on the branch stream beside the VGG passes
@@ -644,6 +645,20 @@ static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStr
   return VP_OK;
 }
 
+// First layers (8-channel image inputs, no batch-norm: encoder_1, encoder_fg_1, discriminator layer_1) on the bf16 path: the direct kernel's
+// epilogue writes the activations the consumers read (what act_apply would materialise in a pass of its own over the 67 .. 201 MB output).
+// Nothing in a step reads the RAW output of such a layer then (consumers read the activations, the chain rule needs their sign only), so
+// it is not stored unless vp_pixrefer_set_option(h, "store_first_raw", 1) asks for it (vp_pixrefer_tensor refuses the tensor otherwise).
+static bool first_layer_acts_fused(const vp_pixrefer* h, const Net& n, const Layer& L) {
+  if (!h->bf16 || L.has_bn || L.tapgemm || L.out_act != ACT_NONE) return false;
+  const Tens& to = n.t[L.out];
+  if (!(to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) || to.is_f32) return false;
+  IgemmArgs a = L.fwd.a;
+  fill_src(n, L, a.x, n.batch / n.groups, 0, 0, h->es);
+  a.ldY = to.C; a.y_f32 = 0; a.out_act = L.out_act;
+  return conv_cin8_eligible(a, 1);
+}
+
 // forward of one conv layer (+ its batch statistics)
 static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void* pool_out = nullptr, int ss = 0) {
   IgemmArgs a = L.fwd.a;
@@ -712,9 +727,10 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
   // first layers (8-channel image inputs, no batch-norm: encoder_1, encoder_fg_1, discriminator layer_1): the direct kernel's epilogue
   // writes the consumers' activations itself - no act_apply pass over the (67 .. 201 MB) output
   bool acts_fused = false;
-  if (h->bf16 && !L.has_bn && !L.tapgemm && (to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) && a.out_act == ACT_NONE && conv_cin8_eligible(a, 1)) {
+  if (first_layer_acts_fused(h, n, L)) {
     a.xa_lrelu = to.need_act[ACT_LRELU] ? to.xa[ACT_LRELU] : nullptr;
     a.xa_relu = to.need_act[ACT_RELU] ? to.xa[ACT_RELU] : nullptr;
+    if (!h->store_first_raw) a.Y = nullptr;
     acts_fused = true;
   }
   profile_tag((L.scope + ":fwd").c_str());
@@ -1125,7 +1141,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
   VP_HIP_CHECK(hipStreamSynchronize(st));   // descs are host vectors owned by the handle; copy is complete
   h->overlap = false; h->forked = false;
   // the schedule of this plan (vp_pixrefer_desc; vp_pixrefer_set_option changes it later)
-  h->ov_on = true; h->dfork_point = d->d_backward_fork ? d->d_backward_fork - 1 : 2; h->dsplit_on = d->d_beside_vgg != 1;
+  h->ov_on = true; h->store_first_raw = false; h->dfork_point = d->d_backward_fork ? d->d_backward_fork - 1 : 2; h->dsplit_on = d->d_beside_vgg != 1;
   if (d->training && d->streams != 1) {
     // lowest priority: the side stream only fills the CUs the main stream's (longer, critical-path) passes leave idle
     int prio_lo = 0, prio_hi = 0;
@@ -1483,6 +1499,7 @@ int vp_pixrefer_set_option(vp_pixrefer_t* h, const char* key, int value) {
   if (k == "overlap") { h->ov_on = value != 0; return VP_OK; }
   if (k == "d_backward_fork") { h->dfork_point = value < 0 ? 0 : (value > 2 ? 2 : value); return VP_OK; }
   if (k == "d_beside_vgg") { h->dsplit_on = value != 0; return VP_OK; }
+  if (k == "store_first_raw") { h->store_first_raw = value != 0; return VP_OK; }
   set_err("vp_pixrefer_set_option: unknown key %s", key);
   return VP_ERR_ARG;
 }
@@ -1733,6 +1750,10 @@ int vp_pixrefer_tensor(vp_pixrefer_t* h, const char* name, void** ptr, int64_t s
   if (k != std::string::npos) { field = rest.substr(k + 1); rest = rest.substr(0, k); }
   for (Tens& t : n->t) {
     if (t.name != rest) continue;
+    if (field.empty() && !h->store_first_raw && t.producer >= 0 && first_layer_acts_fused(h, *n, n->l[t.producer])) {
+      set_err("vp_pixrefer_tensor: the raw output of %s is not stored (its kernel writes the consumers' activations); vp_pixrefer_set_option(h, \"store_first_raw\", 1) before the forward pass", s.c_str());
+      return VP_ERR_STATE;
+    }
     if (field.empty()) return ret(t.y, t.N, t.H, t.W, t.is_f32 ? (t.name == "decoder_1" ? 4 : 1) : t.C, (t.is_f32 || t.hi) ? VP_F32 : cd);
     if (field == "dz32") return t.hi ? ret(t.dz32, t.N, t.H, t.W, t.C, VP_F32) : VP_ERR_ARG;
     if (field == "dy") return ret(t.dz, n == &h->V ? t.N / 2 : t.N, t.H, t.W, t.C, cd);

@@ -284,7 +284,7 @@ class PixReferEngine:
     self.set_option("overlap", 0 if on else 1)
 
   def set_option(self, key, value):
-    """Schedule option of THIS engine's plan (vp_pixrefer_set_option: "overlap", "d_backward_fork", "d_beside_vgg")."""
+    """Schedule option of THIS engine's plan (vp_pixrefer_set_option: "overlap", "d_backward_fork", "d_beside_vgg", "store_first_raw")."""
     _lib.check(self.L.vp_pixrefer_set_option(self.h, key.encode(), int(value)), "vp_pixrefer_set_option(%s)" % key)
 
   def phase_ms(self):
