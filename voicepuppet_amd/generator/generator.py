@@ -395,12 +395,9 @@ class PixReferDataGenerator(DataGenerator):
         return np.concatenate([lo[..., :3], lo[..., 3:] * mask, mask], axis=1).astype(np.float32)
       yield pack_sample(trip(), trip(), S)
 
-  def iterator(self, rand=random):
-    """rand: the source of the order-defining draws (shuffle of the file list, seed of the synthetic clips): the module-level `random`
-    as in the reference, or the private random.Random of ONE iterator (_MfccIterator: its background thread must not share a generator
-    with the main thread, nor with another iterator over the same DataGenerator)."""
+  def iterator(self):
     if self.data_list is None:
-      for s in self._synthetic(rand):
+      for s in self._synthetic():
         yield s
       return
     image_loader = ImageLoader()
