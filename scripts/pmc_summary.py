@@ -26,6 +26,8 @@ def classify(name):
     return "c64_bf16_%dx64" % (16 * int(m.group(2)) * int(m.group(3)) if m else 64)
   if "conv_dc64_kernel" in name:
     return "dc64_bf16_64x128"
+  if "conv_s2c64_kernel" in name:
+    return "s2c64_bf16_128x64"
   if "conv_cin8_kernel" in name:
     return "cin8_bf16_64x16"
   if "deconv_cout4" in name:

@@ -12,6 +12,9 @@ timeout 300 python scripts/phases.py 32 8 4 > $o/phases.txt 2>&1
 timeout 900 python scripts/bench_configs.py > $o/secondary_configs.jsonl 2> $o/secondary.err
 python3 scripts/bench_audio.py 20 f32 > $o/audio_bench.json 2> $o/audio.err
 python3 scripts/bench_audio.py 20 bf16 >> $o/audio_bench.json 2>> $o/audio.err
+python3 scripts/bench_audio.py 20 f32 bfm_dwproj=0 >> $o/audio_bench.json 2>> $o/audio.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $o/aprof -o audio --output-format csv -- python3 scripts/bench_audio.py 10 > $o/aprof.log 2>&1
+f=$(find $o/aprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/audio_kernel_stats.csv; rm -rf $o/aprof
 for b in 4 8; do timeout 300 python scripts/exp_graph.py $b 256 2>&1 | tail -2; done > $o/exp_graph.txt 2>&1
 bash scripts/ab.sh -b "32 8 4" "" "VP_LIB=$PWD/voicepuppet_amd/libvp_r4.so" "tune:streams=1" > $o/ab_vs_r4.txt 2>&1
 tail -c 400 gpurun_out/r05_bench.json; head -12 $o/pmc_instruction_mix.txt; cat $o/ab_vs_r4.txt $o/exp_graph.txt $o/phases.txt
