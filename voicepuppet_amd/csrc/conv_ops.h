@@ -119,6 +119,7 @@ inline int& patch3_knob() { static int v = 1; return v; }   // 3x3 layers on the
 inline int& c64_knob() { static int v = 1; return v; }   // 64 -> 64 channel 3x3 layers on the register-resident-weights kernel (conv_c64.hip)
 inline int& dc64_knob() { static int v = 1; return v; }  // 128 -> 64 channel transposed-conv classes on conv_dc64.hip
 inline int& s2c64_knob() { static int v = 512; return v; }   // 64 -> 128 channel 4x4 / stride-2 convolutions on conv_s2c64.hip from this many 4 x 16-pixel tiles (0: off)
+inline int& s2c64_pair_knob() { static int v = 1; return v; }   // the two-output backward-data of merged2_decoder_2 on conv_s2c64.hip (0: the generic two-output GEMM)
 inline int& patch_minblk_knob() { static int v = 384; return v; }
 
 // pixel tile of a patch-kernel plan: bp = 512 -> 16 x 32, 256 -> 16 x 16, 128 -> 8 x 16
@@ -276,10 +277,11 @@ inline void plan_make_smallp(IgemmPlan& p, int rows, int is_bf16) {
 // 4x4 / stride-2 / pad-1 convolutions from ONE 64-channel tensor to 128 channels on conv_s2c64.hip (weights resident in registers, batch
 // statistics per block).  A plan-time decision: no K split; the generic packing (rows permuted inside 64-row blocks) is what it reads.
 // c0 / c1: channels of the source tensors.
+// rows = 128 (forward layers) or 256 (the two-output backward-data of a 256 -> 64 transposed convolution: split at 128, pixel stride 128)
 inline bool plan_s2c64_eligible(const IgemmPlan& p, int rows, int is_bf16, int c0, int c1) {
   const IgemmArgs& a = p.a;
   if (s2c64_knob() <= 0 || !is_bf16 || a.nclass != 1 || a.ntaps != 16 || a.os != 1 || a.sh != 2 || a.sw != 2) return false;
-  if (rows != 128 || a.Cout != 128 || a.ldY != 128 || a.Cin != 64 || c0 != 64 || c1 != 0 || a.Kpad != 1024) return false;
+  if ((rows != 128 && rows != 256) || a.Cout != rows || a.ldY != 128 || a.Cin != 64 || c0 != 64 || c1 != 0 || a.Kpad != 1024) return false;
   if (a.Hg % 4 || a.Wg % 16 || a.Hin != 2 * a.Hg || a.Win != 2 * a.Wg || a.Hof != a.Hg || a.Wof != a.Wg) return false;
   for (int t = 0; t < 16; ++t)
     if (a.taps[0].dh[t] != (t >> 2) - 1 || a.taps[0].dw[t] != (t & 3) - 1) return false;
@@ -291,7 +293,8 @@ inline void plan_make_s2c64(IgemmPlan& p) {
   IgemmArgs& a = p.a;
   a.patch = 4;
   p.cfg = 0;                 // (128 x 128: the class name's tile; the kernel has its own)
-  a.CoutPad = 128; a.wp_rows = 128;
+  a.CoutPad = a.Cout; a.wp_rows = a.Cout; p.pack.rows_pad = a.Cout;
+  p.pack_elems = (size_t)a.wp_rows * a.Kpad;
   a.splitk = 1; p.partial_bytes = 0;
   a.rowperm = 1; p.pack.perm = 1; p.pack.kswap = 0;
 }

@@ -40,14 +40,42 @@ constexpr int NW = 8;
 constexpr int JP = (NROUND + NW - 1) / NW;    // DMA rounds per wave (the last one only for waves < NROUND - 2 NW)
 }  // namespace
 
-template <bool STATS>
+__device__ __forceinline__ unsigned s2_pk_max_i16(unsigned x, unsigned y) {
+  unsigned r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ unsigned s2_pk_min_u16(unsigned x, unsigned y) {
+  unsigned r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ unsigned s2_pk_mul_lo_u16(unsigned x, unsigned y) {
+  unsigned r;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
+// STATS: batch statistics of the rounded outputs (the forward layers).  PAIR: the two-output backward-data of a 256 -> 64 transposed
+// convolution (merged2_decoder_2: IgemmArgs::split_c = 128): even / odd virtual blocks compute packed rows [0, 128) -> Y / ref /
+// accumulate and [128, 256) -> Y2 / ref2 / accumulate2 of the same pixel tiles, output *= relu'(reference), (+= what another consumer
+// wrote first)
+template <bool STATS, bool PAIR>
 __global__ __launch_bounds__(NW * 64, 1) void conv_s2c64_kernel(const IgemmArgs a, const int ntiles) {
+  static_assert(!(STATS && PAIR), "statistics belong to the forward layers");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fi = lane & 15, fg = lane >> 4;
 
-  // weights: K chunk (4 kh + kw) * 2 + c, packed row 16 wave + fi, piece fg
+  // XCD-aware virtual block index; PAIR: its low bit selects the output half
+  const int G = gridDim.x;
+  int vb = blockIdx.x;
+  if ((G & 7) == 0) vb = (vb & 7) * (G >> 3) + (vb >> 3);
+  const int half = PAIR ? (vb & 1) : 0, row0 = 128 * half;
+  const int bt = PAIR ? (vb >> 1) : vb, GT = PAIR ? (G >> 1) : G;
+
+  // weights: K chunk (4 kh + kw) * 2 + c, packed row row0 + 16 wave + fi, piece fg
   uint4 W[16][NCH];
   {
     const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
@@ -55,7 +83,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_s2c64_kernel(const IgemmArgs 
     for (int t = 0; t < 16; ++t)
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
-        W[t][c] = *reinterpret_cast<const uint4*>(wp + ((size_t)(t * NCH + c) * a.wp_rows + 16 * wave + fi) * 32 + fg * 8);
+        W[t][c] = *reinterpret_cast<const uint4*>(wp + ((size_t)(t * NCH + c) * a.wp_rows + row0 + 16 * wave + fi) * 32 + fg * 8);
   }
   // accumulator rows 4 fg .. 4 fg + 3 of the wave's tile T = wave & 3 of 64-row block wave >> 2: channels 64 b + 32 (T >> 1) + 8 fg + 4 (T & 1) + e
   const int c0 = 64 * (wave >> 2) + 32 * ((wave >> 1) & 1) + 8 * fg + 4 * (wave & 1);
@@ -83,12 +111,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_s2c64_kernel(const IgemmArgs 
 
   __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * 64 * sizeof(bf16)));
   const int tiles_x = a.Wg / TW, tpi = tiles_x * (a.Hg / TH);
-  bf16* Yp = reinterpret_cast<bf16*>(a.Y);
+  bf16* Yp = reinterpret_cast<bf16*>(half ? a.Y2 : a.Y);
+  const bf16* refp = reinterpret_cast<const bf16*>(half ? a.ref2 : a.ref);
+  const bool accum = PAIR && (half ? a.accumulate2 : a.accumulate);
   constexpr int NST = TH * TW * 256 / 1024 / NW;             // 1 KB store instructions per tile and wave (2)
-
-  const int G = gridDim.x;
-  int bt = blockIdx.x;
-  if ((G & 7) == 0) bt = (bt & 7) * (G >> 3) + (bt >> 3);
 
   // patch origin: input pixel (2 q0 - 1, 2 r0 - 1)
   auto issue_patch = [&](int t, int buf) {
@@ -137,14 +163,26 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_s2c64_kernel(const IgemmArgs 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(W[t][c].x), "+v"(W[t][c].y), "+v"(W[t][c].z), "+v"(W[t][c].w));
   int it = 0;
-  for (int t = bt; t < ntiles; t += G, ++it) {
+  for (int t = bt; t < ntiles; t += GT, ++it) {
     const int buf = it & 1;
     // this tile's patch has landed (counted: only the previous tile's NST stores were issued behind its DMAs, conv_c64.hip)
     if (it == 0) wait_vm<0>();
     else wait_vm<NST>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + G < ntiles) issue_patch(t + G, buf ^ 1);
+    // PAIR: the reference rows (and the rows another consumer wrote) of the tile, requested BEFORE the next patch so that they return first
+    uint2 rz[PAIR ? TH : 1], ry[PAIR ? TH : 1];
+    if constexpr (PAIR) {
+      const int n = t / tpi, rem = t - n * tpi;
+      const size_t o00 = ((size_t)(n * a.Hof + (rem / tiles_x) * TH) * a.Wof + (rem % tiles_x) * TW + fi) * 128 + c0;
+#pragma unroll
+      for (int r = 0; r < TH; ++r) rz[r] = *reinterpret_cast<const uint2*>(refp + o00 + (size_t)r * a.Wof * 128);
+      if (accum) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r) ry[r] = *reinterpret_cast<const uint2*>(Yp + o00 + (size_t)r * a.Wof * 128);
+      }
+    }
+    if (t + GT < ntiles) issue_patch(t + GT, buf ^ 1);
     if constexpr (STATS) {
       const int grp = t / a.bn_tpg;
       if (grp != cur_grp) {
@@ -192,8 +230,22 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_s2c64_kernel(const IgemmArgs 
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
       uint2 pk;
+      if constexpr (PAIR) {
+        if (accum) {      // += the gradient another consumer wrote first (of the masked product: added after the mask below would be wrong)
+          const float m0 = __uint_as_float(rz[r].x << 16) > 0.f ? 1.f : 0.f, m1 = __uint_as_float(rz[r].x & 0xffff0000u) > 0.f ? 1.f : 0.f;
+          const float m2 = __uint_as_float(rz[r].y << 16) > 0.f ? 1.f : 0.f, m3 = __uint_as_float(rz[r].y & 0xffff0000u) > 0.f ? 1.f : 0.f;
+          acc[r][0] = fmaf(acc[r][0], m0, __uint_as_float(ry[r].x << 16)); acc[r][1] = fmaf(acc[r][1], m1, __uint_as_float(ry[r].x & 0xffff0000u));
+          acc[r][2] = fmaf(acc[r][2], m2, __uint_as_float(ry[r].y << 16)); acc[r][3] = fmaf(acc[r][3], m3, __uint_as_float(ry[r].y & 0xffff0000u));
+        }
+      }
       pk.x = Elem<bf16>::pack2(acc[r][0], acc[r][1]);
       pk.y = Elem<bf16>::pack2(acc[r][2], acc[r][3]);
+      if constexpr (PAIR) {
+        if (!accum) {     // relu'(reference) per 16-bit half: min(max(ref as int16, 0), 1) is 1 exactly for a positive bf16; times the output's bits
+          pk.x = s2_pk_mul_lo_u16(pk.x, s2_pk_min_u16(s2_pk_max_i16(rz[r].x, 0u), 0x00010001u));
+          pk.y = s2_pk_mul_lo_u16(pk.y, s2_pk_min_u16(s2_pk_max_i16(rz[r].y, 0u), 0x00010001u));
+        }
+      }
       if constexpr (STATS) {
         const float v0 = __uint_as_float(pk.x << 16), v1 = __uint_as_float(pk.x & 0xffff0000u);
         const float v2 = __uint_as_float(pk.y << 16), v3 = __uint_as_float(pk.y & 0xffff0000u);
@@ -242,21 +294,29 @@ int conv_s2c64_grid(const IgemmArgs& a) {
 }
 int conv_s2c64_tiles_per_image(const IgemmArgs& a) { return (a.Hg / TH) * (a.Wg / TW); }
 
-// run-time side of plan_s2c64_eligible (conv_ops.h): a plan made by plan_make_s2c64 with a raw bf16 output and a plain input
+// run-time side of plan_s2c64_eligible (conv_ops.h): a plan made by plan_make_s2c64 with a raw bf16 output and a plain input; either the
+// forward form (128 output channels, no reference) or the two-output backward-data form (split_c = 128: 2 x 128 channels, relu'(reference))
 bool conv_s2c64_eligible(const IgemmArgs& a, int is_bf16) {
-  if (!is_bf16 || a.patch != 4 || a.Cout != 128 || a.wp_rows != 128 || a.ldY != 128 || a.Cin != 64 || a.x.C[0] != 64 || a.x.C[1] != 0 || !a.rowperm || a.splitk != 1) return false;
+  if (!is_bf16 || a.patch != 4 || a.ldY != 128 || a.Cin != 64 || a.x.C[0] != 64 || a.x.C[1] != 0 || !a.rowperm || a.splitk != 1) return false;
   if (a.Hg % TH || a.Wg % TW || a.Hin != 2 * a.Hg || a.Win != 2 * a.Wg) return false;
-  return a.out_act == ACT_NONE && !a.y_f32 && !a.ref && !a.accumulate && !a.split_c && !a.pool_out && !a.x.aff_a[0] && a.x.act == ACT_NONE;
+  if (a.out_act != ACT_NONE || a.y_f32 || a.pool_out || a.x.aff_a[0] || a.x.act != ACT_NONE || a.ref_a) return false;
+  if (a.split_c) {
+    return a.split_c == 128 && a.Cout == 256 && a.wp_rows == 256 && a.Y2 && a.ref && a.ref2 && a.ref_act == ACT_RELU && !a.y2_f32 && !a.bias && !a.bn_part;
+  }
+  return a.Cout == 128 && a.wp_rows == 128 && !a.ref && !a.accumulate;
 }
 
 hipError_t launch_conv_s2c64(const IgemmArgs& a, hipStream_t st) {
   const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);
-  const int grid = conv_s2c64_grid(a);
-  if (a.bn_part && (a.bn_nchunk != grid || a.bn_tpg <= 0 || (ntiles + a.bn_tpg - 1) / a.bn_tpg > 32)) return hipErrorInvalidValue;
-  void (*kern)(const IgemmArgs, const int) = a.bn_part ? conv_s2c64_kernel<true> : conv_s2c64_kernel<false>;
+  const int pair = a.split_c ? 1 : 0;
+  int grid = conv_s2c64_grid(a);
+  if (pair) grid = 2 * ntiles < 512 ? 2 * ntiles : 512;        // both halves of a tile in neighbouring virtual blocks (one XCD); two rounds of 256
+  if (a.bn_part && (pair || a.bn_nchunk != grid || a.bn_tpg <= 0 || (ntiles + a.bn_tpg - 1) / a.bn_tpg > 32)) return hipErrorInvalidValue;
+  const int ki = pair ? 2 : (a.bn_part ? 1 : 0);
+  void (*kerns[3])(const IgemmArgs, const int) = {conv_s2c64_kernel<false, false>, conv_s2c64_kernel<true, false>, conv_s2c64_kernel<false, true>};
+  void (*kern)(const IgemmArgs, const int) = kerns[ki];
   const int smem = 2 * BUFB + STGB;                            // 104 KB
-  static bool attr_done[2] = {false, false};
-  const int ki = a.bn_part ? 1 : 0;
+  static bool attr_done[3] = {false, false, false};
   if (!attr_done[ki]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_done[ki] = true; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, a, ntiles);
   return hipGetLastError();

@@ -395,6 +395,8 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
           ok = plan_smallp_eligible(L.bwd_pair, c0 + c1, bf16, L.g.CoutT, 0);
           if (ok) plan_make_smallp(L.bwd_pair, c0 + c1, bf16);
         }
+        // the 256 -> 64 transposed convolution's pair (merged2_decoder_2: relu inputs): register-resident weights, conv_s2c64.hip
+        if (ok && s2c64_pair_knob() && L.bwd[0].a.patch == 0 && L.in_act == ACT_RELU && plan_s2c64_eligible(L.bwd_pair, c0 + c1, bf16, L.g.CoutT, 0)) plan_make_s2c64(L.bwd_pair);
         if (ok) {
           L.bwd_pair.a.split_c = c0;
           take(L.bwd_pair);
