@@ -1896,6 +1896,15 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     }
   }
   if (a.patch == 4) return hipErrorInvalidValue;
+  if constexpr (sizeof(T) == 2) {
+    // 4x4 / stride-1 taps without batch statistics (the discriminator's layer_4 backward-data passes): the unrolled patch kernel with
+    // 16 tap steps per chunk, 128-row x 16 x 16-pixel tiles (conv_patch3.hip, KW = 4)
+    if (a.patch == 1 && patch4_eligible(a, 1)) {
+      ProfScope prof("patch4", true, 128, 256, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+      return launch_igemm_patch4(a, st);
+    }
+  }
   if (a.patch) {   // stride-1 convs with the input patch staged once per channel chunk (conv_patch.hip)
     // class name per kernel template: patch2 (parity classes, conv_patch2.hip), patch3 (unrolled 3x3, conv_patch3.hip), patch (generic)
     const char* pk = a.patch == 2 ? "patch2" : (patch3_knob() && patch3_eligible(a, sizeof(T) == 2) ? "patch3" : "patch");

@@ -116,6 +116,7 @@ inline int& patch_tiles_knob() { static int v = 7; return v; }
 inline int& patch_small_knob() { static int v = 3; return v; }   // two-blocks-per-CU tiles (see patch_tile_pixels)
 inline int& patch_longk_knob() { static int v = 1; return v; }      // 1: long-K 512-row layers stay on the 256x256 tile
 inline int& patch3_knob() { static int v = 1; return v; }   // 3x3 layers on the unrolled patch kernel (conv_patch3.hip)
+inline int& patch4_knob() { static int v = 1; return v; }   // 4x4 stride-1 backward-data passes on the unrolled patch kernel (conv_patch3.hip, KW = 4)
 inline int& c64_knob() { static int v = 1; return v; }   // 64 -> 64 channel 3x3 layers on the register-resident-weights kernel (conv_c64.hip)
 inline int& dc64_knob() { static int v = 1; return v; }  // 128 -> 64 channel transposed-conv classes on conv_dc64.hip
 inline int& s2c64_knob() { static int v = 512; return v; }   // 64 -> 128 channel 4x4 / stride-2 convolutions on conv_s2c64.hip from this many 4 x 16-pixel tiles (0: off)
@@ -150,13 +151,16 @@ inline bool plan_patch_eligible(const IgemmPlan& p, int rows, int is_bf16, bool 
   if (rows % 64 || a.Cout % 8 || a.ldY % 8 || a.Hg < 16 || a.Wg < 16 || a.Hof != a.Hg || a.Wof != a.Wg) return false;
   // >= 512 output channels with a long K loop (discriminator layer_4 forward): measured faster on the wave-specialised 256x256 tile
   // (0.32 vs 0.36 ms at N = 32), whose exposed prologue / epilogue that loop amortises
-  if (patch_longk_knob() && rows >= 512 && rows % 256 == 0 && a.ntaps * a.Cin >= 4096 && (long long)a.N * a.Hg * a.Wg >= 256 * 256) return false;
-  const int bc = patch_tile_rows(rows, on);
+  // (round 5: 4x4 taps run the unrolled kernel - conv_patch3.hip, KW = 4: 1250 TF on the same layer - and stay here)
+  const bool p4 = patch4_knob() && is_bf16 && a.ntaps == 16 && rows % 128 == 0;
+  if (!p4 && patch_longk_knob() && rows >= 512 && rows % 256 == 0 && a.ntaps * a.Cin >= 4096 && (long long)a.N * a.Hg * a.Wg >= 256 * 256) return false;
+  const int bc = p4 ? 128 : patch_tile_rows(rows, on);
   if (!bc) return false;
   int th, tw;
-  patch_tile_hw(patch_tile_pixels(bc), &th, &tw);
+  patch_tile_hw(p4 ? 256 : patch_tile_pixels(bc), &th, &tw);
   const long long blocks = (long long)a.N * ((a.Hg + th - 1) / th) * ((a.Wg + tw - 1) / tw) * (rows / bc);
   if (blocks < minblk) return false;
+  if (p4 && !any_grid && blocks < 512 && patch_minblk_knob() > 1) return false;     // (batch 8: 384 blocks measured 0.01-0.02 ms slower than the 256 x 256 wave-specialised tile)
   if ((size_t)a.N * a.Hin * a.Win * a.Cin * (is_bf16 ? 2 : 4) >= 0x70000000ull) return false;     // lane offsets of the buffer loads
   // taps on a regular grid
   int ks = 0;
@@ -170,13 +174,16 @@ inline bool plan_patch_eligible(const IgemmPlan& p, int rows, int is_bf16, bool 
 }
 inline void plan_make_patch(IgemmPlan& p, int rows, int is_bf16) {
   IgemmArgs& a = p.a;
-  const int bc = patch_tile_rows(rows, patch_tiles_knob());
+  // 4x4 taps (bf16): the unrolled kernel's 128-row x 16 x 16-pixel tile (conv_patch3.hip patch4_eligible); the plan names the tile the
+  // batch statistics are chunked by
+  const bool p4 = patch4_knob() && is_bf16 && a.ntaps == 16 && rows % 128 == 0;
+  const int bc = p4 ? 128 : patch_tile_rows(rows, patch_tiles_knob());
   int ks = 0;
   while (ks * ks < a.ntaps) ++ks;
   a.patch = 1; a.p_kw = ks;
   a.p_dhf = a.taps[0].dh[0]; a.p_dwf = a.taps[0].dw[0];
   a.p_dhs = a.taps[0].dh[ks] - a.taps[0].dh[0]; a.p_dws = a.taps[0].dw[1] - a.taps[0].dw[0];
-  const int bp = patch_tile_pixels(bc);
+  const int bp = p4 ? 256 : patch_tile_pixels(bc);
   p.cfg = bc == 256 ? (bp == 128 ? 15 : 10) : (bc == 128 ? (bp == 256 ? 13 : 11) : (bp == 256 ? 14 : 12));
   a.CoutPad = round_up(rows, bc);
   a.splitk = 1;

@@ -55,11 +55,13 @@ struct Patch3TilePix {
 // NSTW: stages of the weight ring = NSTW - 1 steps of weights in flight.  A step of a 64-row tile is 8 MFMAs per wave, far shorter than
 // the 1-1.5 us an LDS-DMA takes to land under load: with 3 stages the loop ran at the DMA latency (0.7 us per step whatever the tile),
 // with 6 the weights of five steps are in flight.  18 steps per trip: NSTW divides 18, stage indices stay compile-time.
-template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC, int NSTW = 3>
+// KW: 3 (3x3 taps) or 4 (4x4 taps: the discriminator's layer_4 backward-data passes, round 5 - 32 steps per trip, four ring stages)
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC, int NSTW = 3, int KW = 3>
 __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NW = 8, NT = 512, LA = NSTW - 1;
-  static_assert(18 % NSTW == 0 && NSTW >= 3, "ring stages");
+  constexpr int KS2 = KW * KW, TRIP = 2 * KS2;                       // patch positions of a chunk, steps of a trip (two chunks)
+  static_assert(TRIP % NSTW == 0 && NSTW >= 3, "ring stages");
   static_assert(WC * WP == NW, "eight waves");
   constexpr int BC = WC * TC * 16, BP = TH * TW;
   static_assert(BP == WP * TP * 16, "pixel blocks of the tile = pixel blocks of the waves");
@@ -67,14 +69,14 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   static_assert(NBA % NW == 0 || NBA == 4, "weight DMAs: whole instructions per wave (64-row tiles: half an instruction per wave)");
   constexpr int JA = (NBA + NW - 1) / NW;
   constexpr bool HALFW = NBA < NW;
-  constexpr int PW = TW + 2, PH = TH + 2, NPATCH = PW * PH;
+  constexpr int PW = TW + KW - 1, PH = TH + KW - 1, NPATCH = PW * PH;
   constexpr int PPAD = (NPATCH + 127) / 128 * 128;                   // patch pixels, padded to whole DMA rounds of the 8 waves
   constexpr int JP = PPAD / 128;                                     // patch DMA instructions per wave and chunk
-  static_assert(JP + LA <= 9, "one patch DMA per tap step, none in the last LA steps of a chunk");
+  static_assert(JP + LA <= KS2, "one patch DMA per tap step, none in the last LA steps of a chunk");
   constexpr int PBUFB = PPAD * 64;                                   // bytes of one patch buffer
   constexpr int WSTB = 4 * BC * 16;                                  // bytes of one weight stage
   constexpr int WBASE = 2 * PBUFB;
-  static_assert(PBUFB + 2 * PW * 64 + 64 < 65536 && (NSTW - 1) * WSTB + 7 * 1024 + 16 < 65536, "read offsets are DS immediates");
+  static_assert(PBUFB + (KW - 1) * PW * 64 + 64 < 65536 && (NSTW - 1) * WSTB + 7 * 1024 + 16 < 65536, "read offsets are DS immediates");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   // (backward-data: the flipped kernel).  The loop walks PATCH positions (pr, pc) in a fixed order; the weight chunk that belongs
   // to patch position u is tap u (forward) or tap 8 - u (flipped)
   const bool flip = a.p_dhs < 0;
-  const int dh0 = flip ? a.p_dhf - 2 : a.p_dhf, dw0 = flip ? a.p_dwf - 2 : a.p_dwf;
+  const int dh0 = flip ? a.p_dhf - (KW - 1) : a.p_dhf, dw0 = flip ? a.p_dwf - (KW - 1) : a.p_dwf;
   const unsigned es = sizeof(T);
   const int C0 = a.x.C[0];
   const int nchunkc = C0 / KC;                  // channel chunks (even)
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   const unsigned wstep = (unsigned)(a.wp_rows * KC * es);
   // weights of patch position u (tap u or 8 - u) and channel chunk c -> ring stage `stage`
   auto issue_w = [&](int u, int chunk, int stage) {
-    const int tap = flip ? 8 - u : u;
+    const int tap = flip ? KS2 - 1 - u : u;
     const unsigned wso = (unsigned)(tap * nchunkc + chunk) * wstep;
     uint4* la = reinterpret_cast<uint4*>(smem + WBASE + stage * WSTB);
     if constexpr (HALFW) {
@@ -146,9 +148,9 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   const int fi = lane & 15, fg = lane >> 4;
   const int aaddr = WBASE + (blkA0 * 64 + fi * 4 + (fg ^ rb_swz(fi))) * 16;     // (ring base folded in: stage and block offsets fit the immediate)
   // B fragment lane offsets per column shift c: patch pixel (row of the pixel block, its first column + lane + c)
-  int tb0[3][TP];
+  int tb0[KW][TP];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int c = 0; c < KW; ++c)
 #pragma unroll
     for (int q = 0; q < TP; ++q) {
       constexpr int BPR = TW / 16;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
 #pragma unroll
   for (int j = 0; j < JP; ++j) issue_p(0, 0, j);
 #pragma unroll
-  for (int d = 0; d < LA; ++d) issue_w(d % 9, d / 9, d % NSTW);
+  for (int d = 0; d < LA; ++d) issue_w(d % KS2, d / KS2, d % NSTW);
 
   // One trip = 2 chunks x 9 patch positions.  Step U = 9 * cc + u (cc: chunk of the pair = patch buffer, u: patch position);
   // ring stage U % NSTW.  In DMA order behind the weights of step U (issued at step U - LA): the patch piece of step U - LA, then per
@@ -178,13 +180,13 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
     const bool last_pair = c + 2 >= nchunkc;
     auto step = [&](auto uc) {
       constexpr int U = decltype(uc)::value;
-      constexpr int cc = U / 9, u = U % 9, pr = u / 3, pc = u % 3, stage = U % NSTW;
+      constexpr int cc = U / KS2, u = U % KS2, pr = u / KW, pc = u % KW, stage = U % NSTW;
       // DMAs issued behind the weights of this step: the patch pieces of the LA previous steps, the weights of the LA - 1 next ones
-      constexpr int NPIECE = [] { int n = 0; for (int k = 1; k <= LA; ++k) n += ((U + 18 - k) % 18 % 9) < JP ? 1 : 0; return n; }();
+      constexpr int NPIECE = [] { int n = 0; for (int k = 1; k <= LA; ++k) n += ((U + TRIP - k) % TRIP % KS2) < JP ? 1 : 0; return n; }();
       constexpr int NV = (LA - 1) * JA + NPIECE;
-      constexpr int WLAST = (17 - U < LA - 1 ? 17 - U : LA - 1);                 // behind the last pair no weights of a next trip follow
+      constexpr int WLAST = (TRIP - 1 - U < LA - 1 ? TRIP - 1 - U : LA - 1);                 // behind the last pair no weights of a next trip follow
 #if !(VP_P3_ABL & 2)
-      if (U + LA - 1 > 17 && last_pair) wait_vm<WLAST * JA + NPIECE>();
+      if (U + LA - 1 > TRIP - 1 && last_pair) wait_vm<WLAST * JA + NPIECE>();
       else wait_vm<NV>();
 #endif
 #if !(VP_P3_ABL & 1)
@@ -194,9 +196,9 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
       // weights LA steps ahead (ring stage (U + LA) % NSTW, last read in step U - 1)
 #if !(VP_P3_ABL & 4)
       {
-        constexpr int UL = (U + LA) % 18;
-        if (U + LA < 18) issue_w(UL % 9, c + UL / 9, (U + LA) % NSTW);
-        else if (!last_pair) issue_w(UL % 9, c + 2 + UL / 9, (U + LA) % NSTW);
+        constexpr int UL = (U + LA) % TRIP;
+        if (U + LA < TRIP) issue_w(UL % KS2, c + UL / KS2, (U + LA) % NSTW);
+        else if (!last_pair) issue_w(UL % KS2, c + 2 + UL / KS2, (U + LA) % NSTW);
       }
       if constexpr (u < JP) issue_p(c + cc + 1, 1 - cc, u);
 #endif
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
       constexpr int NA = TC == 8 ? 4 : ((TC == 4 && OCC == 4) ? 2 : TC);
       patch_step_mma<T, TC, TP, NA, stage * WSTB, cc * PBUFB + pr * PW * 64, true>(aaddr, tb0[pc], acc);
     };
-    static_steps(step, std::make_integer_sequence<int, 18>{});
+    static_steps(step, std::make_integer_sequence<int, TRIP>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing patch pieces: the epilogue reuses the LDS
 
@@ -219,10 +221,10 @@ __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs 
   if (!(VP_P3_ABL & 8) || acc[0][0][0] == 1.2345f) staged_epilogue<T, TC, TP, BC, BP, NPASS, NT, STATS, NPASS16>(a, Patch3TilePix<TW>{a, n, y0, x0}, c_base, blkA0, blkB0, acc, smem, bt, 0);
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int OCC, int NSTW = 3>
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int OCC, int NSTW = 3, int KW = 3>
 static hipError_t launch_patch3_t(const IgemmArgs& b, hipStream_t st) {
   constexpr int BC = WC * TC * 16, BP = TH * TW;
-  constexpr int PPAD = ((TH + 2) * (TW + 2) + 127) / 128 * 128;
+  constexpr int PPAD = ((TH + KW - 1) * (TW + KW - 1) + 127) / 128 * 128;
   constexpr int RINGB = NSTW * 4 * BC * 16 + 2 * PPAD * 64;
   constexpr int NPE = epi_passes(BC, BP, WP, RINGB);
   size_t sm = RINGB;
@@ -230,7 +232,7 @@ static hipError_t launch_patch3_t(const IgemmArgs& b, hipStream_t st) {
   if (se > sm) sm = se;
   const int tiles = b.N * ((b.Hg + TH - 1) / TH) * ((b.Wg + TW - 1) / TW);
   dim3 grid(tiles, b.CoutPad / BC, 1);
-  auto kern = b.bn_part ? igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC, NSTW> : igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC, NSTW>;
+  auto kern = b.bn_part ? igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC, NSTW, KW> : igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC, NSTW, KW>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(kern, grid, dim3(512), sm, st, b);
   return hipGetLastError();
@@ -241,6 +243,20 @@ bool patch3_eligible(const IgemmArgs& a, int is_bf16) {
   const int kc = is_bf16 ? 32 : 16;
   return a.patch && a.ntaps == 9 && a.p_kw == 3 && a.p_dhs == a.p_dws && (a.p_dhs == 1 || a.p_dhs == -1) && a.x.C[0] % (2 * kc) == 0 &&
          a.x.C[1] == 0;
+}
+
+// 4x4 taps (stride 1) on the same kernel (the discriminator's layer_4: forward with its batch statistics, backward-data): bf16, channel
+// rows a multiple of 128: the 128-row x 16 x 16-pixel tile (80 KB of LDS with four ring stages: two blocks per CU; the 256-row tile would
+// need 96 KB) - plan_make_patch names that tile for 4x4 layers
+bool patch4_eligible(const IgemmArgs& a, int is_bf16) {
+  return patch4_knob() && is_bf16 && a.patch == 1 && a.ntaps == 16 && a.p_kw == 4 && a.p_dhs == a.p_dws && (a.p_dhs == 1 || a.p_dhs == -1) &&
+         a.x.C[0] % 64 == 0 && a.x.C[1] == 0 && a.CoutPad % 128 == 0 && !a.pool_out;
+}
+hipError_t launch_igemm_patch4(const IgemmArgs& a, hipStream_t st) {
+  IgemmArgs b = a;
+  b.vec_epi = 1;
+  b.xcd_remap = patch_xcd_knob();
+  return launch_patch3_t<bf16, 2, 4, 4, 4, 16, 16, 4, 4, 4>(b, st);
 }
 
 // same tile menu as launch_igemm_patch (conv_patch.hip)

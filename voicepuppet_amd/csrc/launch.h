@@ -12,6 +12,8 @@ void igemm_tile(int cfg, int* bc, int* bp);
 hipError_t launch_igemm_patch(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                    // conv_patch.hip
 bool patch3_eligible(const IgemmArgs& a, int is_bf16);                                                               // conv_patch3.hip
 hipError_t launch_igemm_patch3(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                   // conv_patch3.hip
+bool patch4_eligible(const IgemmArgs& a, int is_bf16);                                                               // conv_patch3.hip (KW = 4)
+hipError_t launch_igemm_patch4(const IgemmArgs& a, hipStream_t st);
 bool conv_cin8_eligible(const IgemmArgs& a, int is_bf16);                                                           // conv_kernels.hip
 bool conv_c64_eligible(const IgemmArgs& a, int is_bf16);                                                            // conv_c64.hip
 hipError_t launch_conv_c64(const IgemmArgs& a, hipStream_t st);
