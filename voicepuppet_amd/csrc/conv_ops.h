@@ -159,8 +159,12 @@ inline bool plan_patch_eligible(const IgemmPlan& p, int rows, int is_bf16, bool 
   int th, tw;
   patch_tile_hw(p4 ? 256 : patch_tile_pixels(bc), &th, &tw);
   const long long blocks = (long long)a.N * ((a.Hg + th - 1) / th) * ((a.Wg + tw - 1) / tw) * (rows / bc);
-  if (blocks < minblk) return false;
-  if (p4 && !any_grid && blocks < 512 && patch_minblk_knob() > 1) return false;     // (batch 8: 384 blocks measured 0.01-0.02 ms slower than the 256 x 256 wave-specialised tile)
+  // 4x4 taps: from 512 blocks (batch 8: 384 blocks measured 0.01-0.02 ms slower than the 256 x 256 wave-specialised tile); from 256 - one per
+  // CU - where K >= 8192 amortises the block's prologue (layer_4's generator-loss pass at batch 32)
+  const long long p4min = (long long)a.ntaps * a.Cin >= 8192 ? 256 : 512;
+  if (p4 && !any_grid && patch_minblk_knob() > 1) {
+    if (blocks < p4min) return false;
+  } else if (blocks < minblk) return false;
   if ((size_t)a.N * a.Hin * a.Win * a.Cin * (is_bf16 ? 2 : 4) >= 0x70000000ull) return false;     // lane offsets of the buffer loads
   // taps on a regular grid
   int ks = 0;
