@@ -462,6 +462,40 @@ def test_two_output_backward_of_the_last_wide_decoder_with_register_resident_wei
 
 
 @pytest.mark.gpu
+def test_last_wide_decoder_forward_with_register_resident_weights_in_situ():
+  """merged2_decoder_2 forward (256 -> 64 transposed convolution over the virtual concat of two 128-channel tensors, batch-norm behind it)
+  on conv_dc64.hip's conv_dc256_kernel (from 8 frames up, where the layer is on the parity-class patch plan): raw output and the batch-norm scale / shift / mean / rstd formed from its
+  per-block partial rows against the unrolled patch kernel + its per-tile statistics (vp_tune("dc64", 0), which also moves the 128 -> 64
+  backward classes back: forward tensors only are compared)."""
+  from voicepuppet_amd import _lib
+  L = _lib.lib()
+  n = 8
+  got = {}
+  names = ["g/merged2_decoder_2" + f for f in ("", ":scale", ":shift", ":mean", ":rstd")] + ["Outputs_raw"]
+  for on in (1, 0):
+    L.vp_tune(b"dc64", on)
+    try:
+      eng = PixReferEngine(n, 256, 64, 64, dtype="bf16", training=True)
+      eng.load_params(eng.random_params(5))
+      g = torch.Generator(device="cpu").manual_seed(9)
+      batch = [torch.rand(n, 256, 256, c, generator=g).cuda() for c in (6, 6, 3, 3)]
+      eng.profile(1)
+      eng.forward(*batch)
+      torch.cuda.synchronize()
+      classes = {r["name"] for r in eng.profile_collect()}
+      eng.profile(0)
+      assert any(c.startswith("dc256_") for c in classes) == bool(on), classes
+      got[on] = {k: eng.tensor(k).float().cpu().numpy() for k in names}
+      del eng
+    finally:
+      L.vp_tune(b"dc64", 1)
+  for k in names:
+    assert np.isfinite(got[1][k]).all() and np.abs(got[1][k]).max() > 0, k
+    tol = 1e-3 if ":" in k else (4e-3 if k.startswith("g/") else 2e-2)
+    assert gu.rel_l2(got[1][k], got[0][k]) < tol, (k, gu.rel_l2(got[1][k], got[0][k]))
+
+
+@pytest.mark.gpu
 def test_first_layers_store_their_raw_output_only_on_request():
   """encoder_1 / encoder_fg_1 / layer_1 (no batch-norm) write the activations their consumers read from the conv epilogue; the raw output
   is not stored in a step (nobody reads it): vp_pixrefer_tensor refuses it, everything downstream is bit-identical with and without

@@ -228,6 +228,215 @@ __global__ __launch_bounds__(256, 2) void conv_dc64_kernel(const IgemmArgs a, co
   }
 }
 
+// conv_dc256_kernel: the FORWARD form for 256 input channels from TWO 128-channel tensors (the virtual concat [decoder | encoder skip] of
+// merged2_decoder_2, the last wide decoder: pixrefer.py:243-270) with the batch statistics in the block.  K = 1024 per class: a wave keeps
+// a 16 x 1024 weight slice (32 fragments, 128 registers), so the block is EIGHT waves - waves 0-3 column parity 0, waves 4-7 parity 1, each
+// one 16-channel MFMA tile of the 64 outputs; the patch is (4 + 1) x (16 + 2) pixels x 8 chunks (48 KB, double-buffered: one block per CU);
+// wave c fetches chunk c of the patch (chunks 0-3 from the first tensor, 4-7 from the second); 80 fragment reads for 128 MFMAs per wave
+// and tile; statistics as conv_s2c64.hip: running per-lane sums of the rounded outputs, one partial row per block AND column parity.
+template <bool STATS>
+__global__ __launch_bounds__(512, 1) void conv_dc256_kernel(const IgemmArgs a, const int ntiles) {
+  constexpr int NC8 = 8;                        // 64-byte chunks of the 256 input channels
+  constexpr int BUF8 = NC8 * PBUFB;             // one patch buffer (48 KB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, fg = lane >> 4;
+  const int pw = wave >> 2, q = wave & 3;       // column parity of this wave's class, its 16-channel tile of the 64 outputs
+
+  const int G = gridDim.x;
+  int v = blockIdx.x;
+  if ((G & 7) == 0) v = (v & 7) * (G >> 3) + (v >> 3);
+  const int ph = v & 1, bt = v >> 1, GT = G >> 1;
+  const int cls = 2 * ph + pw;
+
+  // weights of class cls: [tap][chunk][row][32 k], packed row 16 q + fi (odd 16-byte pieces un-swapped: conv_dc64_kernel)
+  uint4 W[4][NC8];
+  {
+    const bf16* wp = reinterpret_cast<const bf16*>(a.Wp) + (size_t)cls * a.wp_rows * a.Kpad;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < NC8; ++c) {
+        const uint4 w = *reinterpret_cast<const uint4*>(wp + ((size_t)(t * NC8 + c) * a.wp_rows + 16 * q + fi) * 32 + fg * 8);
+        W[t][c] = (fg & 1) ? make_uint4(w.z, w.w, w.x, w.y) : w;
+      }
+  }
+  // accumulator rows 4 fg .. + 3 of tile q of the 64-row block: channels 32 (q >> 1) + 8 fg + 4 (q & 1) + e
+  const int c0 = 32 * (q >> 1) + 8 * fg + 4 * (q & 1);
+  f32x4 bia = (f32x4){0.f, 0.f, 0.f, 0.f};        // (no bias in front of a batch-norm - it cancels; the plain op has one)
+  if (a.bias) bia = (f32x4){a.bias[c0], a.bias[c0 + 1], a.bias[c0 + 2], a.bias[c0 + 3]};
+
+  int tb0[2];
+#pragma unroll
+  for (int pc = 0; pc < 2; ++pc) {
+    const int px = fi + pw + pc;
+    tb0[pc] = (px << 6) + (((fg ^ (px >> 1)) & 3) << 4);
+  }
+  // patch DMA: wave c fetches chunk c, all six rounds of 16 patch pixels; two 128-channel tensors (the step) or one of 256 (the plain op)
+  const bool two = a.x.C[1] != 0;
+  const int pixb = (two ? 128 : 256) * (int)sizeof(bf16);        // bytes of a source pixel
+  int ppy[NROUND], ppx[NROUND], prel[NROUND];
+#pragma unroll
+  for (int j = 0; j < NROUND; ++j) {
+    const int pp = j * 16 + (lane >> 2);
+    ppy[j] = pp < NPATCH ? pp / PW : 1 << 20;
+    ppx[j] = pp % PW;
+    prel[j] = pp < NPATCH ? (ppy[j] * a.Win + ppx[j]) * pixb + (((lane & 3) ^ ((ppx[j] >> 1) & 3)) * 8) * (int)sizeof(bf16) : 0;
+  }
+  const unsigned srcbytes = (unsigned)((size_t)a.N * a.Hin * a.Win * pixb);
+  __amdgpu_buffer_rsrc_t rsX = make_rsrc((two && wave >= 4) ? a.x.ptr[1] : a.x.ptr[0], srcbytes);
+  const unsigned csoff = (unsigned)((two ? (wave & 3) : wave) * 64);
+  const int tiles_x = a.Wg / TW, tpi = tiles_x * (a.Hg / TH);
+  bf16* Yp = reinterpret_cast<bf16*>(a.Y);
+  constexpr int NST = 2;                        // 1 KB store instructions per tile and wave (4 rows x 4 KB / 8 waves)
+
+  auto issue_patch = [&](int t, int buf) {
+    const int n = t / tpi, rem = t - n * tpi;
+    const int y0 = (rem / tiles_x) * TH + ph - 1, x0 = (rem % tiles_x) * TW - 1;
+    const int base = ((n * a.Hin + y0) * a.Win + x0) * pixb;
+    uint4* l0 = reinterpret_cast<uint4*>(smem + buf * BUF8 + wave * PBUFB);
+#pragma unroll
+    for (int j = 0; j < NROUND; ++j) {
+      const int ih = y0 + ppy[j], iw = x0 + ppx[j];
+      const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      dma16_buf(rsX, ok ? (unsigned)(base + prel[j]) : DMA_OOB, csoff, l0 + j * 64);
+    }
+  };
+
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+
+  if (bt < ntiles) issue_patch(bt, 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < NC8; ++c) asm volatile("" : "+v"(W[t][c].x), "+v"(W[t][c].y), "+v"(W[t][c].z), "+v"(W[t][c].w));
+  int it = 0;
+  for (int t = bt; t < ntiles; t += GT, ++it) {
+    const int buf = it & 1;
+    if (it == 0) wait_vm<0>();
+    else wait_vm<NST>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + GT < ntiles) issue_patch(t + GT, buf ^ 1);
+    int tb[2];
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) tb[pc] = tb0[pc] + buf * BUF8;
+
+    // ---- 80 fragment steps (chunk, pc, patch row R): one ds_read_b128 each, fed to tile rows R - 1 (pr = 1) and R (pr = 0): 128 MFMAs ----
+    f32x4 acc[TH];
+#pragma unroll
+    for (int r = 0; r < TH; ++r) acc[r] = bia;
+    constexpr int LA = 2, NS = LA + 1, NSTEP = NC8 * 2 * PH;
+    u32x4 rb[NS];
+    auto rd = [&](auto sc) {
+      constexpr int S = decltype(sc)::value, c = S / (2 * PH), pc = (S / PH) % 2, R = S % PH;
+      rb[S % NS] = lds_rd128<c * PBUFB + R * PW * 64>(tb[pc]);
+    };
+    static_steps([&](auto sc) { rd(sc); }, std::make_integer_sequence<int, LA>{});
+    static_steps([&](auto sc) {
+      constexpr int S = decltype(sc)::value, c = S / (2 * PH), pc = (S / PH) % 2, R = S % PH;
+      if constexpr (S + LA < NSTEP) rd(std::integral_constant<int, S + LA>{});
+      constexpr int AHEAD = (NSTEP - 1 - S < LA ? NSTEP - 1 - S : LA);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(AHEAD) : "memory");
+      asm volatile("" : "+v"(rb[S % NS]));
+      const uint4 fb = make_uint4(rb[S % NS].x, rb[S % NS].y, rb[S % NS].z, rb[S % NS].w);
+      static_steps([&](auto ri) {
+        constexpr int r = R - 1 + decltype(ri)::value;
+        if constexpr (r >= 0 && r < TH) {
+          constexpr int tap = 3 - (2 * (R - r) + pc);
+          acc[r] = mma16<bf16>(W[tap][c], fb, acc[r]);
+        }
+      }, std::make_integer_sequence<int, 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, NSTEP>{});
+
+    // ---- epilogue: rounding, statistics of the rounded values, the tile through LDS, whole output rows out ----
+    char* stg = smem + 2 * BUF8;
+    // this lane's 8 bytes of output column 2 fi + pw: 16-byte slot (c0 / 8) ^ (fi & 7) of the pixel's 128 bytes
+    const int wslot = ((((c0 >> 3) ^ fi) & 7) << 4) + ((c0 & 4) << 1);
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      uint2 pk;
+      pk.x = Elem<bf16>::pack2(acc[r][0], acc[r][1]);
+      pk.y = Elem<bf16>::pack2(acc[r][2], acc[r][3]);
+      if constexpr (STATS) {
+        const float v0 = __uint_as_float(pk.x << 16), v1 = __uint_as_float(pk.x & 0xffff0000u);
+        const float v2 = __uint_as_float(pk.y << 16), v3 = __uint_as_float(pk.y & 0xffff0000u);
+        ssum[0] += v0; ssum[1] += v1; ssum[2] += v2; ssum[3] += v3;
+        ssq[0] = fmaf(v0, v0, ssq[0]); ssq[1] = fmaf(v1, v1, ssq[1]); ssq[2] = fmaf(v2, v2, ssq[2]); ssq[3] = fmaf(v3, v3, ssq[3]);
+      }
+      *reinterpret_cast<uint2*>(stg + (r * 32 + 2 * fi + pw) * 128 + wslot) = pk;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // wave w stores half of output row 2 (q0 + (w >> 1)) + ph: columns 16 (w & 1) + 8 j + (lane >> 3), 16-byte slot lane & 7
+    {
+      const int n = t / tpi, rem = t - n * tpi;
+      const int q0 = (rem / tiles_x) * TH, r0 = (rem % tiles_x) * TW;
+      const int row = wave >> 1;
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        const int oc = 16 * (wave & 1) + 8 * j + (lane >> 3), sl = lane & 7;
+        // column oc = 2 fi' + pw' was written at slot s ^ (fi' & 7) = s ^ ((oc >> 1) & 7)
+        const uint4 o = *reinterpret_cast<const uint4*>(stg + (row * 32 + oc) * 128 + ((sl ^ ((oc >> 1) & 7)) << 4));
+        unsigned* yp = reinterpret_cast<unsigned*>(Yp + ((size_t)(n * a.Hof + 2 * (q0 + row) + ph) * a.Wof + 2 * r0 + oc) * 64 + sl * 8);
+        __builtin_nontemporal_store(o.x, yp); __builtin_nontemporal_store(o.y, yp + 1);
+        __builtin_nontemporal_store(o.z, yp + 2); __builtin_nontemporal_store(o.w, yp + 3);
+      }
+    }
+  }
+  if constexpr (STATS) {
+    // one partial row per block and column parity (chunk 2 block + pw): the 16 lanes of a channel quad combine in a fixed order
+    float s[4], qq[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s[e] = ssum[e]; qq[e] = ssq[e];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) { s[e] += __shfl_xor(s[e], m); qq[e] += __shfl_xor(qq[e], m); }
+    }
+    if (fi == 0) {
+      double* rowp = a.bn_part + ((size_t)(2 * blockIdx.x + pw) * 2) * a.Cout + c0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { rowp[e] = (double)s[e]; rowp[a.Cout + e] = (double)qq[e]; }
+    }
+  }
+}
+
+// a patch2-plan transposed convolution from TWO 128-channel tensors to 64 channels, raw bf16 output, optional batch statistics of ONE group
+bool conv_dc256_eligible(const IgemmArgs& a, int is_bf16) {
+  if (!dc64_knob() || !is_bf16 || a.patch != 2 || a.nclass != 4 || a.ntaps != 4 || a.os != 2) return false;
+  if (a.Cout != 64 || a.CoutPad != 64 || a.ldY != 64 || a.Cin != 256 || !a.rowperm || a.splitk != 1) return false;
+  if (!((a.x.C[0] == 128 && a.x.C[1] == 128) || (a.x.C[0] == 256 && a.x.C[1] == 0))) return false;
+  if (a.Hg % TH || a.Wg % TW || a.Hin != a.Hg || a.Win != a.Wg || a.Hof != 2 * a.Hg || a.Wof != 2 * a.Wg) return false;
+  if (a.out_act != ACT_NONE || a.y_f32 || a.ref || a.accumulate || a.split_c || a.pool_out || a.x.aff_a[0] || a.x.aff_a[1] || a.x.act != ACT_NONE) return false;
+  for (int cls = 0; cls < 4; ++cls) {
+    if (a.o0h[cls] != (cls >> 1) || a.o0w[cls] != (cls & 1)) return false;
+    for (int t = 0; t < 4; ++t)
+      if (a.taps[cls].dh[t] != (cls >> 1) - (t >> 1) || a.taps[cls].dw[t] != (cls & 1) - (t & 1)) return false;
+  }
+  if (a.N * (a.Hg / TH) * (a.Wg / TW) < 256) return false;       // (two tiles per block and row parity at least: the 128-register weight load)
+  return (size_t)a.N * a.Hin * a.Win * 256 * 2 < 0x70000000ull;
+}
+int conv_dc256_grid(const IgemmArgs& a) {
+  const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);          // per row parity
+  return 2 * ntiles < 256 ? 2 * ntiles : 256;                  // one eight-wave block on each CU; even: both row parities
+}
+hipError_t launch_conv_dc256(const IgemmArgs& a, hipStream_t st) {
+  const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);
+  const int grid = conv_dc256_grid(a);
+  if (a.bn_part && a.bn_nchunk != 2 * grid) return hipErrorInvalidValue;
+  const int ki = a.bn_part ? 1 : 0;
+  void (*kerns[2])(const IgemmArgs, const int) = {conv_dc256_kernel<false>, conv_dc256_kernel<true>};
+  void (*kern)(const IgemmArgs, const int) = kerns[ki];
+  const int smem = 2 * 8 * PBUFB + STGB;                       // 112 KB
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[ki]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_done[ki] = true; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a, ntiles);
+  return hipGetLastError();
+}
+
 // a patch2-plan transposed convolution (conv_ops.h plan_make_patch2) from one 128-channel tensor to 64 channels, plain stores
 bool conv_dc64_eligible(const IgemmArgs& a, int is_bf16) {
   if (!is_bf16 || a.patch != 2 || a.nclass != 4 || a.ntaps != 4 || a.os != 2) return false;

@@ -1879,6 +1879,11 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
   if constexpr (sizeof(T) == 2) {
     // 4x4 stride-2 transposed conv from 128 to 64 channels (backward-data of layer_2 / encoder_2 / encoder_fg_2): weights resident in
     // registers, two parity classes per block (conv_dc64.hip)
+    if (conv_dc256_eligible(a, 1)) {
+      ProfScope prof("dc256", true, 64, 128, 2.0 * Pn * a.Cout * kreal,
+                     es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
+      return launch_conv_dc256(a, st);
+    }
     if (dc64_knob() && conv_dc64_eligible(a, 1)) {
       ProfScope prof("dc64", true, 64, 128, 2.0 * Pn * a.Cout * kreal,
                      es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);

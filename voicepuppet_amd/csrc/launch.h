@@ -19,6 +19,9 @@ bool conv_c64_eligible(const IgemmArgs& a, int is_bf16);                        
 hipError_t launch_conv_c64(const IgemmArgs& a, hipStream_t st);
 bool conv_dc64_eligible(const IgemmArgs& a, int is_bf16);                                                           // conv_dc64.hip
 hipError_t launch_conv_dc64(const IgemmArgs& a, hipStream_t st);
+bool conv_dc256_eligible(const IgemmArgs& a, int is_bf16);      // conv_dc64.hip: the forward form for 2 x 128 input channels (merged2_decoder_2)
+int conv_dc256_grid(const IgemmArgs& a);                       // its blocks; batch-norm partial rows = 2 per block
+hipError_t launch_conv_dc256(const IgemmArgs& a, hipStream_t st);
 bool conv_s2c64_eligible(const IgemmArgs& a, int is_bf16);                                                          // conv_s2c64.hip
 int conv_s2c64_grid(const IgemmArgs& a);                   // blocks of the launch = partial rows per batch-norm group
 int conv_s2c64_tiles_per_image(const IgemmArgs& a);

@@ -702,7 +702,12 @@ static int run_layer_fwd(vp_pixrefer* h, Net& n, Layer& L, hipStream_t st, void*
   // batch statistics from the conv epilogue (no re-read of the output) when every pixel tile lies inside one BN group
   bool fused_stats = false;
   int stat_chunks = 0;
-  if (L.has_bn && a.patch == 4) {
+  if (L.has_bn && n.groups == 1 && h->bf16 && !L.tapgemm && conv_dc256_eligible(a, 1)) {
+    // conv_dc64.hip conv_dc256_kernel: one partial row per block and column parity
+    stat_chunks = 2 * conv_dc256_grid(a);
+    a.bn_part = bnp_of(h, ss); a.bn_tpg = 1 << 30; a.bn_nchunk = stat_chunks;
+    fused_stats = true;
+  } else if (L.has_bn && a.patch == 4) {
     // conv_s2c64.hip: one partial row per block and group
     const int grid = conv_s2c64_grid(a);
     if ((size_t)n.groups * grid * 2 * to.C <= (size_t)1024 * 2 * 512 && n.groups <= 32) {
