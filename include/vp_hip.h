@@ -186,9 +186,12 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
  * the call see the new value.  Keys: "patch_tiles" (bit 0 / 1 / 2: allow the 256- / 128- / 64-row tiles of the stride-1 patch
  * kernel, default 7), "patch_min_blocks" (smallest grid that runs on it, default 384), "patch_small_tiles" (bit 0: 16x16-pixel
  * tiles for the 128- / 64-row variants, bit 1: 8x16 for the 256-row variant - two blocks per CU; default 3), "patch_long_k_on_256"
- * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile), "c64" / "dc64" (default 1: the
- * register-resident-weights kernels conv_c64.hip / conv_dc64.hip; 0: the patch kernels those layers ran on before).  No counterpart in
- * the reference.  (The step executor's schedule is per plan: vp_pixrefer_desc / vp_pixrefer_set_option.) */
+ * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile - float32 plans; bf16 plans: "patch4"), "c64" / "dc64" (default 1: the
+ * register-resident-weights kernels conv_c64.hip / conv_dc64.hip - "dc64" also the forward form conv_dc256_kernel; 0: the patch kernels
+ * those layers ran on before), "s2c64" (smallest launch, in 4 x 16-pixel tiles, of the 64 -> 128 stride-2 convolutions that runs on
+ * conv_s2c64.hip: default 512, 0 = never), "s2c64_pair" (default 1: its two-output backward-data form for merged2_decoder_2), "patch4"
+ * (default 1: 4x4 stride-1 layers on the unrolled patch kernel with 16 tap steps), "bfm_dwproj" (default 1: BFMNet's depthwise + projection
+ * in one kernel; read at every forward call).  No counterpart in the reference.  (The step executor's schedule is per plan: vp_pixrefer_desc / vp_pixrefer_set_option.) */
 int vp_tune(const char* key, int value);
 /* Further keys: "smallp_max_pixels" (largest pixel count per parity class that runs on the few-pixel kernel conv_smallp.hip,
  * default 256, 0: off), "phase_marks" (1: the step executor records HIP events on the caller's stream at its phase boundaries).

@@ -12,7 +12,8 @@
 //   * the outputs of the two classes interleave along an output row: the tile goes through LDS and leaves as whole output rows (32 pixels
 //     x 128 bytes = 4 KB contiguous per row) with the act'(reference) product of the chain rule applied in registers before;
 //   * two blocks per CU (two waves per SIMD), counted vmcnt across the tile loop, XCD-aware block -> tile map: as conv_c64.hip.
-// bf16 only; class grids multiples of 4 x 16; no batch statistics: the launches above.
+// bf16 only; class grids multiples of 4 x 16; no batch statistics: the launches above.  conv_dc256_kernel (below): the FORWARD form for
+// 256 input channels from two tensors with the statistics in the block (merged2_decoder_2).
 #include "conv_ops.h"
 #include "igemm_device.h"
 #include "launch.h"

@@ -18,6 +18,8 @@
 //     batch-norm group the block walks; at a group boundary / the end the 16 lanes of a channel quad combine (fixed order) and the block
 //     writes ONE partial row per group: bn_part[group][block][2][128] - the chunk count of the finalize is the grid size.
 //   * one block per CU (two waves per SIMD), counted vmcnt across the tile loop, XCD-aware block -> tile map: as conv_c64.hip.
+//   * TWO-OUTPUT form (PAIR): the backward-data of the 256 -> 64 transposed convolution merged2_decoder_2 is the same convolution with
+//     2 x 128 output channels: see the template comment.
 // bf16 only; output grids multiples of 4 x 16.
 #include "conv_ops.h"
 #include "igemm_device.h"
