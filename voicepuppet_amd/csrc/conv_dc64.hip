@@ -418,6 +418,9 @@ bool conv_dc256_eligible(const IgemmArgs& a, int is_bf16) {
       if (a.taps[cls].dh[t] != (cls >> 1) - (t >> 1) || a.taps[cls].dw[t] != (cls & 1) - (t & 1)) return false;
   }
   if (a.N * (a.Hg / TH) * (a.Wg / TW) < 256) return false;       // (two tiles per block and row parity at least: the 128-register weight load)
+  // batch statistics: only the one-group form this kernel writes (two partial rows per block); a caller that set up per-tile rows (more
+  // than one batch-norm group: per-sample statistics of the inference plans) gets the patch kernel it chunked them for
+  if (a.bn_part && a.bn_nchunk != 2 * conv_dc256_grid(a)) return false;
   return (size_t)a.N * a.Hin * a.Win * 256 * 2 < 0x70000000ull;
 }
 int conv_dc256_grid(const IgemmArgs& a) {
