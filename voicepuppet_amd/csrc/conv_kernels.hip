@@ -2002,7 +2002,9 @@ template <typename T> static hipError_t launch_wgrad_t(const WgradArgs& a, int c
     case 5: case 6: {                                               // 256 / 128 rows x 128 cols, LDS-DMA + transpose reads (wgrad_tr.hip; bf16, plain operands)
       const bool plain = a.zeros && !a.g.aff_a[0] && !a.g.aff_a[1] && a.g.act == ACT_NONE && !a.d.aff_a[0] && !a.d.aff_a[1] && a.d.act == ACT_NONE;
       if (sizeof(T) != 2 || !plain) return hipErrorInvalidValue;
-      e = launch_wgrad_tr(a, st, &g_prof_family);
+      int cols = pbn;
+      e = launch_wgrad_tr(a, st, &g_prof_family, &cols);
+      prof.bp = cols;                                                // (the 256-column tile where the launcher took it: the class names the template instance)
       break;
     }
     default: return hipErrorInvalidValue;

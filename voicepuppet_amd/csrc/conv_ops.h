@@ -116,6 +116,7 @@ inline int& patch_tiles_knob() { static int v = 7; return v; }
 inline int& patch_small_knob() { static int v = 3; return v; }   // two-blocks-per-CU tiles (see patch_tile_pixels)
 inline int& patch_longk_knob() { static int v = 1; return v; }      // 1: long-K 512-row layers stay on the 256x256 tile
 inline int& patch3_knob() { static int v = 1; return v; }   // 3x3 layers on the unrolled patch kernel (conv_patch3.hip)
+inline int& wgrad_big_knob() { static int v = 1; return v; }   // 256 x 256 tile of wgrad_tr.hip where the grid still fills the CUs
 inline int& patch4_knob() { static int v = 1; return v; }   // 4x4 stride-1 backward-data passes on the unrolled patch kernel (conv_patch3.hip, KW = 4)
 inline int& c64_knob() { static int v = 1; return v; }   // 64 -> 64 channel 3x3 layers on the register-resident-weights kernel (conv_c64.hip)
 inline int& dc64_knob() { static int v = 1; return v; }  // 128 -> 64 channel transposed-conv classes on conv_dc64.hip

@@ -34,7 +34,7 @@ hipError_t launch_smallp_fused(const SmallPArgs& s, int is_bf16, hipStream_t st)
 hipError_t launch_wgrad(const WgradArgs& a, int is_bf16, int cfg, hipStream_t st);
 bool wgrad_mm_eligible(const WgradArgs& a, int cfg);                                                                                      // wgrad_mm.hip
 hipError_t launch_wgrad_mm(const WgradArgs& a, int cfg, hipStream_t st);
-hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st, const char** variant = nullptr);                                          // wgrad_tr.hip
+hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st, const char** variant = nullptr, int* tile_cols = nullptr);                                          // wgrad_tr.hip
 void wgrad_tile(int cfg, int* bm, int* bn);
 
 void profile_enable(int on);          // 1: per kernel kind, 2: per layer tag

@@ -68,6 +68,7 @@ int vp_tune(const char* key, int value) {
   if (k == "c64") { c64_knob() = value; return VP_OK; }
   if (k == "dc64") { dc64_knob() = value; return VP_OK; }
   if (k == "s2c64") { s2c64_knob() = value; return VP_OK; }
+  if (k == "wgrad_big") { wgrad_big_knob() = value; return VP_OK; }
   if (k == "patch4") { patch4_knob() = value; return VP_OK; }
   if (k == "s2c64_pair") { s2c64_pair_knob() = value; return VP_OK; }
   if (k == "bfm_dwproj") { bfm_dwproj_knob() = value; return VP_OK; }

@@ -19,6 +19,7 @@
 // 64 x 64, 64 accumulator registers, 3-deep ring of 24 KB stages, counted vmcnt, one barrier per chunk, two blocks per CU.
 #include <stdlib.h>
 
+#include "conv_ops.h"
 #include "igemm_device.h"
 #include "launch.h"
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ const void* tr_src(const WgradArgs& a, const TrTask& 
 // EXACT (fast path only): the padded K grid IS the dY image (Hb = 2^lh, Wb = 2^lw): no slot of a chunk lies outside it, the dY
 // lanes need no per-chunk work at all and the gathered lanes only their two tap range checks
 template <int WM, int WN, int TC, int TP, int NST, bool FAST, bool EXACT = false>
-__global__ __launch_bounds__(WM * WN * 64, 4) void wgrad_tr_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (TC * TP > 16 ? 2 : 4)) void wgrad_tr_kernel(const WgradArgs a) {      // (256 x 256 tile: 128 accumulator registers, one block per CU)
   constexpr int NW = WM * WN;
   static_assert(NW == 8, "eight waves");
   constexpr int BM = WM * TC * 16, BN = WN * TP * 16;
@@ -304,7 +305,15 @@ static hipError_t launch_wgrad_tr_t(const WgradArgs& a, hipStream_t st, const ch
 
 // wgrad cfg 5: 256 rows x 128 columns; cfg 6: 128 x 128 (the 6- / 3-channel input layers: 16 taps x 8 padded channels = 128 rows,
 // 64 real columns - HBM-bound, the point is the loader: LDS-DMA instead of register loads + 8x8 transposes)
-hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st, const char** variant) {
+hipError_t launch_wgrad_tr(const WgradArgs& a, hipStream_t st, const char** variant, int* tile_cols) {
+  if (tile_cols) *tile_cols = 128;
+  // 256 x 256 tile (round 5 experiment): half the operand fill per MFMA of the 256 x 128 tile, one block per CU; where it still fills the CUs
+  // (and the dense operand's 256-column tile must not straddle a virtual concat: the fast loader)
+  if (wgrad_big_knob() && a.Mpad % 256 == 0 && a.Dpad % 256 == 0 && (long long)(a.Mpad / 256) * (a.Dpad / 256) * a.splitk >= 256 &&
+      (a.d.C[1] == 0 || a.d.C[0] % 256 == 0) && a.lw + a.lh >= 5) {       // (few-pixel layers keep the 128-column tile: they run the generic loader)
+    if (tile_cols) *tile_cols = 256;
+    return launch_wgrad_tr_t<4, 2, 4, 8>(a, st, variant);
+  }
   if (a.Mpad % 256 == 0) return launch_wgrad_tr_t<4, 2, 4, 4>(a, st, variant);
   return launch_wgrad_tr_t<4, 2, 2, 4>(a, st, variant);
 }
