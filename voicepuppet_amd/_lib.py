@@ -175,6 +175,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
       raise RuntimeError("libvp_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "or `make -C voicepuppet_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # PyTorch first: it carries its own HIP runtime (torch/lib/libamdhip64.so); a process that loaded the system runtime through THIS
+    # library before importing torch ends up with two runtimes, and the second finds no device ("no ROCm-capable device is detected" from
+    # the first HIP call of the library - seen with __graft_entry__.build() followed by smoke() in one process).  Loaded in this order
+    # the library binds to the runtime torch already mapped.
+    try:
+      import torch  # noqa: F401
+    except ImportError:
+      pass
     l = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
       try:
