@@ -53,6 +53,7 @@ def parse_args(argv=None):
   ap.add_argument("--no-other-scaling", action="store_true")
   ap.add_argument("--no-input-pipeline", action="store_true")
   ap.add_argument("--no-bfmnet-train", action="store_true", help="skip the BFMNet training-step sub-record (SURVEY.md 8f-4)")
+  ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE workloads (h512_bs2, h512_bs8, bs8_256, config3 sub-records)")
   ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="vp_tune knob for experiments (repeatable)")
   ap.add_argument("--grad-dtype", default="auto", choices=["auto", "f32", "bf16"],
                   help="N > 1: transport type of the gradient all-reduce (f32 master either way); auto = the compute dtype")
@@ -294,6 +295,7 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
       ev.record()
       dog.beat(ev)
 
+  beat()          # armed from the start: a peer that dies during rendezvous / warm-up must not leave this rank in sync() for ever
   for _ in range(warmup):
     step()
   beat()
@@ -400,6 +402,57 @@ def run_with_input_pipeline(per_gpu, height, dtype, steps, warmup, device):
           "what": "uint8 frames in pinned host memory -> PCIe -> vp_pixrefer_pack_frames -> G+D step, copies and packing overlapped with the previous step"}
 
 
+def secondary_records(device, steps, rank, world, group):
+  """The other BASELINE.json workloads inside the driver-run line: few steps each, every one with `ms_per_step`,
+  `step_frac` against the SURVEY.md 8d step roofline scaled to its batch and image size, and its dominant kernel class from the live
+  HIP-event pass.  h512_bs2 = the reference's own training configuration (train_pixrefer.py:36-43); h512_bs8 = BASELINE config 4's
+  per-GPU share; bs8_256 = BASELINE config 2; config3 = log-mel + BFMNet on 64 x 1 s (BASELINE config 3)."""
+  import numpy as np
+  import torch
+  out = {}
+  for key, n, h in (("bs8_256", 8, 256), ("h512_bs2", 2, 512), ("h512_bs8", 8, 512)):
+    r = run_config(n, h, "bf16", max(10, steps), 5, rank, world, device, group, True)
+    roof = r.get("roofline") or {}
+    out[key] = {"workload": "G+D step bf16, batch %d, %dx%d" % (n, h, h), "ms_per_step": r["ms_per_step"], "frames_per_s": r["frames_per_s"],
+                "step_tflops": r["step_tflops"], "step_roofline_ms": roof.get("step_roofline_ms"), "step_frac": roof.get("step_frac"),
+                "dominant_class": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches_per_step")}}
+  # BASELINE config 3: log-mel (one launch, HBM / launch bound) + BFMNet inference (float32 MFMA) on 64 clips of 1 s
+  from voicepuppet_amd.audio import BFMNetEngine, LogMel
+  from voicepuppet_amd.bfmnet.bfmnet import random_variables
+  B, T = 64, 25
+  samples = 128 * (5 * T - 1) + 512                                   # infer_bfmvid.py:166: exactly 5 log-mel rows per video frame
+  g = torch.Generator(device="cpu").manual_seed(0)
+  tt = torch.arange(samples, dtype=torch.float32) / 16000.0
+  sweep = 0.3 * torch.sin(2 * np.pi * (100.0 * tt + 0.5 * (4000.0 - 100.0) / tt[-1] * tt * tt))     # SURVEY.md 8d: noise + 100 -> 4000 Hz sweep
+  pcm = (0.1 * torch.randn(B, samples, generator=g) + sweep).clamp(-1, 1).to(device)
+  lm, net = LogMel(B, samples), BFMNetEngine(B, T)
+  net.load_params(random_variables(0))
+  ears, seq = torch.full((B, T, 1), 0.3, device=device), [T] * B
+
+  def timed(fn, warm, k):
+    for _ in range(warm):
+      fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+      fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / k * 1e3
+  ms_lm = timed(lambda: lm(pcm), 3, 20)
+  mf = lm(pcm)
+  ms_net = timed(lambda: net.forward(ears, mf, seq), 3, 10)
+  gflop = 10.64 * B                                                   # SURVEY.md 8d: 10.61 MfccNet + 0.03 head per 1 s clip
+  out["config3"] = {"workload": "log-mel -> BFMNet f32, 64 clips x 1 s", "ms_per_step": ms_lm + ms_net, "logmel_ms": ms_lm, "bfmnet_ms": ms_net,
+                    "audio_seconds_per_s": B / (ms_lm + ms_net) * 1e3,
+                    "bfmnet": {"bound": "mfma", "achieved": gflop / ms_net, "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": gflop / ms_net / F32_MFMA_PEAK},
+                    "logmel": {"bound": "hbm", "achieved": 4.0 * (pcm.numel() + mf.numel()) / ms_lm / 1e6, "peak": 8000.0, "unit": "GB/s",
+                               "frac": 4.0 * (pcm.numel() + mf.numel()) / ms_lm / 1e6 / 8000.0, "note": "one 35 us launch: launch-bound, no MFMA roofline claimed"},
+                    "step_frac": gflop / ms_net / F32_MFMA_PEAK}
+  del lm, net
+  torch.cuda.empty_cache()
+  return out
+
+
 def per_gpu_batch(args, scaling, world):
   if scaling == "weak":
     return args.batch
@@ -485,6 +538,10 @@ def main():
   if world == 1 and not args.no_bfmnet_train:
     f4 = bfmnet_train_record(device, not args.no_cpu_baseline)
 
+  secondary = None
+  if world == 1 and not args.no_secondary and args.dtype == "bf16":
+    secondary = secondary_records(device, min(args.steps, 10), rank, world, group)
+
   if rank == 0:
     n, h = main_res["per_gpu_batch"], args.height
     out = {"metric": "PixReferNet G+D step frames/sec @256x256 bs=32", "value": main_res["frames_per_s"], "unit": "frames/s",
@@ -508,6 +565,8 @@ def main():
       out["with_input_pipeline"] = pcie
     if f4 is not None:
       out["bfmnet_train"] = f4
+    if secondary is not None:
+      out.update(secondary)           # h512_bs2, h512_bs8, bs8_256, config3: top-level keys of the line
     if not args.no_cpu_baseline and world == 1:
       out["cpu_baseline"] = cpu_baseline(args.height)
     print(json.dumps(out), flush=True)

@@ -63,6 +63,13 @@ typedef struct vp_pixrefer_desc {
   int d_beside_vgg;
 } vp_pixrefer_desc;
 
+/* ABI rule for this descriptor (the precedent is utils/cython/mesh_core.h:53-77: explicit sizes, caller-owned buffers): the struct only
+ * ever GROWS AT THE TAIL (rounds 1-4: the first 9 fields = 36 bytes; round 5 added the three schedule fields = 48 bytes), and every entry
+ * point that takes it reads sizeof(vp_pixrefer_desc) bytes OF THE LIBRARY'S BUILD.  A binding that declares the struct itself (ctypes,
+ * cgo, JNI) must check vp_pixrefer_desc_size() == its own sizeof at load time and refuse to run on a mismatch - a shorter struct would
+ * be over-read (INTEGRATION.md B does; tests/test_host_logic.py executes that stub under AddressSanitizer). */
+size_t vp_pixrefer_desc_size(void);
+
 typedef struct vp_pixrefer vp_pixrefer_t;
 
 /* Parameter manifest: TF variable names -> offset/shape in the flat f32 arenas.
@@ -98,6 +105,10 @@ int vp_pixrefer_optimizer_stepped(vp_pixrefer_t* h);
  * discriminator applications, the VGG trunk and all losses. */
 int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_inputs,
                         const float* targets, const float* masks, void* stream);
+
+/* The inference graph as infer_bfmvid.py:202-205 feeds it: fg_inputs3 [N,H,H,3] (build_inference_op reads fg_inputs[..., :3] only,
+ * pixrefer.py:281).  Inference plans only (VP_ERR_STATE on a training plan, whose graph reads channels 3:6 too). */
+int vp_pixrefer_forward_fg3(vp_pixrefer_t* h, const float* inputs, const float* fg_inputs3, const float* targets, void* stream);
 
 /* Both gradient sets from the forward just run: d(Discrim_loss)/d(discriminator*) -> grads_d,
  * d(Gen_loss)/d(generator*) -> grads_g (pixrefer.py:396-407; pre-update weights for both). */

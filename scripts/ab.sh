@@ -17,7 +17,7 @@ for round in 1 2; do
       for tok in $setting; do
         case "$tok" in tune:*) tunes="$tunes --tune ${tok#tune:}";; *) envs="$envs $tok";; esac
       done
-      env $envs python bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-profile --no-f32 --no-scaling-ceiling --no-input-pipeline --no-bfmnet-train --global-batch $gb $tunes > $o/b_${gb}_$i.json 2> $o/b_${gb}_$i.err
+      env $envs python bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-profile --no-f32 --no-scaling-ceiling --no-input-pipeline --no-bfmnet-train --no-secondary --global-batch $gb $tunes > $o/b_${gb}_$i.json 2> $o/b_${gb}_$i.err
       python -c "import json;d=json.load(open('$o/b_${gb}_$i.json'));print('batch $gb [$setting]', round(d['ms_per_step'],3))" || tail -3 $o/b_${gb}_$i.err
     done
   done

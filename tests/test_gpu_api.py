@@ -413,3 +413,48 @@ def test_host_fetch_path_holds_no_framework_arithmetic():
   eng = open(os.path.join(root, "bfmnet", "train_engine.py")).read()
   for pat in (r"part\.sum\(\)", r"torch\.stack\(", r"torch\.sqrt\(ss\)", r"grads\.mul_\(", r"torch\.clamp\("):
     assert not re.search(pat, eng), pat
+
+
+def test_infer_bfmvid_frame_batch_runs_no_framework_kernel_but_copies():
+  """a frame batch of infer_bfmvid (build_inference_op fed a 3-channel FGInputs, infer_bfmvid.py:202-205, fetching the
+  uint8 frames and Outputs_FG) traced op by op: every ATen call the host path makes is a copy / allocation / view - torch.cat and
+  zeros_like on the foreground reference are gone (vp_pixrefer_forward_fg3 reads the [N,H,H,3] tensor as it is) - and the result equals
+  the 6-channel feed of the same data bit for bit."""
+  import torch
+  from torch.utils._python_dispatch import TorchDispatchMode
+  from voicepuppet_amd.pixrefer.pixrefer import PixReferNet
+  from voicepuppet_amd.runtime import Placeholder
+
+  net = PixReferNet(CFG)
+  params = net.params
+  params.batch_size = 2
+  params.add_hparam('is_training', False)
+  params.ngf = params.ndf = 8
+  net.set_params(params)
+  ih, fh, th = Placeholder((None, 256, 256, 6), 'inputs'), Placeholder((None, 256, 256, 3), 'fg'), Placeholder((None, 256, 256, 3), 'targets')
+  nodes = net.build_inference_op(ih, fh, th)
+  rng = np.random.default_rng(5)
+  feed = {ih: rng.uniform(size=(2, 256, 256, 6)).astype(np.float32), fh: rng.uniform(size=(2, 256, 256, 3)).astype(np.float32),
+          th: rng.uniform(size=(2, 256, 256, 3)).astype(np.float32)}
+  net.execute(['Outputs_u8'], feed)       # (first call: packs the weights)
+
+  seen = []
+
+  class Trace(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+      seen.append(func.__name__ if hasattr(func, '__name__') else str(func))
+      return func(*args, **(kwargs or {}))
+
+  with Trace():
+    got = net.execute(['Outputs_u8', 'Outputs_FG', 'Alphas'], feed)
+  allowed = ('_to_copy', 'copy_', 'empty', 'empty_strided', 'lift_fresh', 'detach', 'alias', 'view', '_unsafe_view', 'as_strided', 'slice', 'select',
+             'contiguous', 'clone', '_local_scalar_dense', 'unsqueeze', 'reshape', '_reshape_alias', 'to', 'cpu', 'is_pinned', '_pin_memory', 'record_stream')
+  bad = sorted({n for n in seen if n.split('.')[0] not in allowed})
+  assert not bad, (bad, seen)
+  assert seen, "the trace saw nothing"
+  # the same frames through the 6-channel entry point (what engine.forward did with torch.cat / zeros_like before)
+  eng = net.engine
+  fg6 = np.concatenate([feed[fh], np.zeros_like(feed[fh])], axis=-1)
+  eng.forward(torch.tensor(feed[ih]).cuda(), torch.tensor(fg6).cuda(), torch.tensor(feed[th]).cuda())
+  want = eng.fetch('Outputs_u8').cpu().numpy()
+  assert np.array_equal(got['Outputs_u8'], want)

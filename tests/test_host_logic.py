@@ -306,6 +306,67 @@ def test_host_layer_under_sanitizers():
   assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
 
 
+def _integration_stub():
+  """The host part of the ctypes binding INTEGRATION.md section B documents (the fenced block marked '[binding-stub: host part]')."""
+  import re
+  doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+  m = re.search(r"```python\n(# \[binding-stub: host part\]\n.*?)```", doc, re.S)
+  assert m, "INTEGRATION.md: the host part of the binding stub is gone"
+  return m.group(1)
+
+
+def _asan_env():
+  import shutil, subprocess
+  csrc = os.path.join(ROOT, "voicepuppet_amd", "csrc")
+  if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+    pytest.skip("no hipcc: the sanitizer build needs the HIP host compiler")
+  b = subprocess.run(["make", "-C", csrc, "-j4", "host-asan"], capture_output=True, text=True, timeout=900)
+  assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
+  so = os.path.join(ROOT, "voicepuppet_amd", "libvp_host_asan.so")
+  rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+  assert os.path.exists(rt), rt
+  env = dict(os.environ)
+  # PYTHONMALLOC=malloc: ctypes structures come from malloc (not from pymalloc's arenas), so ASan puts a red zone behind each one
+  env.update({"VP_LIB": so, "LD_PRELOAD": rt, "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0:exitcode=99", "UBSAN_OPTIONS": "halt_on_error=1:exitcode=98",
+              "PYTHONMALLOC": "malloc"})
+  return env
+
+
+def test_integration_stub_executes_under_asan():
+  """Row b3 of SURVEY.md section 8: the reference-side binding INTEGRATION.md shows is EXECUTED, as written, against the sanitizer build
+  of the host layer (declarations, load-time layout check, vp_pixrefer_param_count / _workspace_bytes / _validate_plan).  A descriptor
+  that drifts from include/vp_hip.h (round 5 grew the struct 36 -> 48 bytes and left the documented stub behind: VERDICT r5) fails
+  here twice over: the stub's own vp_pixrefer_desc_size() check, and AddressSanitizer on the over-read."""
+  import subprocess
+  env = _asan_env()
+  stub = _integration_stub()
+  code = stub + "\nassert ws_bytes > 0 and all(c > 0 for c in counts), (ws_bytes, counts)\nprint('stub ok', ctypes.sizeof(Desc), counts, ws_bytes)\n"
+  r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+  assert "stub ok 48" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout + r.stderr[-3000:]
+  # the declarations agree with the product binding and with the header's field list
+  import re
+  from voicepuppet_amd import _lib
+  fields = re.findall(r'\("(\w+)", ctypes\.c_(\w+)\)', stub[stub.index("class Desc"):stub.index("lib.vp_pixrefer_desc_size")])
+  assert fields == [(n, t.__name__[2:]) for n, t in _lib.PixReferDesc._fields_], fields
+  hdr = open(os.path.join(ROOT, "include", "vp_hip.h")).read()
+  body = hdr[hdr.index("typedef struct vp_pixrefer_desc {"):hdr.index("} vp_pixrefer_desc;")]
+  body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+  hfields = [n for decl in re.findall(r"\b(?:int|float)\s+([^;]+);", body) for n in re.split(r"\s*,\s*", decl.strip())]
+  assert hfields == [n for n, _ in fields], (hfields, fields)
+  # the test has teeth: the 9-field struct of rounds 1-4 (what INTEGRATION.md still showed after round 5), pushed past the size check,
+  # is caught by AddressSanitizer as a heap over-read inside the library
+  old = stub.replace('                ("streams", ctypes.c_int), ("d_backward_fork", ctypes.c_int), ("d_beside_vgg", ctypes.c_int)]', "                ]")
+  old = old.replace("if lib.vp_pixrefer_desc_size() != ctypes.sizeof(Desc):", "if False:")
+  assert old != stub and "if False:" in old
+  r2 = subprocess.run([sys.executable, "-c", old], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert r2.returncode != 0 and "heap-buffer-overflow" in r2.stderr, (r2.returncode, r2.stderr[-2000:])
+  # ... and by the stub's own check when it is left in
+  r3 = subprocess.run([sys.executable, "-c", old.replace("if False:", "if lib.vp_pixrefer_desc_size() != ctypes.sizeof(Desc):")], env=env, cwd=ROOT,
+                      capture_output=True, text=True, timeout=600)
+  assert r3.returncode != 0 and "library 48 bytes, binding 36" in r3.stderr, r3.stderr[-2000:]
+
+
 def test_product_library_reads_no_environment_switches():
   """Kernel selection and the executor's schedule are arguments (vp_pixrefer_desc, vp_pixrefer_set_option, vp_tune), not environment
   variables read once per process: no getenv in the library sources."""

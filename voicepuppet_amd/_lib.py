@@ -56,6 +56,8 @@ _SIGNATURES = {
     "vp_pixrefer_params_changed": (ctypes.c_int, [_P]),
     "vp_pixrefer_optimizer_stepped": (ctypes.c_int, [_P]),
     "vp_pixrefer_forward": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
+    "vp_pixrefer_forward_fg3": (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    "vp_pixrefer_desc_size": (ctypes.c_size_t, []),
     "vp_pixrefer_backward": (ctypes.c_int, [_P, _P]),
     "vp_pixrefer_backward_update": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                    ctypes.c_float, ctypes.c_float, _P]),
@@ -193,6 +195,12 @@ def lib():
         continue                             # an A/B build of an older tree (scripts/ab.sh): entry points added since are simply absent
       fn.restype = res
       fn.argtypes = args
+    # the descriptor is declared twice (include/vp_hip.h, PixReferDesc above): a library built from another header must not be handed
+    # this layout (include/vp_hip.h, "ABI rule"); an older A/B build (VP_LIB) without the query is the 48-byte round-5 layout
+    if hasattr(l, "vp_pixrefer_desc_size") and l.vp_pixrefer_desc_size.argtypes is not None:
+      want = int(l.vp_pixrefer_desc_size())
+      if want != ctypes.sizeof(PixReferDesc):
+        raise RuntimeError("%s: vp_pixrefer_desc is %d bytes in the library, %d in this binding" % (LIB_PATH, want, ctypes.sizeof(PixReferDesc)))
     _lib = l
   return _lib
 

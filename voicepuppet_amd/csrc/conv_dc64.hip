@@ -420,7 +420,9 @@ bool conv_dc256_eligible(const IgemmArgs& a, int is_bf16) {
   if (a.N * (a.Hg / TH) * (a.Wg / TW) < 256) return false;       // (two tiles per block and row parity at least: the 128-register weight load)
   // batch statistics: only the one-group form this kernel writes (two partial rows per block); a caller that set up per-tile rows (more
   // than one batch-norm group: per-sample statistics of the inference plans) gets the patch kernel it chunked them for
-  if (a.bn_part && a.bn_nchunk != 2 * conv_dc256_grid(a)) return false;
+  // (the caller states that layout itself: bn_tpg == 1 << 30 marks "one group, two partial rows per block" - a per-group table whose chunk
+  // count merely happens to equal 2 * grid must not be taken for it: ADVICE r5)
+  if (a.bn_part && (a.bn_tpg != (1 << 30) || a.bn_nchunk != 2 * conv_dc256_grid(a))) return false;
   return (size_t)a.N * a.Hin * a.Win * 256 * 2 < 0x70000000ull;
 }
 int conv_dc256_grid(const IgemmArgs& a) {
@@ -430,7 +432,7 @@ int conv_dc256_grid(const IgemmArgs& a) {
 hipError_t launch_conv_dc256(const IgemmArgs& a, hipStream_t st) {
   const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);
   const int grid = conv_dc256_grid(a);
-  if (a.bn_part && a.bn_nchunk != 2 * grid) return hipErrorInvalidValue;
+  if (a.bn_part && (a.bn_tpg != (1 << 30) || a.bn_nchunk != 2 * grid)) return hipErrorInvalidValue;
   const int ki = a.bn_part ? 1 : 0;
   void (*kerns[2])(const IgemmArgs, const int) = {conv_dc256_kernel<false>, conv_dc256_kernel<true>};
   void (*kern)(const IgemmArgs, const int) = kerns[ki];

@@ -311,7 +311,9 @@ size_t bfm_carve(vp_bfmnet* h, char* base) {
     const int P = B * h->T5 * W;
     plan_gemm(h, b.g_expand, P, b.cin, b.cexp, 0, b.expand.wf, b.cexp, b.expand.bf, tb);
     plan_gemm(h, b.g_project, P, b.cexp, b.cout, 0, b.project.wf, b.cout, b.project.bf, tb);
-    b.fusable = !tb && dwproj_eligible(W, b.cexp, b.cout);
+    // (the fused kernel addresses the expanded tensor with 32-bit lane offsets - launch_dwproj refuses 0xF0000000 bytes and more: very long
+    // clips fall back to the depthwise kernel + the GEMM here, at plan time, instead of failing at run time: ADVICE r5)
+    b.fusable = !tb && dwproj_eligible(W, b.cexp, b.cout) && (size_t)P * b.cexp * sizeof(float) < 0xF0000000ull;
     if (b.fusable) { b.g_project.plan.pack.perm = 0; b.g_project.plan.a.rowperm = 0; }     // (the fused kernel reads plain packed rows; the GEMM kernels take either)
     if (b.shortcut) plan_gemm(h, b.g_sc, P, b.cin, b.cout, 0, b.sc.wf, b.cout, b.sc.bf, tb);
     if ((size_t)P * b.cexp > max_exp) max_exp = (size_t)P * b.cexp;

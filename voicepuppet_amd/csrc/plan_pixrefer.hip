@@ -1206,8 +1206,22 @@ int vp_pixrefer_optimizer_stepped(vp_pixrefer_t* h) {
   return VP_OK;
 }
 
+static int forward_impl(vp_pixrefer_t* h, const float* inputs, const float* fg_inputs, int fg_c, const float* targets, const float* masks, void* stream);
+
 int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_inputs,
                         const float* targets, const float* masks, void* stream) {
+  return forward_impl(h, inputs, fg_inputs, 6, targets, masks, stream);
+}
+
+// build_inference_op as infer_bfmvid.py:202-205 feeds it: fg_inputs [N,H,H,3] (the graph reads fg_inputs[..., :3] only, pixrefer.py:281)
+int vp_pixrefer_forward_fg3(vp_pixrefer_t* h, const float* inputs, const float* fg_inputs3, const float* targets, void* stream) {
+  if (h && h->d.training) { set_err("vp_pixrefer_forward_fg3: inference plans only (the training graph reads fg_inputs[..., 3:], pixrefer.py:297,321)"); return VP_ERR_STATE; }
+  return forward_impl(h, inputs, fg_inputs3, 3, targets, nullptr, stream);
+}
+
+size_t vp_pixrefer_desc_size(void) { return sizeof(vp_pixrefer_desc); }
+
+static int forward_impl(vp_pixrefer_t* h, const float* inputs, const float* fg_inputs, int fg_c, const float* targets, const float* masks, void* stream) {
   if (!h || !inputs || !fg_inputs || !targets) { set_err("vp_pixrefer_forward: null argument"); return VP_ERR_ARG; }
   const vp_pixrefer_desc& d = h->d;
   if (d.training && !masks) { set_err("vp_pixrefer_forward: masks required when training"); return VP_ERR_ARG; }
@@ -1227,7 +1241,7 @@ int vp_pixrefer_forward(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   PackInputsArgs pi;
   memset(&pi, 0, sizeof(pi));
   pi.inputs = inputs; pi.fg_inputs = fg_inputs; pi.gin = h->gin; pi.gfg = h->gfg; pi.din = h->din; pi.vin = h->vin;
-  pi.N = N; pi.HW = H * H; pi.train = d.training;
+  pi.N = N; pi.HW = H * H; pi.train = d.training; pi.fg_c = fg_c;
   phase_mark(h, st, 0);
   VP_HIP_CHECK(launch_pack_inputs(pi, bf, st));
 

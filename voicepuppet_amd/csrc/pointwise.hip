@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const PackInputsArgs a
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float in[6], fg[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { in[c] = a.inputs[i * 6 + c] * 2.f - 1.f; fg[c] = a.fg_inputs[i * 6 + c] * 2.f - 1.f; }
+    for (int c = 0; c < 6; ++c) { in[c] = a.inputs[i * 6 + c] * 2.f - 1.f; fg[c] = c < a.fg_c ? a.fg_inputs[i * a.fg_c + c] * 2.f - 1.f : -1.f; }
     { const float f[8] = {in[0], in[1], in[2], in[3], in[4], in[5], 0.f, 0.f}; store8<T>(reinterpret_cast<T*>(a.gin) + i * 8, f); }
     { const float f[8] = {fg[0], fg[1], fg[2], 0.f, 0.f, 0.f, 0.f, 0.f}; store8<T>(reinterpret_cast<T*>(a.gfg) + i * 8, f); }
     if (a.train) {

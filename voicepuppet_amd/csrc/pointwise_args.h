@@ -57,12 +57,13 @@ struct BnArgs {
 
 struct PackInputsArgs {
   const float* inputs;      // [N,H,W,6] in [0,1]
-  const float* fg_inputs;   // [N,H,W,6]
+  const float* fg_inputs;   // [N,H,W,fg_c]
   void* gin;                // [N,H,W,8]   generator input  (inputs*2-1, 0, 0)
   void* gfg;                // [N,H,W,8]   fg branch input  (fg[...,:3]*2-1, 0 x5)
   void* din;                // [3N,H,W,8]  discriminator batch: real1 | real2 | fake(cond only)
   void* vin;                // [2N,H,W,8]  VGG batch: real fg | (fake, written by composite)
   int N, HW, train;
+  int fg_c;                 // channels of fg_inputs: 6 (training graphs) or 3 (infer_bfmvid.py:203 feeds [N,H,W,3]); only 0:3 feed the generator
 };
 
 // On-device form of PixReferDataGenerator.iterator (generator/generator.py:956-1019): per sample two decoded jpg triptychs

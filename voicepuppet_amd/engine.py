@@ -155,13 +155,16 @@ class PixReferEngine:
     """float32 NHWC device tensors in [0,1] (generator.py:1011-1019 layout)."""
     N, H = self.desc.batch, self.desc.height
     assert inputs.shape == (N, H, H, 6) and targets.shape == (N, H, H, 3)
-    if fg_inputs.shape[-1] == 3:   # infer_bfmvid.py feeds a 3-channel foreground reference
-      fg_inputs = torch.cat([fg_inputs, torch.zeros_like(fg_inputs)], dim=-1)
     ts = [t.contiguous() for t in (inputs, fg_inputs, targets)]
     m = masks.contiguous() if masks is not None else None
     for t in ts + ([m] if m is not None else []):
       assert t.dtype == torch.float32 and t.is_cuda
     self._keep = (ts, m)   # the backward reads targets/masks again
+    if fg_inputs.shape[-1] == 3:   # infer_bfmvid.py:203 feeds a 3-channel foreground reference: the library reads it as it is
+      assert fg_inputs.shape == (N, H, H, 3) and not self.training
+      _lib.check(self.L.vp_pixrefer_forward_fg3(self.h, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _stream()), "vp_pixrefer_forward_fg3")
+      return
+    assert fg_inputs.shape == (N, H, H, 6)
     _lib.check(self.L.vp_pixrefer_forward(self.h, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(m), _stream()),
                "vp_pixrefer_forward")
 

@@ -225,7 +225,11 @@ class _MfccIterator(DatasetIterator):
     # The worker thread's order-defining draws come from a generator of THIS iterator, seeded from the module-level state where the
     # iterator is made (on the caller's thread) WITHOUT advancing it: the sample order is a function of random.seed() alone, whatever
     # the main thread or another iterator over the same DataGenerator draws meanwhile, and a caller that seeded `random` keeps its stream
-    self._rand = random.Random(hash(random.getstate()))
+    # (the seed is DRAWN from the stream and the stream put back: hash(random.getstate()) - round 5 - is not a function of the seed, the state
+    # tuple ends in None and hash(None) is the object's address before CPython 3.12, so two processes after random.seed(5) disagreed: ADVICE r5)
+    st = random.getstate()
+    self._rand = random.Random(random.getrandbits(64))
+    random.setstate(st)
 
   def _samples(self):
     while True:   # repeat()

@@ -113,7 +113,7 @@ def main(argv=None):
   # i.e. it continues the optimisation, not the bit-exact sample sequence of the interrupted run.
   resumed_step = 0
   resume_flag = opts.resume or (params.get('amd') or {}).get('resume', False)
-  if resume_flag:
+  if resume_flag and rank == 0:     # rank 0 reads the checkpoint; the other replicas receive the WHOLE restored state below
     from voicepuppet_amd.utils import tf_checkpoint
     latest = tf_checkpoint.latest_checkpoint(params.save_dir) if os.path.isdir(params.save_dir) else None
     if latest is not None and not os.path.exists(latest + '.index'):
@@ -132,6 +132,18 @@ def main(argv=None):
     for a in (vid2vidnet.engine.params_g, vid2vidnet.engine.params_d, vid2vidnet.engine.params_vgg):
       dist.broadcast(a, 0)
     vid2vidnet.engine.params_changed()
+    if resume_flag:
+      # ... and on a resumed run everything else a checkpoint restores: the Adam slots, the two update counters and global_step (the
+      # number of iterations left and the learning rate are functions of it).  A replica that restored from its own view of save_dir -
+      # or saw none and started at step 0 - would run a different number of iterations and hang its peers in a collective
+      eng = vid2vidnet.engine
+      for key in ('g', 'd'):
+        for a in eng.adam[key]:
+          dist.broadcast(a, 0)
+      st = torch.tensor([vid2vidnet.global_step, eng.t_g, eng.t_d], dtype=torch.int64, device=eng.device)
+      dist.broadcast(st, 0)
+      vid2vidnet.global_step, eng.t_g, eng.t_d = (int(x) for x in st.tolist())
+      resumed_step = vid2vidnet.global_step
 
   # rank liveness: losses are read only on summary steps, so a peer lost inside a collective shows up as a device
   # stream that stops finishing steps; the watchdog then ends this rank non-zero and torch.distributed.run stops the others
