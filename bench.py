@@ -253,14 +253,14 @@ STEP_ROOFLINE_MS_BS32_256 = {"bf16": 2.65, "f32": 33.6}      # mix
 
 # --tune keys that select the step executor's schedule of the benchmark plan: "streams" (vp_pixrefer_desc::streams: 1 = everything on
 # the caller's stream, no executor streams), "overlap" / "d_backward_fork" / "d_beside_vgg" (vp_pixrefer_set_option)
-SCHEDULE_KEYS = ("streams", "overlap", "d_backward_fork", "d_beside_vgg")
+SCHEDULE_KEYS = ("streams", "overlap", "d_backward_fork", "d_beside_vgg", "vgg_real_fork", "bwd_sums_in_epilogue")
 SCHEDULE = {}
 
 
 def make_engine(per_gpu, height, dtype):
   from voicepuppet_amd.engine import PixReferEngine
   eng = PixReferEngine(per_gpu, height, 64, 64, dtype=dtype, training=True, streams=SCHEDULE.get("streams", 0))
-  for k in ("overlap", "d_backward_fork", "d_beside_vgg"):
+  for k in ("overlap", "d_backward_fork", "d_beside_vgg", "vgg_real_fork", "bwd_sums_in_epilogue"):
     if k in SCHEDULE:
       eng.set_option(k, SCHEDULE[k])
   return eng

@@ -148,6 +148,12 @@ int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n);
  * initial values come from the descriptor (vp_pixrefer_desc::streams / d_backward_fork / d_beside_vgg).  Bit-identical results under
  * every setting. */
 int vp_pixrefer_set_option(vp_pixrefer_t* h, const char* key, int value);
+/* Round 6 keys: "bwd_sums_in_epilogue" 0 / 1 (default 1): the two sums of a batch-norm backward pass (sum dz, sum dz * zhat) come from the
+ * epilogue of the launch that completes the tensor's gradient instead of a pass of their own over y and dz (same values up to the order of
+ * float32 partial sums); "vgg_real_fork" k (default 3): the VGG pass of the real half starts on the side stream in front of generator layer
+ * k (TF scope order; 0 = right behind the input packing).  vp_pixrefer_counter: "bwd_sums_launches" = launches since create that carried
+ * such sums (-1: unknown key); for tests. */
+long long vp_pixrefer_counter(vp_pixrefer_t* h, const char* key);
 /* Node values PixReferNet.execute hands to a caller, formed on the device from the last forward pass into `dst` (device memory,
  * N * H * H * 3 elements): what = 0 Outputs (float32, (x + 1) / 2: pixrefer.py:424 / :380), 1 the same as uint8 frames (clamp, * 255,
  * truncate: the bytes infer_bfmvid.py:243 writes), 2 Alphas (float32, three channels: pixrefer.py:284), 3 Outputs_FG as this plan's

@@ -118,8 +118,8 @@ for mode in modes:
       eager = timed(f1)
       dot = os.path.join(OUT, "fwd_s%d_bs%d.dot" % (streams, n))
       report("fwd/s%d" % streams, eager, timed(capture(f1, dot).replay), dot)
-  elif mode == "trace":
-    eng, b = make(1)
+  elif mode in ("trace", "tracemulti"):
+    eng, b = make(1 if mode == "trace" else 0)
     fn = lambda: eng.train_step(*b, lr=3e-4)
     timed(fn, 5, 3)
     g = capture(fn)

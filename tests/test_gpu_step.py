@@ -740,3 +740,47 @@ def test_fused_backward_update_equals_separate_calls():
     assert a[0] == b[0], dtype
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), dtype
     assert all(torch.equal(x, y) for x, y in zip(a[3], b[3])) and a[4:] == b[4:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n,tol_stat,tol_grad,min_launches", [("f32", 2, 2e-5, 2e-4, 3), ("bf16", 8, 2e-5, 2e-2, 8)])
+def test_batch_norm_backward_sums_from_the_gradient_epilogue_in_situ(dtype, n, tol_stat, tol_grad, min_launches):
+  """Round 6: the launch that completes the gradient of a batch-normalised tensor also produces sum dz and sum dz * zhat in its epilogue
+  (staged_epilogue STATS == 2; plain, two-output, 2x2-tap and 4x4 patch launches of a full-width plan: generator encoders / decoders, the
+  discriminator's three-group pass and its one-group generator-loss pass), so the tensor's batch-norm backward starts at its finalize.
+  Against the same plan with the separate reduce pass (vp_pixrefer_set_option "bwd_sums_in_epilogue" 0): dgamma / dbeta of every
+  batch-norm (they ARE the sums) to float32 rounding of a different summation order, every gradient downstream to the same plus - bf16 -
+  the handful of roundings of dy that a 1e-7 change of its two coefficients flips."""
+  grads, counts = {}, {}
+  for on in (1, 0):
+    eng = PixReferEngine(n, 256, 64, 64, dtype=dtype, training=True)
+    eng.load_params(eng.random_params(5))
+    eng.set_option("bwd_sums_in_epilogue", 2 * on)         # 2: every launch that can carry them (the default keeps to the classes where it pays)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    batch = [torch.rand(n, 256, 256, c, generator=g).cuda() for c in (6, 6, 3, 3)]
+    eng.forward(*batch); eng.backward()
+    torch.cuda.synchronize()
+    counts[on] = int(eng.L.vp_pixrefer_counter(eng.h, b"bwd_sums_launches"))
+    grads[on] = (eng.get_params(1, src=eng.grads_d), eng.get_params(0, src=eng.grads_g))
+    del eng
+  # generator: encoder_2/3(/4 from 8 frames up), their foreground twins, the wide decoders; discriminator: layer_2, layer_3 (+ layer_4 on the
+  # tap path's 1x1 product) in both passes
+  assert counts[0] == 0 and counts[1] >= min_launches, counts
+  worst = {}
+  for which in (0, 1):
+    for k, ref_v in grads[0][which].items():
+      got = grads[1][which][k]
+      if not np.abs(ref_v).max() > 0:
+        assert not np.abs(got).max() > 0, k          # (the analytically zero bias gradients in front of a batch-norm)
+        continue
+      e = gu.rel_l2(got, ref_v)
+      kind = "stat" if k.endswith(("gamma", "beta")) else "grad"
+      worst[kind] = max(worst.get(kind, 0.0), e)
+      assert e < tol_grad, (k, e)
+  # the sums themselves, on the tensors whose gradient does not pass through an earlier fused batch-norm: the discriminator's deepest
+  # batch-norm (layer_4) and the generator's last (merged2_decoder_2)
+  for which, k in ((0, "discriminator/layer_4/batch_normalization/"), (1, "generator/merged2_decoder_2/batch_normalization/")):
+    for f in ("gamma", "beta"):
+      e = gu.rel_l2(grads[1][which][k + f], grads[0][which][k + f])
+      assert e < tol_stat, (k + f, e)
+  print("bwd sums in the epilogue (%s): %d launches, worst rel-L2 vs the reduce pass: %s" % (dtype, counts[1], worst))

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "vp_pixrefer_use_streams": (ctypes.c_int, [_P, ctypes.c_int]),
     "vp_pixrefer_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
     "vp_pixrefer_fetch": (ctypes.c_int, [_P, ctypes.c_int, _P, _P]),
+    "vp_pixrefer_counter": (ctypes.c_longlong, [_P, ctypes.c_char_p]),
     "vp_crc32c": (ctypes.c_uint, [_P, ctypes.c_size_t, ctypes.c_uint]),
     "vp_pixrefer_phase_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     "vp_grad_pack_bf16": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P]),

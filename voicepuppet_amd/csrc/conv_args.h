@@ -67,6 +67,14 @@ struct IgemmArgs {
   int xcd_remap;            // conv_patch3.hip: pixel tiles dealt to the XCDs in contiguous runs (set by the launcher)
   double* bn_part;          // staged epilogue also writes batch-norm partials [group][bn_nchunk][2][Cout] (null: no)
   int bn_tpg, bn_nchunk;    // pixel tiles per BN group (per class), partial chunks per group = nclass * bn_tpg
+  // Backward sums of a batch-normalised tensor in the epilogue of the launch that completes its gradient (staged epilogue, STATS == 2):
+  // bst_y = that tensor's raw forward output (Y's geometry and channel count); the partial rows [group][bn_nchunk][2][C] = RAW moments
+  // (sum dz, sum dz * y) go to bn_part (bn_tpg / bn_nchunk as for the forward statistics; bn_bwd_finalize_kernel with BnArgs::raw turns
+  // them into sum dz * zhat).  Two-output launches: bst_y2 / bn_part2 belong to the second output; either side may be null (that output
+  // is not complete yet / has no batch-norm)
+  const void* bst_y;
+  const void* bst_y2;
+  double* bn_part2;
   const void* zeros;        // >= 16 bytes of zeros (padding source of the LDS-DMA loader); null: register loader
   // patch kernel (conv_patch.hip; plan-time decision, the packed weights carry PackDesc::kswap): stride-1 taps on a regular grid,
   // tap t = r * p_kw + c  ->  (dh, dw) = (p_dhf + r * p_dhs, p_dwf + c * p_dws)

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 // (rb_swz) so that global reads are coalesced AND ds_read_b128 stays conflict-free.  Padding / ragged
 // pixels read a 16-byte zero page instead (LDS-DMA cannot zero-fill).  One barrier per K chunk.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int WC, int WP, int TC, int TP, bool STAGED, bool STATS = false, bool DUAL = false>
+template <typename T, int WC, int WP, int TC, int TP, bool STAGED, int STATS = 0, bool DUAL = false>
 __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NW = WC * WP, NT = NW * 64;             // 4 waves (256 threads) or 8 waves (512 threads: 128x256 / 256x256 tiles)
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(WC * WP * 64) void igemm_dma_kernel(const IgemmArgs
 //   consumer kc: barrier kc -> fragments + MFMAs of chunk kc
 // fastk operands only (scalar K stepping, hardware zero fill); epilogue = the staged 16-byte row stores, all waves storing.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int WC, int WP, int TC, int TP, int NST, bool STATS = false, bool DUAL = false>
+template <typename T, int WC, int WP, int TC, int TP, int NST, int STATS = 0, bool DUAL = false>
 __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NPW = 4;
@@ -1713,6 +1713,7 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
   if (plain) {
     IgemmArgs b = a;
     b.vec_epi = (a.splitk == 1 && a.Cout % 8 == 0 && a.ldY % 8 == 0) ? 1 : 0;
+    const bool bst = a.bst_y || a.bst_y2;              // backward sums of a batch-normalised tensor in the epilogue (staged_epilogue, STATS == 2)
     // register-direct epilogue: measured SLOWER than the LDS-staged one (64-byte store segments vs 256-byte rows): opt-in
     // scalar-stepped loader: every 64-byte K chunk inside one tap and one source tensor, sources below the 2 GiB lane-offset range
     constexpr int KCE = 16 * 4 / (int)sizeof(T);
@@ -1732,21 +1733,27 @@ static hipError_t launch_igemm_cfg(const IgemmArgs& a, hipStream_t st) {
         const size_t se = (size_t)(BP / NPE) * (BC * 4 + 16) + (BP / NPE) * 8;
         if (se > sm) sm = se;
         g_prof_family = "ws";
-        if (b.bn_part) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, true>), grid, dim3((NW + 4) * 64), sm, st, b);
-        else if (b.split_c) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, false, true>), grid, dim3((NW + 4) * 64), sm, st, b);
-        else hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, false>), grid, dim3((NW + 4) * 64), sm, st, b);
+        if (bst && b.split_c) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, 2, true>), grid, dim3((NW + 4) * 64), sm, st, b);
+        else if (bst) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, 2>), grid, dim3((NW + 4) * 64), sm, st, b);
+        else if (b.bn_part) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, 1>), grid, dim3((NW + 4) * 64), sm, st, b);
+        else if (b.split_c) hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, 0, true>), grid, dim3((NW + 4) * 64), sm, st, b);
+        else hipLaunchKernelGGL((igemm_ws_kernel<T, WC, WP, TC, TP, NSTW, 0>), grid, dim3((NW + 4) * 64), sm, st, b);
         return hipGetLastError();
       }
     }
     g_prof_family = "dma";
-    if (b.vec_epi && b.bn_part) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, true>), grid, dim3(NW * 64), smem, st, b);
-    else if (b.vec_epi && b.split_c) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, false, true>), grid, dim3(NW * 64), smem, st, b);
+    if (bst && !b.vec_epi) return hipErrorInvalidValue;          // (the backward sums exist in the staged epilogue only: the host asks for them under its conditions)
+    if (bst && b.split_c) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, 2, true>), grid, dim3(NW * 64), smem, st, b);
+    else if (bst) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, 2>), grid, dim3(NW * 64), smem, st, b);
+    else if (b.vec_epi && b.bn_part) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, 1>), grid, dim3(NW * 64), smem, st, b);
+    else if (b.vec_epi && b.split_c) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true, 0, true>), grid, dim3(NW * 64), smem, st, b);
     else if (b.vec_epi) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, true>), grid, dim3(NW * 64), smem, st, b);
-    else if (b.split_c) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false, false, true>), grid, dim3(NW * 64), smem, st, b);
+    else if (b.split_c) hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false, 0, true>), grid, dim3(NW * 64), smem, st, b);
     else hipLaunchKernelGGL((igemm_dma_kernel<T, WC, WP, TC, TP, false>), grid, dim3(NW * 64), smem, st, b);
     return hipGetLastError();
   }
   g_prof_family = "reg";
+  if (a.bst_y || a.bst_y2) return hipErrorInvalidValue;     // (the staged epilogue of the LDS-DMA kernels only)
   if (a.split_c) return hipErrorInvalidValue;        // the two-output form exists on the LDS-DMA kernels only
   if constexpr (NW == 4) hipLaunchKernelGGL((igemm_kernel<T, WC, WP, TC, TP>), grid, dim3(256), 2 * 4 * (BC + BP) * 16 + 64, st, a);
   else return hipErrorInvalidValue;

@@ -63,7 +63,7 @@ __device__ __forceinline__ void patch_frag_read(const uint4* __restrict__ pa, co
   for (int t = 0; t < TC; ++t) fa[t] = pa[t * 64];
 }
 
-template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int NSTW, bool STATS, int OCC>
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int NSTW, int STATS, int OCC>
 __global__ __launch_bounds__(WC * WP * 64, OCC) void igemm_patch_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NW = WC * WP, NT = NW * 64;
@@ -220,7 +220,8 @@ static hipError_t launch_patch_t(const IgemmArgs& b, hipStream_t st) {
   if (se > sm) sm = se;
   const int tiles = b.N * ((b.Hg + TH - 1) / TH) * ((b.Wg + TW - 1) / TW);
   dim3 grid(tiles, b.CoutPad / BC, 1);
-  auto kern = b.bn_part ? igemm_patch_kernel<T, WC, WP, TC, TP, TH, TW, NSTW, true, OCC> : igemm_patch_kernel<T, WC, WP, TC, TP, TH, TW, NSTW, false, OCC>;
+  if (b.bst_y || b.bst_y2) return hipErrorInvalidValue;      // (backward sums in the epilogue: the unrolled 4x4 kernel and the 2x2-tap kernel only; the host asks accordingly)
+  auto kern = b.bn_part ? igemm_patch_kernel<T, WC, WP, TC, TP, TH, TW, NSTW, 1, OCC> : igemm_patch_kernel<T, WC, WP, TC, TP, TH, TW, NSTW, 0, OCC>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(kern, grid, dim3(512), sm, st, b);
   return hipGetLastError();

@@ -34,7 +34,7 @@ struct Patch2TilePix {
 };
 
 // TWOSRC: the pixel operand is a virtual concat of two tensors (decoder layers); single-source launches carry one set of lane offsets
-template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC, bool TWOSRC>
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int STATS, int OCC, bool TWOSRC>
 __global__ __launch_bounds__(512, OCC) void igemm_patch2_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NW = 8, NT = 512, NSTW = 4, NSTEP = 8;
@@ -197,8 +197,11 @@ static hipError_t launch_patch2_t(const IgemmArgs& b, hipStream_t st) {
   const int tiles = b.N * ((b.Hg + TH - 1) / TH) * ((b.Wg + TW - 1) / TW);
   dim3 grid(tiles, b.CoutPad / BC, b.nclass);
   const bool two = b.x.C[1] > 0;
-  auto kern = b.bn_part ? (two ? igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC, true> : igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC, false>)
-                        : (two ? igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC, true> : igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC, false>);
+  const bool bst = b.bst_y != nullptr;                       // backward sums of the tensor this launch completes the gradient of (single-source launches: backward-data)
+  if (bst && two) return hipErrorInvalidValue;
+  auto kern = bst ? igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, 2, OCC, false>
+            : b.bn_part ? (two ? igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, 1, OCC, true> : igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, 1, OCC, false>)
+                        : (two ? igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, 0, OCC, true> : igemm_patch2_kernel<T, WC, WP, TC, TP, TH, TW, 0, OCC, false>);
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(kern, grid, dim3(512), sm, st, b);
   return hipGetLastError();

@@ -56,7 +56,7 @@ struct Patch3TilePix {
 // the 1-1.5 us an LDS-DMA takes to land under load: with 3 stages the loop ran at the DMA latency (0.7 us per step whatever the tile),
 // with 6 the weights of five steps are in flight.  18 steps per trip: NSTW divides 18, stage indices stay compile-time.
 // KW: 3 (3x3 taps) or 4 (4x4 taps: the discriminator's layer_4 backward-data passes, round 5 - 32 steps per trip, four ring stages)
-template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, bool STATS, int OCC, int NSTW = 3, int KW = 3>
+template <typename T, int WC, int WP, int TC, int TP, int TH, int TW, int STATS, int OCC, int NSTW = 3, int KW = 3>
 __global__ __launch_bounds__(512, OCC) void igemm_patch3_kernel(const IgemmArgs a) {
   constexpr int E = Elem<T>::E, KC = 4 * E;
   constexpr int NW = 8, NT = 512, LA = NSTW - 1;
@@ -232,7 +232,11 @@ static hipError_t launch_patch3_t(const IgemmArgs& b, hipStream_t st) {
   if (se > sm) sm = se;
   const int tiles = b.N * ((b.Hg + TH - 1) / TH) * ((b.Wg + TW - 1) / TW);
   dim3 grid(tiles, b.CoutPad / BC, 1);
-  auto kern = b.bn_part ? igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, true, OCC, NSTW, KW> : igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, false, OCC, NSTW, KW>;
+  auto kern = b.bn_part ? igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, 1, OCC, NSTW, KW> : igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, 0, OCC, NSTW, KW>;
+  if (b.bst_y) {       // backward sums of a batch-normalised tensor (the discriminator's layer_3 under layer_4's backward-data): the 4x4 form only
+    if constexpr (KW == 4) kern = igemm_patch3_kernel<T, WC, WP, TC, TP, TH, TW, 2, OCC, NSTW, KW>;
+    else return hipErrorInvalidValue;
+  }
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(kern, grid, dim3(512), sm, st, b);
   return hipGetLastError();

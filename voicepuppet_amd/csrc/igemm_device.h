@@ -162,10 +162,14 @@ __device__ __forceinline__ void epi_store8(const IgemmArgs& a, long long ot, int
 // product, no accumulation and a bf16 output, bias + activation + rounding are applied in the lane's own registers - the same
 // operations in the same order, so the stored bits are the same - and the tile is staged as bf16: half the LDS bytes, NPASS16
 // passes instead of NPASS, the store loop a plain copy; the fused max pool takes the maximum of the rounded values (rounding is monotonic).
-template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, bool STATS = false, int NPASS16 = 0, bool DUAL = false, typename PixFn>
+// STATS == 2 (the launch that completes the gradient of a batch-normalised tensor, round 6): the epilogue also produces the two sums of
+// that tensor's batch-norm BACKWARD pass - as raw moments sum dz and sum dz * y of the gradient AS STORED (after the act'(ref) product, the
+// accumulation and the rounding to T) - so bn_reduce_kernel<T, 1> never re-reads y and dz (IgemmArgs::bst_y).
+// A thread of the store loop stays on one 8-channel group (NT % CG == 0): sixteen running sums in registers.
+template <typename T, int TC, int TP, int BC, int BP, int NPASS, int NT, int STATS = 0, int NPASS16 = 0, bool DUAL = false, typename PixFn>
 __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn& pixfn, int c_base, int blkA0, int blkB0,
                                                 f32x4 (&acc)[TC][TP], char* smem, int pt = 0, int cls = 0) {
-  if constexpr (NPASS16 > 0 && sizeof(T) == 2 && !STATS) {
+  if constexpr (NPASS16 > 0 && sizeof(T) == 2 && STATS == 0) {
     if (!a.ref && !a.accumulate && !a.y_f32 && (a.out_act == ACT_NONE || a.out_act == ACT_RELU)) {
       constexpr int PITCHB = BC * 2 + 16, CGB = BC / 8, RPB = BP / NPASS16;
       static_assert(RPB % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
@@ -253,8 +257,25 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
   static_assert(RP % (TP * 16) == 0, "a wave's pixel rows must fall into one pass");
   const int tid = threadIdx.x, lane = tid & 63;
   long long* otab = reinterpret_cast<long long*>(smem + RP * PITCH);
-  static_assert(!STATS || NT % BC == 0, "column sums: whole thread groups per channel");
+  static_assert(STATS != 1 || NT % BC == 0, "column sums: whole thread groups per channel");
+  static_assert(STATS != 2 || NT % CG == 0, "backward sums: a thread keeps one channel group");
   float bsum = 0.f, bsq = 0.f;
+  // STATS == 2: this thread's channel group and which output it belongs to; RAW moments (sum dz, sum dz * y - the finalize turns the second
+  // into sum dz * zhat = rstd * (sum dz * y - mean * sum dz), BnArgs::raw): no per-channel constants in registers next to the accumulators
+  float gs0[STATS == 2 ? 8 : 1], gs1[STATS == 2 ? 8 : 1];
+  const T* gy = nullptr;
+  if constexpr (STATS == 2) {
+    int c0 = c_base + (tid % CG) * 8;
+    const void* yb = a.bst_y;
+    int ct = a.Cout;
+    if constexpr (DUAL) {
+      ct = a.split_c;
+      if (c0 >= a.split_c) { yb = a.bst_y2; c0 -= a.split_c; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gs0[e] = 0.f; gs1[e] = 0.f; }
+    if (yb && c0 < ct) gy = reinterpret_cast<const T*>(yb);
+  }
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     __syncthreads();                                 // ring (pass 0) / previous pass's tile no longer needed
@@ -271,7 +292,7 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
         }
     }
     __syncthreads();
-    if constexpr (STATS) {
+    if constexpr (STATS == 1) {
       const int col = tid % BC;
       for (int rr = tid / BC; rr < RP; rr += NT / BC) {
         if (otab[rr] < 0) continue;
@@ -295,7 +316,31 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
         const float4 v1 = *reinterpret_cast<const float4*>(smem + p * PITCH + cgp * 32 + 16);
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
       }
+      // STATS == 2: y of the same element, requested BEFORE the store helper's own loads (reference, accumulated gradient) so that all of
+      // them wait out one memory latency (behind it the load cost a second round trip per item: +0.17 ms on the batch-32 step)
+      uint4 ry0 = make_uint4(0, 0, 0, 0), ry1 = make_uint4(0, 0, 0, 0);
+      if constexpr (STATS == 2) {
+        if (gy) {
+          size_t yo = off;
+          if constexpr (DUAL) { if (c0 >= a.split_c) yo -= (size_t)a.split_c; }
+          ry0 = reinterpret_cast<const uint4*>(gy + yo)[0];
+          if (sizeof(T) == 4) ry1 = reinterpret_cast<const uint4*>(gy + yo)[1];
+        }
+      }
       epi_store8<T, DUAL>(a, ot, c0, off, v);
+      if constexpr (STATS == 2) {
+        if (gy) {        // (epi_store8 left the value it stored in v, unrounded)
+          float fy[8];
+          if (sizeof(T) == 2) Elem<bf16>::unpack(ry0, fy);
+          else { Elem<float>::unpack(ry0, fy); Elem<float>::unpack(ry1, fy + 4); }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = sizeof(T) == 2 ? bf16_bits_to_f32(f32_to_bf16_bits(v[e])) : v[e];
+            gs0[e] += d;
+            gs1[e] = fmaf(d, fy[e], gs1[e]);
+          }
+        }
+      }
     }
     // fused 2x2 / stride-2 max pool of the tile (VGG conv1_2 / conv2_2: slim max_pool2d, vgg_simple.py:141,144): the pass holds
     // whole pairs of 16-pixel tile rows; bias + (monotonic) activation + rounding commute with the max, so this equals pooling the
@@ -339,7 +384,29 @@ __device__ __forceinline__ void staged_epilogue(const IgemmArgs& a, const PixFn&
       }
     }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS == 2) {
+    __syncthreads();                                   // the staged tile is dead: reuse its LDS
+    float* red = reinterpret_cast<float*>(smem);       // [NT / CG][2][BC]
+    {
+      float* r0 = red + (tid / CG) * 2 * BC + (tid % CG) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { r0[e] = gs0[e]; r0[BC + e] = gs1[e]; }
+    }
+    __syncthreads();
+    const int grp = pt / a.bn_tpg, chunk = cls * a.bn_tpg + (pt - grp * a.bn_tpg);
+    for (int j = tid; j < 2 * BC; j += NT) {
+      float t = 0.f;
+      for (int m = 0; m < NT / CG; ++m) t += red[m * 2 * BC + j];
+      int c = c_base + (j % BC), ct = a.Cout;
+      double* part = a.bn_part;
+      if constexpr (DUAL) {
+        ct = a.split_c;
+        if (c >= a.split_c) { part = a.bn_part2; c -= a.split_c; }
+      }
+      if (part && c < ct) part[((size_t)(grp * a.bn_nchunk + chunk) * 2 + j / BC) * ct + c] = (double)t;
+    }
+  }
+  if constexpr (STATS == 1) {
     __syncthreads();                                   // the staged tile is dead: reuse its LDS
     float* red = reinterpret_cast<float*>(smem);       // [NT / BC][2][BC]
     red[(tid / BC) * 2 * BC + tid % BC] = bsum;

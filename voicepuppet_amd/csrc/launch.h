@@ -50,6 +50,7 @@ bool bn_small(const BnArgs& a);     // few pixels per group: statistics + finali
 hipError_t launch_bn_small_fwd(const BnArgs& a, void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st);
 hipError_t launch_bn_small_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
+hipError_t launch_bn_bwd_tail(const BnArgs& a, int is_bf16, hipStream_t st);     // finalize + apply from partial rows a conv epilogue wrote (IgemmArgs::bst_*)
 hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate, int is_bf16, hipStream_t st);
 hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int C, int Pg, size_t npix,
                             void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st);

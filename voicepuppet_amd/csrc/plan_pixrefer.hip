@@ -46,7 +46,12 @@ struct Arena {
   }
 };
 
-struct BnBuf { float *a, *b, *mu, *rstd, *c1, *c2, *c1g, *c2g; };   // c1g / c2g: the generator-loss pass through the discriminator
+struct BnBuf {
+  float *a, *b, *mu, *rstd, *c1, *c2, *c1g, *c2g;   // c1g / c2g: the generator-loss pass through the discriminator
+  // backward sums written by the conv epilogue that completes this tensor's gradient (IgemmArgs::bst_*): partial rows [group][chunks][2][C]
+  // of this tensor's OWN buffer (the launch and the batch-norm backward may sit on different streams with other layers' work in between)
+  double *pb, *pbg;
+};
 
 struct Tens {
   std::string name;
@@ -73,6 +78,8 @@ struct Tens {
   // of the size of the result (element-wise gradient errors of 0.35-0.75 against the float64 oracle).
   bool hi = false;
   void* dz32 = nullptr;
+  int pb_cap = 0, pbg_cap = 0;      // rows per group the buffers bn.pb / bn.pbg hold (plan time: the largest table a gradient-completing launch writes; 0: none)
+  int bst_chunks = 0, bst_chunks_g = 0;   // run time: rows per group the last launch DID write in this backward pass (0: the reduce kernel runs)
   size_t elems() const { return (size_t)N * H * W * C; }
 };
 
@@ -155,6 +162,9 @@ struct vp_pixrefer {
   hipEvent_t ev_fork, ev_join, ev_bfork, ev_bjoin;
   hipEvent_t ev_upd_b, ev_upd_m;   // fused update: a generator bucket's weight gradients (branch stream) / data gradients (caller's stream) are done
   bool overlap, forked;
+  int bst_count;              // launches since vp_pixrefer_create that carried such sums (vp_pixrefer_counter("bwd_sums_launches"): tests)
+  int bst_on;                 // vp_pixrefer_set_option("bwd_sums_in_epilogue", default 1; 2 = every launch that can): the batch-norm backward's sums from the epilogue of the launch that completes the gradient
+  int vgg_fork_layer;         // vp_pixrefer_set_option("vgg_real_fork"): generator layer (TF scope order) in front of which the side stream starts the VGG pass of the real half (0: at once)
   bool store_first_raw;       // vp_pixrefer_set_option("store_first_raw"): the first layers also store their raw output (tests / debugging; see first_layer_acts_fused)
   bool ov_on;                 // vp_pixrefer_set_option("overlap"): spread the step over the executor's streams (false: everything on the caller's)
   int dfork_point;            // ... ("d_backward_fork"): where vp_pixrefer_backward starts the discriminator-loss pass on the side stream (0 / 1 / 2)
@@ -288,6 +298,9 @@ static void build_vgg(Net& n, int N, int H) {
   int c32 = add_layer(n, P, "conv3/conv3_2", 0, 3, 1, 1, {c31}, 256, 256, false, ACT_NONE, ACT_RELU, "weights", "biases");
   add_layer(n, P, "conv3/conv3_3", 0, 3, 1, 1, {c32}, 256, 256, false, ACT_NONE, ACT_RELU, "weights", "biases");
 }
+
+static int epi_stat_chunks(const IgemmPlan& p, int batch, int groups);
+constexpr int BST_MAX_CHUNKS = 8192;      // rows per group of a backward-sums table (the finalize walks them 512 at a time)
 
 // plans + packed-weight layout for one net.  alt_batch > 0: also plan bwd-data for that batch (D, G-loss pass)
 static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_batch, size_t* scratch_max, bool fwd_halves = false) {
@@ -429,6 +442,24 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
       for (int s = 0; s < L.nsrc; ++s)
         if (L.in_act == ACT_NONE) n.t[L.src[s]].hi = false;
   }
+  // backward sums from the epilogue of the launch that completes a batch-normalised tensor's gradient: the largest table any of the
+  // tensor's gradient contributions could write (which one is last is decided by the backward walk at run time)
+  for (Tens& t : n.t) t.pb_cap = t.pbg_cap = 0;
+  if (training)
+    for (Layer& L : n.l) {
+      auto cap = [&](Tens& t, const IgemmPlan& p, int batch, int groups, int& c) {
+        if (!t.has_bn || t.hi) return;
+        const int k = epi_stat_chunks(p, batch, groups);
+        if (k > 0 && k <= BST_MAX_CHUNKS && k > c) c = k;
+      };
+      for (int s = 0; s < L.nsrc; ++s) {
+        if (!L.need_bwd[s]) continue;
+        Tens& ts = n.t[L.src[s]];
+        cap(ts, L.bwd[s], n.batch, n.groups, ts.pb_cap);
+        if (alt_batch > 0) cap(ts, L.bwd_alt[s], alt_batch, 1, ts.pbg_cap);
+        if (L.has_pair) cap(ts, L.bwd_pair, n.batch, n.groups, ts.pb_cap);
+      }
+    }
   for (size_t i = 0; i < n.l.size(); ++i) n.l[i].desc1 = i + 1 < n.l.size() ? n.l[i + 1].desc0 : n.descs.size();
   for (Tens& t : n.t) t.n_bwd_consumers = 0;
   n.sp_cnt_n = 0;
@@ -457,6 +488,8 @@ static void carve_net(Net& n, Arena& ar, int es, bool training) {
       t.bn.mu = (float*)ar.alloc(gc); t.bn.rstd = (float*)ar.alloc(gc);
       t.bn.c1 = (float*)ar.alloc(gc); t.bn.c2 = (float*)ar.alloc(gc);
       t.bn.c1g = (float*)ar.alloc(gc); t.bn.c2g = (float*)ar.alloc(gc);
+      t.bn.pb = (training && t.pb_cap) ? (double*)ar.alloc((size_t)n.groups * t.pb_cap * 2 * t.C * sizeof(double)) : nullptr;
+      t.bn.pbg = (training && t.pbg_cap) ? (double*)ar.alloc((size_t)t.pbg_cap * 2 * t.C * sizeof(double)) : nullptr;
     }
   }
   for (Layer& L : n.l) {
@@ -626,6 +659,22 @@ static bool plan_can_pool(const IgemmPlan& p) {
   int th, tw;
   patch_tile_hw(bp, &th, &tw);
   return tw == 16 && th % 2 == 0;
+}
+
+// Rows per batch-norm group of the partial table a launch of plan `p` over `batch` samples in `groups` groups writes from its staged
+// epilogue (forward statistics, backward sums): one row per pixel tile and parity class.  0: that launch has no such epilogue (K split,
+// few-pixel / register-resident-weights kernels) or its pixel tiles straddle groups.
+static int epi_stat_chunks(const IgemmPlan& p, int batch, int groups) {
+  const IgemmArgs& a = p.a;
+  if (a.splitk != 1 || a.patch == 3 || a.patch == 4 || batch % groups) return 0;
+  int bc, bp;
+  igemm_tile(p.cfg, &bc, &bp);
+  const int pg = (batch / groups) * a.Hg * a.Wg;
+  if (!(a.patch || groups == 1 || pg % bp == 0)) return 0;
+  int pth = 16, ptw = 16;
+  patch_tile_hw(bp, &pth, &ptw);
+  const int tpg = a.patch ? (batch / groups) * ((a.Hg + pth - 1) / pth) * ((a.Wg + ptw - 1) / ptw) : (pg + bp - 1) / bp;
+  return a.nclass * tpg;
 }
 
 // forward of one half of the batch of a plain conv layer (VGG: no batch-norm, activation in the epilogue): half 0 / 1
@@ -810,6 +859,32 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
     }
   }
+  // Backward sums of a batch-normalised tensor from the epilogue of the launch that completes its gradient (IgemmArgs::bst_*, staged_epilogue
+  // STATS == 2): the tensor's batch-norm backward then starts at its finalize - bn_reduce_kernel<T, 1> never re-reads y and dz.  `which`:
+  // output 0 / 1 of a two-output launch.  Not for tensors the one-launch batch-norm backward handles (<= 2048 pixels per group), not for
+  // launches on the few-pixel / register-resident-weights kernels (no such epilogue), not when a pixel tile would straddle two groups.
+  auto try_bst = [&](IgemmArgs& a, const IgemmPlan& p, Tens& ts, int which, bool last) {
+    if (!h->bst_on || !last || !ts.has_bn || ts.hi || ts.producer < 0 || ts.is_input) return;
+    const int groups = (gpass || alt) ? 1 : n.groups;
+    if ((nb / groups) * ts.H * ts.W <= 2048) return;                       // bn_small
+    if (a.y_f32 || a.ldY % 8 || a.Cout % 8 || a.ldY != ts.C) return;
+    // bwd_sums_in_epilogue = 1 (default): only where the A/B said it pays (profiles/r06_bwd_sums_per_layer.txt) - single-output launches of the
+    // 2x2-tap patch kernel and the plain implicit GEMM.  The sixteen accumulators do not fit beside the staged tile's registers in the
+    // 128-register kernels: on the two-output launches (decoder_1: 0.090 -> 0.178 ms), the 4x4 patch kernel (layer_4: +0.063 ms) and the
+    // 16-deep tap product (layer_5) the spills cost more than the reduce pass they replace.  2: every launch that can.
+    if (h->bst_on < 2 && (a.split_c || a.patch == 1 || L.tapgemm)) return;
+    if (a.patch == 1 && !patch4_eligible(a, h->bf16)) return;
+    if (a.patch == 2 && (a.x.C[1] > 0 || (h->bf16 && conv_dc64_eligible(a, 1)))) return;
+    const int chunks = epi_stat_chunks(p, nb, groups);
+    if (chunks <= 0 || chunks > (gpass ? ts.pbg_cap : ts.pb_cap)) return;
+    double* part = gpass ? ts.bn.pbg : ts.bn.pb;
+    const void* y = (const char*)ts.y + (size_t)sample0 * ts.H * ts.W * ts.C * es;
+    if (which == 0) { a.bn_part = part; a.bst_y = y; }
+    else { a.bn_part2 = part; a.bst_y2 = y; }
+    a.bn_tpg = chunks / a.nclass; a.bn_nchunk = chunks;
+    (gpass ? ts.bst_chunks_g : ts.bst_chunks) = chunks;
+    h->bst_count++;
+  };
   // few-pixel pairs: only the usual case - this launch is the LAST contribution to the first tensor (its batch-norm backward runs in
   // the launch) and NOT the last one to the second (the skip tensor's own encoder consumer comes later)
   const bool pair_sp = L.has_pair && L.bwd_pair.a.patch == 3;
@@ -861,6 +936,8 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     a.ref_act = L.in_act;
     a.ref_group_n = group_n;
     a.zeros = h->zeros;
+    try_bst(a, L.bwd_pair, t0, 0, t0.dz_writes == t0.n_bwd_consumers);
+    try_bst(a, L.bwd_pair, t1, 1, t1.dz_writes == t1.n_bwd_consumers);
     profile_tag((L.scope + ":bwd").c_str());
     VP_HIP_CHECK(launch_igemm(a, h->bf16, L.bwd_pair.cfg, st));
     return VP_OK;
@@ -921,6 +998,8 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       VP_HIP_CHECK(launch_smallp_fused(sp, h->bf16, st));
       continue;
     }
+    // (the discriminator's tensors have one consumer each and no write counter: every gradient launch completes its tensor)
+    if (!ts.is_input) try_bst(a, alt ? L.bwd_alt[s] : L.bwd[s], ts, 0, (gpass || n.groups != 1) ? true : ts.dz_writes == ts.n_bwd_consumers);
     VP_HIP_CHECK(launch_igemm(a, h->bf16, alt ? L.bwd_alt[s].cfg : L.bwd[s].cfg, st));
   }
   return VP_OK;
@@ -943,6 +1022,15 @@ static int run_bn_bwd(vp_pixrefer* h, Net& n, Layer& L, bool want_dw, int sample
   b.mu = t.bn.mu + (size_t)group0 * t.C; b.rstd = t.bn.rstd + (size_t)group0 * t.C;
   b.c1 = gpass ? t.bn.c1g : t.bn.c1; b.c2 = gpass ? t.bn.c2g : t.bn.c2;
   if (want_dw) { b.dgamma = n.grads + L.gamma_off; b.dbeta = n.grads + L.beta_off; b.dbias_zero = n.grads + L.b_off; }
+  int& fused = gpass ? t.bst_chunks_g : t.bst_chunks;
+  if (fused > 0) {      // the launch that completed the gradient left the partial sums in the tensor's own table: finalize + apply only
+    b.partial = gpass ? t.bn.pbg : t.bn.pb;
+    b.nchunk = fused;
+    b.raw = 1;
+    fused = 0;
+    VP_HIP_CHECK(launch_bn_bwd_tail(b, h->bf16, st));
+    return VP_OK;
+  }
   if (bn_small(b)) { VP_HIP_CHECK(launch_bn_small_bwd(b, h->bf16, st)); return VP_OK; }
   VP_HIP_CHECK(launch_bn_bwd(b, h->bf16, st));
   return VP_OK;
@@ -1065,6 +1153,8 @@ int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d) {
       if (t.has_bn) {
         const size_t gc = (size_t)n->groups * t.C * sizeof(float);
         for (const float* p : {t.bn.a, t.bn.b, t.bn.mu, t.bn.rstd, t.bn.c1, t.bn.c2, t.bn.c1g, t.bn.c2g}) region_of(p, gc, (nm + ".bn").c_str());
+        if (d->training && t.pb_cap) region_of(t.bn.pb, (size_t)n->groups * t.pb_cap * 2 * t.C * sizeof(double), (nm + ".bn.pb").c_str());
+        if (d->training && t.pbg_cap) region_of(t.bn.pbg, (size_t)t.pbg_cap * 2 * t.C * sizeof(double), (nm + ".bn.pbg").c_str());
         if ((size_t)n->groups * t.C > (size_t)1024 * 512) fail("%s: %d groups x %d channels exceed the batch-norm partial rows", nm.c_str(), n->groups, t.C);
       }
       if (d->training && !t.is_input) {
@@ -1148,6 +1238,7 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
   VP_HIP_CHECK(hipStreamSynchronize(st));   // descs are host vectors owned by the handle; copy is complete
   h->overlap = false; h->forked = false;
   // the schedule of this plan (vp_pixrefer_desc; vp_pixrefer_set_option changes it later)
+  h->bst_on = 1; h->vgg_fork_layer = 3;
   h->ov_on = true; h->store_first_raw = false; h->dfork_point = d->d_backward_fork ? d->d_backward_fork - 1 : 2; h->dsplit_on = d->d_beside_vgg != 1;
   if (d->training && d->streams != 1) {
     // lowest priority: the side stream only fills the CUs the main stream's (longer, critical-path) passes leave idle
@@ -1248,7 +1339,9 @@ static int forward_impl(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   // the real half of the perceptual trunk only needs the packed inputs: side stream, under the generator forward
   bool split_vgg = d.training && h->overlap && h->ov_on;
   if (split_vgg) for (Layer& L : h->V.l) split_vgg = split_vgg && L.has_fwd_half;
-  if (split_vgg) {
+  // (vp_pixrefer_set_option("vgg_real_fork", k): the side stream starts it in front of generator layer k instead of at once - the
+  // encoders then share the device with one stream less and the real half fills the few-pixel section of the generator: EXPERIMENTS.md)
+  auto vgg_real_half = [&]() -> int {
     VP_HIP_CHECK(hipEventRecord(h->ev_fork, st));
     VP_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     Net& Vs = h->V;
@@ -1265,7 +1358,10 @@ static int forward_impl(vp_pixrefer_t* h, const float* inputs, const float* fg_i
       }
     }
     VP_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
-  }
+    return VP_OK;
+  };
+  bool vgg_real_started = false;
+  if (split_vgg && h->vgg_fork_layer <= 0) { if ((rc = vgg_real_half())) return rc; vgg_real_started = true; }
 
   // generator: the two encoder branches (encoder_1..4 on `inputs`, encoder_fg_1..4 on `fg_inputs`, pixrefer.py:169-213) are
   // independent chains of small kernels until merged_encoder_2: the foreground branch runs on the branch stream
@@ -1279,10 +1375,12 @@ static int forward_impl(vp_pixrefer_t* h, const float* inputs, const float* fg_i
   for (Layer& L : h->G.l) {
     if (split_enc && L.scope.rfind("encoder_fg_", 0) == 0) continue;
     if (split_enc && L.scope == "merged_encoder_2") VP_HIP_CHECK(hipStreamWaitEvent(st, h->ev_bjoin, 0));
+    if (split_vgg && !vgg_real_started && (int)(&L - &h->G.l[0]) >= h->vgg_fork_layer) { if ((rc = vgg_real_half())) return rc; vgg_real_started = true; }
     if (g_phase_detail) phase_mark(h, st, 8 + (int)(&L - &h->G.l[0]));          // per-layer marks: [8 + layer] = before the layer's forward
     if ((rc = run_layer_fwd(h, h->G, L, st))) return rc;
   }
 
+  if (split_vgg && !vgg_real_started) { if ((rc = vgg_real_half())) return rc; vgg_real_started = true; }
   CompositeArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.y4 = h->y4; ca.targets = targets; ca.masks = masks; ca.o4 = h->o4; ca.outputs = h->outputs; ca.outputs_fg = h->outputs_fg;
@@ -1521,8 +1619,18 @@ int vp_pixrefer_set_option(vp_pixrefer_t* h, const char* key, int value) {
   if (k == "d_backward_fork") { h->dfork_point = value < 0 ? 0 : (value > 2 ? 2 : value); return VP_OK; }
   if (k == "d_beside_vgg") { h->dsplit_on = value != 0; return VP_OK; }
   if (k == "store_first_raw") { h->store_first_raw = value != 0; return VP_OK; }
+  if (k == "bwd_sums_in_epilogue") { h->bst_on = value < 0 ? 0 : (value > 2 ? 2 : value); return VP_OK; }
+  if (k == "vgg_real_fork") { h->vgg_fork_layer = value < 0 ? 0 : value; return VP_OK; }
   set_err("vp_pixrefer_set_option: unknown key %s", key);
   return VP_ERR_ARG;
+}
+
+// Counters of a plan since vp_pixrefer_create (tests): "bwd_sums_launches" = gradient launches whose epilogue also produced the sums of a
+// batch-norm backward pass (IgemmArgs::bst_*).  -1: unknown key.
+long long vp_pixrefer_counter(vp_pixrefer_t* h, const char* key) {
+  if (!h || !key) return -1;
+  if (std::string(key) == "bwd_sums_launches") return h->bst_count;
+  return -1;
 }
 
 int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream) {
@@ -1542,7 +1650,7 @@ static int backward_d_on(vp_pixrefer_t* h, hipStream_t st, bool side) {
   Net& D = h->D;
 
   // ---- Discrim_loss -> discriminator* (pixrefer.py:396-400), all three applications at once ----
-  for (Tens& t : D.t) t.dz_written = false;
+  for (Tens& t : D.t) { t.dz_written = false; t.bst_chunks = 0; }
   for (int i = (int)D.l.size() - 1; i >= 0; --i) {
     Layer& L = D.l[i];
     Tens& to = D.t[L.out];
@@ -1594,7 +1702,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
     VP_HIP_CHECK(hipStreamWaitEvent(h->branch, h->ev_bfork, 0));
   }
-  for (Tens& t : D.t) t.dz2_written = false;
+  for (Tens& t : D.t) { t.dz2_written = false; t.bst_chunks_g = 0; }
   for (int i = (int)D.l.size() - 1; i >= 0; --i) {
     Layer& L = D.l[i];
     Tens& to = D.t[L.out];
@@ -1645,7 +1753,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   ca.d_din = h->d_din; ca.d_vin = h->d_vin; ca.dy4 = h->dy4; ca.N = N; ca.HW = H * H; ca.l1_weight = d.l1_weight;
   VP_HIP_CHECK(launch_composite_bwd(ca, bf, st));
   phase_mark(h, st, 3);
-  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; }
+  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; t.bst_chunks = 0; }
   }
   // (d) generator, last layer first.  Below merged_encoder_2 the two encoder branches are independent again: the foreground
   // branch (encoder_fg_4 .. encoder_fg_1) runs on the branch stream, joined before this call returns control of `st`

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnArgs a) {
   for (int grp = 0; grp < a.G; ++grp) {
     double s0, s1;
     chunk_sum(a, grp, c, lane, s0, s1);
+    if (a.raw) s1 = (double)a.rstd[grp * a.C + c] * (s1 - (double)a.mu[grp * a.C + c] * s0);      // sum dz * y -> sum dz * zhat
     if (lane == 0) {
       a.c1[grp * a.C + c] = (float)(s0 / a.Pg);
       a.c2[grp * a.C + c] = (float)(s1 / a.Pg);
@@ -947,6 +948,15 @@ hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st) {
   dim3 grid(a.nchunk, a.G);
   if (is_bf16) hipLaunchKernelGGL((bn_reduce_kernel<bf16, 1>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 3) / 4), dim3(256), 0, st, a);
+  const size_t work = (size_t)a.G * a.Pg * (a.C / (is_bf16 ? 8 : 4));
+  VP_DISPATCH(is_bf16, bn_bwd_apply_kernel, dim3(nblocks(work)), dim3(256), st, a);
+  return hipGetLastError();
+}
+
+// the same without the reduce pass: the launch that completed the gradient left the partial rows (sum dz, sum dz * zhat) in a.partial
+// (staged_epilogue STATS == 2, igemm_device.h; a.nchunk = that launch's rows per group)
+hipError_t launch_bn_bwd_tail(const BnArgs& a, int is_bf16, hipStream_t st) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 3) / 4), dim3(256), 0, st, a);
   const size_t work = (size_t)a.G * a.Pg * (a.C / (is_bf16 ? 8 : 4));
   VP_DISPATCH(is_bf16, bn_bwd_apply_kernel, dim3(nblocks(work)), dim3(256), st, a);

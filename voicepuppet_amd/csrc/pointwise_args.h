@@ -53,6 +53,7 @@ struct BnArgs {
   int accumulate;           // dgamma/dbeta +=
   float eps;
   float* dbias_zero;        // bwd: [C] bias gradient of the conv in front of this BN, set to its analytic value 0 (may be null)
+  int raw;                  // bwd finalize: the partial rows hold RAW moments (sum dz, sum dz * y) from a conv epilogue (IgemmArgs::bst_y)
 };
 
 struct PackInputsArgs {
