@@ -118,7 +118,7 @@ BOTTLENECK = ("merged_encoder_2", "merged_encoder_3", "merged_encoder_4", "merge
 
 
 @pytest.mark.parametrize("dtype,tol_pix,tol_loss,tol_late,tol_grad,tol_grad_deep,tol_upd",
-                         [("f32", 1e-3, 1e-4, 3e-2, 1.5e-2, 1.5e-2, 1e-1), ("bf16", 3e-2, 5e-2, 1e-1, 5e-1, 5e-1, 2e-1)])
+                         [("f32", 1e-3, 1e-4, 3e-2, 1.5e-2, 1.5e-2, 1e-1), ("bf16", 3e-2, 5e-2, 1e-1, 5e-1, 5e-1, 1e-1)])
 def test_three_full_width_steps_on_a_batch_of_four(dtype, tol_pix, tol_loss, tol_late, tol_grad, tol_grad_deep, tol_upd):
   """tests/golden/full_width_n4.npz (make_golden.py full_n4): FOUR different samples at ngf = ndf = 64 (also the 4-per-GPU share of
   the 8-GPU strong-scaling run), so the 1x1 bottleneck batch-norm has real statistics and merged_encoder_5 / merged_decoder_5 real
@@ -148,6 +148,7 @@ def test_three_full_width_steps_on_a_batch_of_four(dtype, tol_pix, tol_loss, tol
   for w in (0, 1):
     p0.update(eng.get_params(w))
   late, worst_upd, worst_sum, worst_upd_at = 0.0, 0.0, 0.0, (-1, "")
+  worst_upd_small, worst_upd_small_at, upd_num, upd_den = 0.0, (-1, ""), 0.0, 0.0
   table = []
   for step in range(3):
     eng.forward(*dev)
@@ -186,14 +187,25 @@ def test_three_full_width_steps_on_a_batch_of_four(dtype, tol_pix, tol_loss, tol
       if ref_upd == 0:
         assert upd == 0, n
         continue
-      if abs(upd - ref_upd) / ref_upd > worst_upd:
-        worst_upd, worst_upd_at = abs(upd - ref_upd) / ref_upd, (step, n)
+      # update norms, three statistics: the worst tensor among the kernels (>= 4096 elements), the worst among the small
+      # vectors (batch-norm gamma / beta, biases: an Adam update of a few hundred sign-like terms - one flipped sign of 256 moves its norm
+      # by several per cent), and the norm-weighted aggregate over ALL tensors, which no 256-element beta decides
+      e = abs(upd - ref_upd) / ref_upd
+      upd_num += (upd - ref_upd) ** 2
+      upd_den += ref_upd ** 2
+      if now[n].size >= 4096:
+        if e > worst_upd:
+          worst_upd, worst_upd_at = e, (step, n)
+      elif e > worst_upd_small:
+        worst_upd_small, worst_upd_small_at = e, (step, n)
       scale = max(abs(d["param_sums_after"][step, j]), np.sqrt(now[n].size) * 0.02)
       worst_sum = max(worst_sum, abs(now[n].astype(np.float64).sum() - d["param_sums_after"][step, j]) / scale)
   print("\n" + "\n".join(table))
+  upd_agg = float(np.sqrt(upd_num / upd_den))
   print("[%s] N=4 full width: step-1 pixels %.3e, worst loss %.3e, gradient samples: bottleneck worst %.3e, others worst %.3e, late losses %.3e, "
-        "update norms %.3e (step %d: %s), param sums %.3e\n worst tensors: %s" % (dtype, pix, worst_loss, max(deep.values()), max(rest.values()), late,
-                                                                                    worst_upd, worst_upd_at[0], worst_upd_at[1], worst_sum, top))
+        "update norms: kernels %.3e (step %d: %s), small vectors %.3e (step %d: %s), norm-weighted aggregate %.3e, param sums %.3e\n worst tensors: %s"
+        % (dtype, pix, worst_loss, max(deep.values()), max(rest.values()), late, worst_upd, worst_upd_at[0], worst_upd_at[1], worst_upd_small,
+           worst_upd_small_at[0], worst_upd_small_at[1], upd_agg, worst_sum, top))
   assert pix < tol_pix and worst_loss < tol_loss and late < tol_late, (pix, worst_loss, late)
   print(" worst gradient norms: %s" % sorted(((v, n) for n, v in nerr.items()), reverse=True)[:6])
   assert max(nerr.values()) < (5e-3 if dtype == "f32" else 1.5e-1), sorted(((v, n) for n, v in nerr.items()), reverse=True)[:4]
@@ -202,7 +214,12 @@ def test_three_full_width_steps_on_a_batch_of_four(dtype, tol_pix, tol_loss, tol
   # update norms, bf16: the worst tensor is a 256-element batch-norm beta in the third step (generator/encoder_fg_3), whose Adam update is
   # a sum of three sign-like terms: 0.054 with discriminator layer_2 on the generic kernel, 0.127 with the SAME layer on conv_s2c64.hip
   # (another K-sum order of one layer, round 5; late losses 0.0168 -> 0.0150 and parameter sums 0.35 -> 0.24 moved the other way); f32: 0.024
-  assert worst_upd < tol_upd and worst_sum < (tol_upd if dtype == "f32" else 5e-1)     # (sums of N(0, 0.02) weights are small numbers)
+  # Round 6: the bound of round 4 (1e-1) is back for every tensor that is a kernel, and for the aggregate at half of it; the one statistic
+  # that moved 0.054 -> 0.127 -> 0.081 with nothing but summation orders (rounds 4 / 5 / 6) - the worst 128..512-element vector - has its
+  # own stated bound
+  assert worst_upd < tol_upd and upd_agg < 0.5 * tol_upd, (worst_upd, worst_upd_at, upd_agg)
+  assert worst_upd_small < (tol_upd if dtype == "f32" else 2.5e-1), (worst_upd_small, worst_upd_small_at)
+  assert worst_sum < (tol_upd if dtype == "f32" else 5e-1)     # (sums of N(0, 0.02) weights are small numbers)
 
 
 def test_bf16_generator_gradients_at_full_width_against_the_rounding_aware_oracle():
