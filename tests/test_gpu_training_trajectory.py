@@ -5,19 +5,21 @@ comparison of the bf16 path against the float64 graph is conditioning-limited (0
 end-to-end statement for the benchmark dtype is made here: ngf = ndf = 64, the four-sample fixture (tests/golden/full_width_n4.npz),
 200 iterations of the reference's schedule (Adam(D) then Adam(G), lr = 3e-4 * 0.999^floor(global_step / 1000)).
 
-Round 5 ran ONE seed and compared the bf16 window means with the float32 ones inside hard-coded bands (5-8 %); changing one kernel
-selection knob moved the step-50 perceptual term 8.9 % - the band measured rounding luck.  Now the yardstick is the float32 path
-itself (scripts/train_spread.py):
+Round 5 ran ONE seed and compared 10-step window means with the float32 ones inside hard-coded bands (5-8 %); changing one kernel
+selection knob moved the step-50 perceptual term 8.9 % - and in round 6 changing the summation order of ONE batch-norm reduction moved
+the same build's step-50 Gen_loss_L1 from 5 % to 10 % off float32: per-step losses of this GAN carry 10-20 % bumps that last 2-3
+iterations and arrive at different iterations in every run, so a 10-step window at the knee of the curve measures whether it holds a
+bump.  Now (scripts/train_spread.py; curves and statistics in profiles/r06_train_spread.json / .txt):
   * THREE seeds of the initial weights, each run on the float32 engine, on the float32 engine from weights perturbed by 1e-6 relative
     (the float32 path's own chaos), on the bf16 engine, and on the bf16 engine with vp_tune("patch_min_blocks", 256) (the arm that left
     round 5's band);
-  * the band of a loss term is the LARGEST SEED-TO-SEED SPREAD of the float32 window means over the checkpoints 10 / 50 / 100 / 200,
-    measured in this run, not written down (relative for Gen_loss_L1 / Gen_loss, nats for the two GAN terms; the perceptual term's spread
-    is 50-75 % - its level is set by the initial weights - so its band is capped at 25 %; measured 15.4 % at step 50, 3.5-7.7 % elsewhere): every bf16 run must sit within it of the
-    float32 run OF ITS OWN SEED, i.e. no further from it than another float32 initialisation would;
-  * measured (profiles/r06_train_spread.json, .txt): Gen_loss_L1 bf16-vs-f32 0.6 / 5.0 / 3.5 / 3.7 % at the four checkpoints, float32
-    seed-to-seed 7.8 / 3.7 / 6.5 / 7.5 %, float32 vs 1e-6-perturbed float32 0.3 / 1.2 / 3.6 / 2.2 % - a 1e-6 perturbation of float32
-    weights moves the trajectory as much as bf16 arithmetic does by step 100; GAN terms 0.06-0.36 nats (float32 seed-to-seed 0.06-0.51).
+  * 50-iteration windows [25, 75), [75, 125), [125, 175) - geometric means of the decaying terms, arithmetic means (nats) of the GAN terms;
+  * the yardstick is the float32 path itself, measured in this run and not written down: Gen_loss_L1 / Gen_loss of every bf16 run within
+    the largest SEED-TO-SEED spread of the float32 runs (measured 5.8 % / 4.9 %; bf16 sits 1.3-2.3 % from the float32 run of its own
+    seed, a 1e-6 perturbation of the float32 weights moves float32 by 0.4-1.0 %); the two GAN terms within 1.65 x the largest float32
+    seed-to-seed range (the 95 % band of the difference between two float32 initialisations estimated from a three-sample range: 0.60 /
+    0.55 nats; bf16 0.05-0.29 nats, perturbed float32 0.07-0.22); the perceptual term's level is a property of the initial weights (seed
+    spread 55-67 %: no yardstick), so it gets a stated band of 12 % (bf16 3.8-6.6 %, perturbed float32 1.5-2.1 %).
 Gen_loss_L1 (L1 + matte + 1x perceptual, weight 500 in Gen_loss) must fall by the same factor on both paths and the trained generators
 must produce the same pixels.  (These runs use the SHIPPED plan options - the first layers write no raw output, store_first_raw = 0:
 ADVICE r5 asked for a whole-step test on that default path.)"""
@@ -35,8 +37,8 @@ pytestmark = pytest.mark.gpu
 
 STEPS = 200
 SEEDS = (0, 1, 2)
-CAP_REL = 0.25           # the perceptual term: float32 seed-to-seed spread 0.5-0.75 (its level is a property of the initial weights)
-FLOOR_REL = 0.05         # ... and no band below the float32 path's own sensitivity to a 1e-6 perturbation (measured 3.6 % at step 100)
+BAND_PERCEPTUAL = 0.12
+GAN_RANGE_FACTOR = 1.65
 
 
 def test_bf16_loss_trajectory_sits_inside_the_float32_seed_spread():
@@ -44,34 +46,32 @@ def test_bf16_loss_trajectory_sits_inside_the_float32_seed_spread():
   for c in runs.values():
     assert np.isfinite(c).all()
   dist = ts.distances(runs, SEEDS, STEPS)
+  print("\n" + ts.report(dist))
   K = {k: i for i, k in enumerate(tc.KEYS)}
-  lines = []
   band = {}
   for k in tc.KEYS:
     spread = max(dist[at][k]["f32_seed_spread"] for at in ts.AT)
-    band[k] = min(max(spread, FLOOR_REL), CAP_REL) if dist[ts.AT[0]][k]["relative"] else spread
+    band[k] = BAND_PERCEPTUAL if k == "Perceptual_loss" else (spread if k in ts.REL_KEYS else GAN_RANGE_FACTOR * spread)
+  print("bands: " + ", ".join("%s %.4f" % kv for kv in band.items()))
+  assert band["Gen_loss_L1"] < 0.10 and band["Gen_loss"] < 0.10, band        # (the yardstick itself stays a yardstick)
   for at in ts.AT:
-    a = min(at, STEPS - 1)
     for k, i in K.items():
-      r = dist[at][k]
-      lines.append("step %3d %-16s float32 seed-to-seed %.4f | float32 vs 1e-6-perturbed float32 %.4f | bf16 vs float32 (3 seeds x 2 arms) %.4f | band %.4f %s"
-                   % (at, k, r["f32_seed_spread"], r["f32_vs_perturbed_f32"], r["bf16_vs_f32"], band[k], "rel" if r["relative"] else "nats"))
+      rel = k in ts.REL_KEYS
       for s in SEEDS:
-        wf = tc.window_mean(runs[(s, "f32")], a)[i]
+        wf = ts.window_stat(runs[(s, "f32")][:, i], at, rel)
         for arm in ("bf16", "bf16_pmb256"):
-          wb = tc.window_mean(runs[(s, arm)], a)[i]
-          d = abs(wb - wf) / (abs(wf) if r["relative"] else 1.0)
+          wb = ts.window_stat(runs[(s, arm)][:, i], at, rel)
+          d = abs(wb - wf) / (abs(wf) if rel else 1.0)
           assert d <= band[k], (at, k, s, arm, wf, wb, d, band[k])
-  print("\n" + "\n".join(lines))
   # the generator learns: Gen_loss_L1 falls, by the same factor on both paths, for every seed and both bf16 arms
   i = K["Gen_loss_L1"]
   for s in SEEDS:
     f = runs[(s, "f32")]
-    fall_f = tc.window_mean(f, STEPS - 1)[i] / f[0, i]
+    fall_f = ts.window_stat(f[:, i], STEPS - ts.HALF, True) / f[0, i]
     assert fall_f < 0.7, (s, fall_f)
     for arm in ("bf16", "bf16_pmb256"):
       b = runs[(s, arm)]
-      fall_b = tc.window_mean(b, STEPS - 1)[i] / b[0, i]
+      fall_b = ts.window_stat(b[:, i], STEPS - ts.HALF, True) / b[0, i]
       assert abs(fall_b - fall_f) < 0.1 * fall_f, (s, arm, fall_f, fall_b)
 
 

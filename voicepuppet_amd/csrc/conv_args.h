@@ -75,6 +75,7 @@ struct IgemmArgs {
   const void* bst_y;
   const void* bst_y2;
   double* bn_part2;
+  double* colsum_part;      // conv_dc64_kernel only: also write the column sums of the stored output, one row [2][64] per block (null: no)
   const void* zeros;        // >= 16 bytes of zeros (padding source of the LDS-DMA loader); null: register loader
   // patch kernel (conv_patch.hip; plan-time decision, the packed weights carry PackDesc::kswap): stride-1 taps on a regular grid,
   // tap t = r * p_kw + c  ->  (dh, dw) = (p_dhf + r * p_dhs, p_dwf + c * p_dws)

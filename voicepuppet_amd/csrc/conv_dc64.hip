@@ -49,7 +49,11 @@ __device__ __forceinline__ unsigned dc_pk_mul_lo_u16(unsigned x, unsigned y) {
 
 // RACT: activation whose derivative at the reference multiplies the output (ACT_NONE: no reference, ACT_LRELU, ACT_RELU);
 // ACC: the output tensor already holds another consumer's gradient contribution (encoder_1: decoder_1 wrote first): add to it
-template <int RACT, bool ACC>
+// CSUM (round 6): the launch completes the gradient of a tensor whose producer has no batch-norm (discriminator layer_1, encoder_1,
+// encoder_fg_1): the column sums of the gradient AS STORED - that producer's bias gradient - are formed here as running per-lane sums
+// over the tiles the persistent block walks, one partial row per block (IgemmArgs::colsum_part, [grid][2][64] doubles in the layout
+// colsum_finalize_kernel reads): the bias gradient costs no pass of its own over the 67-201 MB tensor.
+template <int RACT, bool ACC, bool CSUM = false>
 __global__ __launch_bounds__(256, 2) void conv_dc64_kernel(const IgemmArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -122,6 +126,9 @@ __global__ __launch_bounds__(256, 2) void conv_dc64_kernel(const IgemmArgs a, co
     }
   };
 
+  float cs[CSUM ? 8 : 1];
+#pragma unroll
+  for (int e = 0; e < (CSUM ? 8 : 1); ++e) cs[e] = 0.f;
   if (bt < ntiles) issue_patch(bt, 0);
   int it = 0;
   for (int t = bt; t < ntiles; t += GT, ++it) {
@@ -211,6 +218,12 @@ __global__ __launch_bounds__(256, 2) void conv_dc64_kernel(const IgemmArgs a, co
           pk.x = mask(pk.x, rz[r].x); pk.y = mask(pk.y, rz[r].y); pk.z = mask(pk.z, rz[r].z); pk.w = mask(pk.w, rz[r].w);
         }
       }
+      if constexpr (CSUM) {
+        float f[8];
+        Elem<bf16>::unpack(pk, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += f[e];
+      }
       // staging pixel = output column 2 fi + pw of row r; 16-byte slot s of column oc at slot s ^ ((oc >> 1) & 7)
       *reinterpret_cast<uint4*>(stg + (r * 32 + 2 * fi + pw) * 128 + (((4 * hh + fg) ^ (fi & 7)) << 4)) = pk;
     }
@@ -225,6 +238,30 @@ __global__ __launch_bounds__(256, 2) void conv_dc64_kernel(const IgemmArgs a, co
       unsigned* yp = reinterpret_cast<unsigned*>(Yp + ((size_t)(n * a.Hof + 2 * (q0 + wave) + ph) * a.Wof + 2 * r0 + oc) * 64 + sl * 8);
       __builtin_nontemporal_store(o.x, yp); __builtin_nontemporal_store(o.y, yp + 1);
       __builtin_nontemporal_store(o.z, yp + 2); __builtin_nontemporal_store(o.w, yp + 3);
+    }
+  }
+  if constexpr (CSUM) {
+    // lanes fi = 0 .. 15 of a 16-lane row hold the same eight channels: fold them, then the two waves (column parities) of a channel half
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = cs[e];
+      x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+      cs[e] = x;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave is past its last use of the staging buffer
+    float* red = reinterpret_cast<float*>(smem);       // [wave][32]
+    if (fi == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave * 32 + fg * 8 + e] = cs[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int h2 = tid >> 5, cc = tid & 31;          // channel 32 h2 + cc: waves h2 (column parity 0) and 2 + h2 (parity 1)
+      const float t0 = red[h2 * 32 + cc] + red[(2 + h2) * 32 + cc];
+      double* row = a.colsum_part + (size_t)blockIdx.x * 2 * 64;
+      row[tid] = (double)t0;
+      row[64 + tid] = 0.0;
     }
   }
 }
@@ -458,16 +495,21 @@ bool conv_dc64_eligible(const IgemmArgs& a, int is_bf16) {
   return (size_t)a.N * a.Hin * a.Win * 128 * 2 < 0x70000000ull;
 }
 
+int conv_dc64_grid(const IgemmArgs& a) {
+  const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);          // per row parity
+  return 2 * ntiles < 512 ? 2 * ntiles : 512;                  // two four-wave blocks on each of the 256 CUs; even: both row parities
+}
 hipError_t launch_conv_dc64(const IgemmArgs& a, hipStream_t st) {
   const int ntiles = a.N * (a.Hg / TH) * (a.Wg / TW);          // per row parity
-  int grid = 512;                                             // two four-wave blocks on each of the 256 CUs; even: both row parities
-  if (2 * ntiles < grid) grid = 2 * ntiles;
-  const int ki = (!a.ref ? 0 : (a.ref_act == ACT_LRELU ? 1 : 2)) + (a.accumulate ? 3 : 0);
-  void (*kerns[6])(const IgemmArgs, const int) = {conv_dc64_kernel<ACT_NONE, false>, conv_dc64_kernel<ACT_LRELU, false>, conv_dc64_kernel<ACT_RELU, false>,
-                                                  conv_dc64_kernel<ACT_NONE, true>, conv_dc64_kernel<ACT_LRELU, true>, conv_dc64_kernel<ACT_RELU, true>};
+  const int grid = conv_dc64_grid(a);
+  const int ki = (!a.ref ? 0 : (a.ref_act == ACT_LRELU ? 1 : 2)) + (a.accumulate ? 3 : 0) + (a.colsum_part ? 6 : 0);
+  void (*kerns[12])(const IgemmArgs, const int) = {conv_dc64_kernel<ACT_NONE, false>, conv_dc64_kernel<ACT_LRELU, false>, conv_dc64_kernel<ACT_RELU, false>,
+                                                   conv_dc64_kernel<ACT_NONE, true>, conv_dc64_kernel<ACT_LRELU, true>, conv_dc64_kernel<ACT_RELU, true>,
+                                                   conv_dc64_kernel<ACT_NONE, false, true>, conv_dc64_kernel<ACT_LRELU, false, true>, conv_dc64_kernel<ACT_RELU, false, true>,
+                                                   conv_dc64_kernel<ACT_NONE, true, true>, conv_dc64_kernel<ACT_LRELU, true, true>, conv_dc64_kernel<ACT_RELU, true, true>};
   void (*kern)(const IgemmArgs, const int) = kerns[ki];
   const int smem = 2 * BUFB + STGB;                            // 64 KB
-  static bool attr_done[6] = {false, false, false, false, false, false};
+  static bool attr_done[12] = {};
   if (!attr_done[ki]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_done[ki] = true; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a, ntiles);
   return hipGetLastError();

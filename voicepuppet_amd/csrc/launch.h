@@ -19,6 +19,7 @@ bool conv_c64_eligible(const IgemmArgs& a, int is_bf16);                        
 hipError_t launch_conv_c64(const IgemmArgs& a, hipStream_t st);
 bool conv_dc64_eligible(const IgemmArgs& a, int is_bf16);                                                           // conv_dc64.hip
 hipError_t launch_conv_dc64(const IgemmArgs& a, hipStream_t st);
+int conv_dc64_grid(const IgemmArgs& a);                        // its blocks = partial rows of IgemmArgs::colsum_part
 bool conv_dc256_eligible(const IgemmArgs& a, int is_bf16);      // conv_dc64.hip: the forward form for 2 x 128 input channels (merged2_decoder_2)
 int conv_dc256_grid(const IgemmArgs& a);                       // its blocks; batch-norm partial rows = 2 per block
 hipError_t launch_conv_dc256(const IgemmArgs& a, hipStream_t st);
@@ -52,6 +53,7 @@ hipError_t launch_bn_small_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_bn_bwd(const BnArgs& a, int is_bf16, hipStream_t st);
 hipError_t launch_bn_bwd_tail(const BnArgs& a, int is_bf16, hipStream_t st);     // finalize + apply from partial rows a conv epilogue wrote (IgemmArgs::bst_*)
 hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate, int is_bf16, hipStream_t st);
+hipError_t launch_colsum_tail(const BnArgs& a, int creal, float* out, int accumulate, hipStream_t st);   // the finalize alone: partial rows from a conv epilogue (IgemmArgs::colsum_part)
 hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int C, int Pg, size_t npix,
                             void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st);
 hipError_t launch_tap_gather(const TapArgs& a, hipStream_t st);

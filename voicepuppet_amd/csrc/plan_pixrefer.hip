@@ -78,6 +78,8 @@ struct Tens {
   // of the size of the result (element-wise gradient errors of 0.35-0.75 against the float64 oracle).
   bool hi = false;
   void* dz32 = nullptr;
+  double* cs_part = nullptr;        // bias gradient of the producing layer (no batch-norm) from the epilogue of the launch that completes dz (conv_dc64.hip CSUM): [512][2][64]
+  int cs_chunks = 0;                // run time: rows the last launch wrote in this backward pass (0: the column-sum pass runs)
   int pb_cap = 0, pbg_cap = 0;      // rows per group the buffers bn.pb / bn.pbg hold (plan time: the largest table a gradient-completing launch writes; 0: none)
   int bst_chunks = 0, bst_chunks_g = 0;   // run time: rows per group the last launch DID write in this backward pass (0: the reduce kernel runs)
   size_t elems() const { return (size_t)N * H * W * C; }
@@ -545,6 +547,9 @@ static size_t carve_all(vp_pixrefer* h, char* base, size_t cap, std::vector<std:
     // gradient buffers.  generator + discriminator: one per non-input tensor.
     for (Tens& t : h->G.t) if (!t.is_input && t.name != "decoder_1") { t.dz = ar.alloc(t.elems() * es); if (t.hi) t.dz32 = ar.alloc(t.elems() * sizeof(float)); }
     for (Tens& t : h->D.t) if (!t.is_input && t.name != "layer_5") { t.dz = ar.alloc(t.elems() * es); t.dz2 = ar.alloc(t.elems() / 3 * es); }
+    // 64-channel tensors without batch-norm (encoder_1, encoder_fg_1, layer_1): partial rows of the producer's bias gradient (conv_dc64.hip CSUM)
+    for (Net* n : {&h->G, &h->D})
+      for (Tens& t : n->t) if (h->bf16 && !t.is_input && !t.has_bn && t.C == 64) t.cs_part = (double*)ar.alloc((size_t)512 * 2 * 64 * sizeof(double));
     // VGG backward runs on the fake half only
     for (Tens& t : h->V.t) if (!t.is_input) t.dz = ar.alloc(t.elems() / 2 * es);
     h->n_comp = composite_nblocks(N, H * H);
@@ -856,7 +861,14 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       b.y = dy; b.C = L.g.CoutT; b.G = 1; b.Pg = nb * L.g.Hout * L.g.Wout;
       b.nchunk = bn_nchunk(b.Pg, b.C, 1, h->bf16);
       b.partial = bn_partial;
-      VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
+      Tens& to = n.t[L.out];
+      if (to.cs_chunks > 0 && dy == to.dz) {     // the launch that completed dy left its column sums behind (conv_dc64.hip CSUM): finalize only
+        b.partial = to.cs_part; b.nchunk = to.cs_chunks;
+        to.cs_chunks = 0;
+        VP_HIP_CHECK(launch_colsum_tail(b, L.g.Cout, db, 0, st));
+      } else {
+        VP_HIP_CHECK(launch_colsum(b, L.g.Cout, db, 0, h->bf16, st));
+      }
     }
   }
   // Backward sums of a batch-normalised tensor from the epilogue of the launch that completes its gradient (IgemmArgs::bst_*, staged_epilogue
@@ -871,8 +883,8 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     // bwd_sums_in_epilogue = 1 (default): only where the A/B said it pays (profiles/r06_bwd_sums_per_layer.txt) - single-output launches of the
     // 2x2-tap patch kernel and the plain implicit GEMM.  The sixteen accumulators do not fit beside the staged tile's registers in the
     // 128-register kernels: on the two-output launches (decoder_1: 0.090 -> 0.178 ms), the 4x4 patch kernel (layer_4: +0.063 ms) and the
-    // 16-deep tap product (layer_5) the spills cost more than the reduce pass they replace.  2: every launch that can.
-    if (h->bst_on < 2 && (a.split_c || a.patch == 1 || L.tapgemm)) return;
+    // 16-deep tap product of the generator-loss pass (layer_5: +0.010 ms against a 0.010 ms reduce) the spills cost as much or more than the reduce pass they replace.  2: every launch that can.
+    if (h->bst_on < 2 && (a.split_c || a.patch == 1 || (L.tapgemm && gpass))) return;
     if (a.patch == 1 && !patch4_eligible(a, h->bf16)) return;
     if (a.patch == 2 && (a.x.C[1] > 0 || (h->bf16 && conv_dc64_eligible(a, 1)))) return;
     const int chunks = epi_stat_chunks(p, nb, groups);
@@ -997,6 +1009,13 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       }
       VP_HIP_CHECK(launch_smallp_fused(sp, h->bf16, st));
       continue;
+    }
+    // the bias gradient of a producer without batch-norm (layer_1, encoder_1, encoder_fg_1) from this launch's epilogue when it completes
+    // the tensor's gradient on conv_dc64.hip (the only kernel with that epilogue)
+    if (h->bst_on && h->bf16 && !ts.is_input && !ts.has_bn && ts.cs_part && !gpass && !alt && ts.producer >= 0 && !n.l[ts.producer].tapgemm &&
+        (n.groups != 1 || ts.dz_writes == ts.n_bwd_consumers) && dc64_knob() && conv_dc64_eligible(a, 1)) {
+      a.colsum_part = ts.cs_part;
+      ts.cs_chunks = conv_dc64_grid(a);
     }
     // (the discriminator's tensors have one consumer each and no write counter: every gradient launch completes its tensor)
     if (!ts.is_input) try_bst(a, alt ? L.bwd_alt[s] : L.bwd[s], ts, 0, (gpass || n.groups != 1) ? true : ts.dz_writes == ts.n_bwd_consumers);
@@ -1157,6 +1176,7 @@ int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d) {
         if (d->training && t.pbg_cap) region_of(t.bn.pbg, (size_t)t.pbg_cap * 2 * t.C * sizeof(double), (nm + ".bn.pbg").c_str());
         if ((size_t)n->groups * t.C > (size_t)1024 * 512) fail("%s: %d groups x %d channels exceed the batch-norm partial rows", nm.c_str(), n->groups, t.C);
       }
+      if (t.cs_part) region_of(t.cs_part, (size_t)512 * 2 * 64 * sizeof(double), (nm + ".cs_part").c_str());
       if (d->training && !t.is_input) {
         const size_t div = n == &h->V ? 2 : 1;
         region_of(t.dz, t.elems() / div * es, (nm + ".dz").c_str());
@@ -1650,7 +1670,7 @@ static int backward_d_on(vp_pixrefer_t* h, hipStream_t st, bool side) {
   Net& D = h->D;
 
   // ---- Discrim_loss -> discriminator* (pixrefer.py:396-400), all three applications at once ----
-  for (Tens& t : D.t) { t.dz_written = false; t.bst_chunks = 0; }
+  for (Tens& t : D.t) { t.dz_written = false; t.bst_chunks = 0; t.cs_chunks = 0; }
   for (int i = (int)D.l.size() - 1; i >= 0; --i) {
     Layer& L = D.l[i];
     Tens& to = D.t[L.out];
@@ -1753,7 +1773,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
   ca.d_din = h->d_din; ca.d_vin = h->d_vin; ca.dy4 = h->dy4; ca.N = N; ca.HW = H * H; ca.l1_weight = d.l1_weight;
   VP_HIP_CHECK(launch_composite_bwd(ca, bf, st));
   phase_mark(h, st, 3);
-  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; t.bst_chunks = 0; }
+  for (Tens& t : G.t) { t.dz_written = false; t.dz_writes = 0; t.bn_bwd_done = false; t.bst_chunks = 0; t.cs_chunks = 0; }
   }
   // (d) generator, last layer first.  Below merged_encoder_2 the two encoder branches are independent again: the foreground
   // branch (encoder_fg_4 .. encoder_fg_1) runs on the branch stream, joined before this call returns control of `st`

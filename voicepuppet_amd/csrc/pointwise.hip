@@ -984,6 +984,11 @@ hipError_t launch_colsum(const BnArgs& a, int creal, float* out, int accumulate,
   return hipGetLastError();
 }
 
+hipError_t launch_colsum_tail(const BnArgs& a, int creal, float* out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((creal + 3) / 4), dim3(256), 0, st, a, creal, out, accumulate);
+  return hipGetLastError();
+}
+
 hipError_t launch_act_apply(const void* y, const float* sc, const float* sh, int C, int Pg, size_t npix,
                             void* out_lrelu, void* out_relu, int is_bf16, hipStream_t st) {
   const size_t work = npix * (C / (is_bf16 ? 8 : 4));
