@@ -68,6 +68,7 @@ CLASS_CASES = [
     (1, (0, 2, 64, 64, 128, 128, 4, 2, 1, 0, 0, False)),      # backward-data of a 128 -> 128 stride-2 conv (layer_3 geometry): patch2 128x256
     (384, (0, 2, 8, 8, 64, 128, 4, 2, 1, 0, 0, False)),       # 4 x 4 output grid (fewer than 32 K slots per image): the generic wgrad_tr 256x128
     (384, (0, 8, 128, 128, 64, 128, 4, 2, 1, 0, 0, False)),   # 512 tiles of 4 x 16 pixels (layer_2 / encoder_2 forward from 8 frames): register-resident weights, conv_s2c64.hip
+    (384, (0, 2, 192, 192, 8, 128, 4, 2, 1, 0, 0, False)),     # 144 blocks of 128 x 128 (above the small-grid rule of round 6, vp_tune "igemm_small_grid"), 8-channel taps (no scalar K stepping in either dtype): igemm_dma 128x128
     (384, (1, 8, 64, 64, 256, 64, 4, 2, 1, 0, 0, False)),     # merged2_decoder_2 geometry (256 -> 64 transposed conv, 512 tiles per row parity): conv_dc256_kernel; its backward-data: the two-output s2c64 form needs the step (test_gpu_step.py)
 ]
 

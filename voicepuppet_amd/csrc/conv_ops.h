@@ -29,9 +29,14 @@ inline ConvGeomX make_geom(int kind, int ks, int stride, int pad, int N, int Hin
 
 inline int kc_elems(int is_bf16) { return is_bf16 ? 32 : 16; }
 
+// vp_tune("igemm_small_grid", n): a launch whose 128 x 128 tiling has at most n blocks per class takes the 64-row x 128-pixel tile (twice
+// the blocks: a grid below the CU count runs at the per-CU L2 -> LDS fill rate of the CUs it occupies; 1.5 x the fill on 2 x the CUs)
+inline int& igemm_small_grid_knob() { static int v = 128; return v; }
+
 // tile choice for an igemm producing `rows` channels over P pixels
 inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
   if (P >= 96) {
+    if (rows % 128 == 0 && igemm_small_grid_knob() > 0 && (long long)((P + 127) / 128) * (rows / 128) <= igemm_small_grid_knob()) return 1;
     // 256x256 (8-wave tile) runs one block per CU: its prologue / epilogue are exposed, only long K loops amortise them
     if (rows % 256 == 0 && P >= 256 * 256 && Kpad >= 4096) return 7;
     if (rows % 128 == 0 && P >= 256 * 512) return 6;           // 128x256, 8 waves

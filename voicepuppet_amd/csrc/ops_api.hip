@@ -75,6 +75,7 @@ int vp_tune(const char* key, int value) {
   if (k == "patch2") { patch2_knob() = value; return VP_OK; }
   if (k == "patch_xcd") { patch_xcd_knob() = value; return VP_OK; }
   if (k == "smallp_max_pixels") { smallp_knob() = value; return VP_OK; }
+  if (k == "igemm_small_grid") { igemm_small_grid_knob() = value; return VP_OK; }
   if (k == "phase_marks") { vp_phase_marks_enable(value); return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
   return VP_ERR_ARG;
