@@ -201,7 +201,7 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
 
 /* Kernel-selection knobs for tests and experiments (they choose between kernels that compute the same result); plans made AFTER
  * the call see the new value.  Keys: "patch_tiles" (bit 0 / 1 / 2: allow the 256- / 128- / 64-row tiles of the stride-1 patch
- * kernel, default 7), "patch_min_blocks" (smallest grid that runs on it, default 384), "patch_small_tiles" (bit 0: 16x16-pixel
+ * kernel, default 7), "patch_min_blocks" (smallest grid that runs on it, default 192 since round 6 - 384 before; < 0: back to the default), "patch_small_tiles" (bit 0: 16x16-pixel
  * tiles for the 128- / 64-row variants, bit 1: 8x16 for the 256-row variant - two blocks per CU; default 3), "patch_long_k_on_256"
  * (default 1: >= 512-channel layers with K >= 4096 stay on the wave-specialised 256x256 tile - float32 plans; bf16 plans: "patch4"), "c64" / "dc64" (default 1: the
  * register-resident-weights kernels conv_c64.hip / conv_dc64.hip - "dc64" also the forward form conv_dc256_kernel; 0: the patch kernels
@@ -210,6 +210,9 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
  * (default 1: 4x4 stride-1 layers on the unrolled patch kernel with 16 tap steps), "bfm_dwproj" (default 1: BFMNet's depthwise + projection
  * in one kernel; read at every forward call).  No counterpart in the reference.  (The step executor's schedule is per plan: vp_pixrefer_desc / vp_pixrefer_set_option.) */
 int vp_tune(const char* key, int value);
+/* Round-6 plan heuristics: "igemm_small_grid" (default 128: a launch whose 128 x 128 tiling has at most that many blocks per class takes the
+ * 64-row x 128-pixel tile - twice the blocks; 0: off), "igemm_splitk_target" (default 64, rounds 2-5: 128: resident blocks a K split aims at;
+ * < 0: back to the default). */
 /* Further keys: "smallp_max_pixels" (largest pixel count per parity class that runs on the few-pixel kernel conv_smallp.hip,
  * default 256, 0: off), "phase_marks" (1: the step executor records HIP events on the caller's stream at its phase boundaries).
  * vp_pixrefer_phase_ms: milliseconds between consecutive marks of the last step (synchronises on them): generator forward,

@@ -4,8 +4,9 @@
 
 200 iterations of the reference's schedule on the four-sample full-width fixture (scripts/train_curves.py), for three seeds of the
 initial weights, on: the float32 engine, the float32 engine again with every initial weight perturbed by one float32 ulp-scale factor
-(1 + 1e-6 * N(0,1): the float32 path's own chaos), the bf16 engine, the bf16 engine with vp_tune("patch_min_blocks", 256) (another kernel
-class for several small-batch layers = another K-sum order: the arm that left the 5 % band of round 5).
+(1 + 1e-6 * N(0,1): the float32 path's own chaos), the bf16 engine, the bf16 engine under the plan heuristics of rounds 2-5
+(vp_tune "patch_min_blocks" 384, "igemm_splitk_target" 128: other kernel classes and K splits for several small-batch layers = other K-sum
+orders; round 5's version of this arm left its 5 % band).
 
   python scripts/train_spread.py [steps] [out.json]
 
@@ -49,11 +50,13 @@ def run_all(steps, seeds):
     runs[(s, "f32")] = tc.run_curves("f32", steps, p, batch)[0]
     runs[(s, "f32_perturbed")] = tc.run_curves("f32", steps, perturbed(p, s), batch)[0]
     runs[(s, "bf16")] = tc.run_curves("bf16", steps, p, batch)[0]
-    L.vp_tune(b"patch_min_blocks", 256)
+    L.vp_tune(b"patch_min_blocks", 384)            # the round-2..5 plan heuristics: other kernel classes / K splits for several layers
+    L.vp_tune(b"igemm_splitk_target", 128)
     try:
-      runs[(s, "bf16_pmb256")] = tc.run_curves("bf16", steps, p, batch)[0]
+      runs[(s, "bf16_alt")] = tc.run_curves("bf16", steps, p, batch)[0]
     finally:
-      L.vp_tune(b"patch_min_blocks", 384)
+      L.vp_tune(b"patch_min_blocks", -1)
+      L.vp_tune(b"igemm_splitk_target", -1)
   return runs
 
 
@@ -74,7 +77,7 @@ def distances(runs, seeds, steps):
       scale = f.mean() if rel else 1.0
       spread = (f.max() - f.min()) / scale
       chaos = max(abs(w[(s, "f32_perturbed")] - w[(s, "f32")]) / (w[(s, "f32")] if rel else 1.0) for s in seeds)
-      low = max(abs(w[(s, arm)] - w[(s, "f32")]) / (w[(s, "f32")] if rel else 1.0) for s in seeds for arm in ("bf16", "bf16_pmb256"))
+      low = max(abs(w[(s, arm)] - w[(s, "f32")]) / (w[(s, "f32")] if rel else 1.0) for s in seeds for arm in ("bf16", "bf16_alt"))
       row[k] = {"f32_seed_spread": float(spread), "f32_vs_perturbed_f32": float(chaos), "bf16_vs_f32": float(low), "relative": rel,
                 "f32_values": [float(x) for x in f]}
     out[at] = row

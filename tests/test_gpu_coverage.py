@@ -77,7 +77,7 @@ def op_case_classes(dtype, min_blocks):
     return _collect()
   finally:
     L.vp_profile_enable(0)
-    L.vp_tune(b"patch_min_blocks", 384)
+    L.vp_tune(b"patch_min_blocks", -1)       # (< 0: the library default)
 
 
 # op cases (numerics asserted by tests/test_gpu_ops.py::test_more_kernel_classes) that exist to put a benchmark class under the oracle

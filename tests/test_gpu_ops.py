@@ -78,7 +78,7 @@ def small_grids_on_the_patch_kernel():
   L = _lib.lib()
   L.vp_tune(b"patch_min_blocks", 1)
   yield
-  L.vp_tune(b"patch_min_blocks", 384)
+  L.vp_tune(b"patch_min_blocks", -1)       # (< 0: the library default)
 
 
 def make_case(case, seed=0):

@@ -49,13 +49,15 @@ inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {
   return P > 16 ? 3 : 4;
 }
 
+constexpr int IGEMM_SPLITK_TARGET_DEFAULT = 64;   // rounds 2-5: 128
+inline int& igemm_splitk_target_knob() { static int v = IGEMM_SPLITK_TARGET_DEFAULT; return v; }   // vp_tune("igemm_splitk_target"): resident blocks a K split aims at
 inline int pick_igemm_splitk(int blocks, int nchunk) {
   // round-2 sweep (scripts/ab.sh with VP_SPLITK_TARGET / _MAX / _MINCHUNK): target 128 / cap 8 / at least 4 chunks per split: 8.79 vs 8.97 ms at batch 32, 2.84 vs 3.00 ms at
   // batch 4 against the round-1 setting 512 / 32 / 2 - the slab reduce and the short blocks cost more than the idle CUs
-  constexpr int target = 128;      // resident blocks aimed at
+  const int target = igemm_splitk_target_knob();      // resident blocks aimed at
   constexpr int cap = 8;
   constexpr int minchunk = 4;      // K chunks per split at least
-  if (blocks >= 256) return 1;
+  if (blocks >= 256 || blocks >= target) return 1;
   int s = (target + blocks - 1) / blocks;
   if (s > nchunk / minchunk) s = nchunk / minchunk;
   if (s > cap) s = cap;
@@ -127,7 +129,8 @@ inline int& c64_knob() { static int v = 1; return v; }   // 64 -> 64 channel 3x3
 inline int& dc64_knob() { static int v = 1; return v; }  // 128 -> 64 channel transposed-conv classes on conv_dc64.hip
 inline int& s2c64_knob() { static int v = 512; return v; }   // 64 -> 128 channel 4x4 / stride-2 convolutions on conv_s2c64.hip from this many 4 x 16-pixel tiles (0: off)
 inline int& s2c64_pair_knob() { static int v = 1; return v; }   // the two-output backward-data of merged2_decoder_2 on conv_s2c64.hip (0: the generic two-output GEMM)
-inline int& patch_minblk_knob() { static int v = 384; return v; }
+constexpr int PATCH_MIN_BLOCKS_DEFAULT = 192;     // round 6 (with the K-split target below): 4 frames 2.34-2.37 -> 2.28 ms, 8 frames 3.00 -> 2.97, 32 frames +-0 (profiles/r06_ab_plan_heuristics.txt); rounds 2-5: 384
+inline int& patch_minblk_knob() { static int v = PATCH_MIN_BLOCKS_DEFAULT; return v; }
 
 // pixel tile of a patch-kernel plan: bp = 512 -> 16 x 32, 256 -> 16 x 16, 128 -> 8 x 16
 inline void patch_tile_hw(int bp, int* th, int* tw) { *th = bp == 128 ? 8 : 16; *tw = bp == 512 ? 32 : 16; }

@@ -60,7 +60,7 @@ int vp_tune(const char* key, int value) {
   if (!key) return VP_ERR_ARG;
   const std::string k(key);
   if (k == "patch_tiles") { patch_tiles_knob() = value; return VP_OK; }
-  if (k == "patch_min_blocks") { patch_minblk_knob() = value; return VP_OK; }
+  if (k == "patch_min_blocks") { patch_minblk_knob() = value < 0 ? PATCH_MIN_BLOCKS_DEFAULT : value; return VP_OK; }      // (< 0: back to the default)
   if (k == "patch_small_tiles") { patch_small_knob() = value; return VP_OK; }
   if (k == "patch_long_k_on_256") { patch_longk_knob() = value; return VP_OK; }
   if (k == "wgrad_tr") { wgrad_tr_knob() = value; return VP_OK; }
@@ -75,6 +75,7 @@ int vp_tune(const char* key, int value) {
   if (k == "patch2") { patch2_knob() = value; return VP_OK; }
   if (k == "patch_xcd") { patch_xcd_knob() = value; return VP_OK; }
   if (k == "smallp_max_pixels") { smallp_knob() = value; return VP_OK; }
+  if (k == "igemm_splitk_target") { igemm_splitk_target_knob() = value < 0 ? IGEMM_SPLITK_TARGET_DEFAULT : value; return VP_OK; }
   if (k == "igemm_small_grid") { igemm_small_grid_knob() = value; return VP_OK; }
   if (k == "phase_marks") { vp_phase_marks_enable(value); return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
