@@ -56,10 +56,13 @@ def plan_classes(batch, height, dtype):
     eng.profile(0)
 
 
-def op_case_classes(dtype, min_blocks):
-  """Classes the op cases of test_gpu_ops.py run on (device side only: their numerics are asserted there)."""
+def op_case_classes(dtype, min_blocks, old_wgrad_split=False):
+  """Classes the op cases of test_gpu_ops.py run on (device side only: their numerics are asserted there).  old_wgrad_split: the weight-
+  gradient K split of rounds 2-5 (no per-tile slab cost: 64 and more slabs on small cases), which is what puts an op-sized case on the
+  256 x 256 tile of wgrad_tr.hip - a batch-32 plan reaches it with its pixel counts (tests/test_gpu_ops.py::test_weight_gradient_on_the_256x256_tile)."""
   L = _lib.lib()
   L.vp_tune(b"patch_min_blocks", min_blocks)
+  L.vp_tune(b"wgrad_slab_tile_x1000", 0 if old_wgrad_split else -1)
   L.vp_profile_enable(1)
   try:
     for case in T.FWD_CASES + EXTRA_CASES:
@@ -78,6 +81,7 @@ def op_case_classes(dtype, min_blocks):
   finally:
     L.vp_profile_enable(0)
     L.vp_tune(b"patch_min_blocks", -1)       # (< 0: the library default)
+    L.vp_tune(b"wgrad_slab_tile_x1000", -1)
 
 
 # op cases (numerics asserted by tests/test_gpu_ops.py::test_more_kernel_classes) that exist to put a benchmark class under the oracle
@@ -87,7 +91,7 @@ EXTRA_CASES = [c for _, c in T.CLASS_CASES]
 @pytest.mark.parametrize("batch,height", [(32, 256), (8, 512), (4, 256)])
 def test_every_benchmark_kernel_class_has_an_oracle_op_case(batch, height):
   want = plan_classes(batch, height, "bf16")
-  have = op_case_classes("bf16", 1) | op_case_classes("bf16", 384)
+  have = op_case_classes("bf16", 1) | op_case_classes("bf16", 384) | op_case_classes("bf16", 384, old_wgrad_split=True)
   missing = sorted(c for c in want if c not in have and c not in IN_STEP)
   print("\n[batch %d, %dx%d] step classes: %s" % (batch, height, height, sorted(want)))
   assert not missing, "kernel classes of the bs-%d/%d^2 plan without an oracle op case: %s" % (batch, height, missing)
@@ -96,7 +100,7 @@ def test_every_benchmark_kernel_class_has_an_oracle_op_case(batch, height):
 def test_f32_parity_path_classes_are_covered():
   """The float32 plan (the path that meets the 1e-3 pixel tolerance) at the 4-per-GPU batch."""
   want = plan_classes(4, 256, "f32")
-  have = op_case_classes("f32", 1) | op_case_classes("f32", 384)
+  have = op_case_classes("f32", 1) | op_case_classes("f32", 384) | op_case_classes("f32", 384, old_wgrad_split=True)
   in_step = {k.replace("bf16", "f32") for k in IN_STEP}
   missing = sorted(c for c in want if c not in have and c not in in_step)
   assert not missing, missing

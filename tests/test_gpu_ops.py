@@ -244,6 +244,22 @@ def test_stride2_conv_with_register_resident_weights(case):
   assert any(c.startswith("s2c64_") for c in classes), classes
 
 
+def test_weight_gradients_under_the_k_split_of_rounds_2_to_5():
+  """wgrad_tr.hip's 256 x 256 tile needs (256 x 256 tiles) x (K splits) >= 256 blocks.  Since round 6 the K split prices a slab by its
+  tiles (vp_tune "wgrad_slab_tile_x1000", profiles/r06_ab_wgrad_split_cost.txt): op-sized cases no longer split 32-64 ways, the batch-32 /
+  512 x 512 plans still reach the tile with their pixel counts.  Every weight-gradient case again under the split of rounds 2-5 (parity
+  with the oracle as test_conv_bwd_weight), and the profile shows that the 256 x 256 tile with the power-of-two K grid is among what ran
+  (tests/test_gpu_coverage.py counts these classes as covered on the strength of this test)."""
+  L = _lib.lib()
+  cases = [c for c in FWD_CASES + [c for _, c in CLASS_CASES] if c[5] >= 8 and (c[5] & (c[5] - 1)) == 0]
+  L.vp_tune(b"wgrad_slab_tile_x1000", 0)
+  try:
+    classes = _profile_classes(lambda: [test_conv_bwd_weight(c, "bf16") for c in cases])
+  finally:
+    L.vp_tune(b"wgrad_slab_tile_x1000", -1)
+  assert "wgrad_tr_exact_bf16_256x256" in classes, sorted(classes)
+
+
 def test_thin_layer_cases_run_on_their_dedicated_kernels():
   """The parity cases above are only worth something if the dedicated kernels are what runs: check the profile's class names."""
   l1 = (0, 4, 128, 128, 8, 64, 4, 2, 1, 0, 0, False)

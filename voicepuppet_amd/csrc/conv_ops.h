@@ -31,6 +31,8 @@ inline int kc_elems(int is_bf16) { return is_bf16 ? 32 : 16; }
 
 // vp_tune("igemm_small_grid", n): a launch whose 128 x 128 tiling has at most n blocks per class takes the 64-row x 128-pixel tile (twice
 // the blocks: a grid below the CU count runs at the per-CU L2 -> LDS fill rate of the CUs it occupies; 1.5 x the fill on 2 x the CUs)
+// cost model of the weight-gradient K split (plan_wgrad): [0] fixed cost of a block in K iterations x 10, [1] cost of a slab x 100
+inline int& wgrad_cost_knob(int i) { static int v[3] = {80, 15, 150}; return v[i]; }    // [2]: round 6 (0 before): bs 32 -0.2 ms, bs 8 -0.1, bs 4 -0.1 (profiles/r06_ab_wgrad_split_cost.txt)
 inline int& igemm_small_grid_knob() { static int v = 128; return v; }
 
 // tile choice for an igemm producing `rows` channels over P pixels
@@ -460,7 +462,9 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
   // K split: minimise (rounds of the ~512 resident blocks) x (iterations per block + fixed per-block cost),
   // plus a small penalty per slab for the reduce pass
   int s = 1;
-  constexpr double wg_fixed = 8.0, wg_slab = 0.15;
+  // vp_tune("wgrad_fixed_x10" / "wgrad_slab_x100" / "wgrad_slab_tile_x1000"): a slab costs a constant + a term per tile (its reduce moves the
+  // whole slab through HBM twice: 2 x 128 KB per 256 x 128 tile)
+  const double wg_fixed = wgrad_cost_knob(0) * 0.1, wg_slab = wgrad_cost_knob(1) * 0.01 + wgrad_cost_knob(2) * 0.001 * tiles;
   {
     const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
     double best = 1e30;

@@ -76,6 +76,9 @@ int vp_tune(const char* key, int value) {
   if (k == "patch_xcd") { patch_xcd_knob() = value; return VP_OK; }
   if (k == "smallp_max_pixels") { smallp_knob() = value; return VP_OK; }
   if (k == "igemm_splitk_target") { igemm_splitk_target_knob() = value < 0 ? IGEMM_SPLITK_TARGET_DEFAULT : value; return VP_OK; }
+  if (k == "wgrad_fixed_x10") { wgrad_cost_knob(0) = value; return VP_OK; }
+  if (k == "wgrad_slab_tile_x1000") { wgrad_cost_knob(2) = value < 0 ? 150 : value; return VP_OK; }      // (< 0: back to the default)
+  if (k == "wgrad_slab_x100") { wgrad_cost_knob(1) = value; return VP_OK; }
   if (k == "igemm_small_grid") { igemm_small_grid_knob() = value; return VP_OK; }
   if (k == "phase_marks") { vp_phase_marks_enable(value); return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
