@@ -33,6 +33,8 @@ inline int kc_elems(int is_bf16) { return is_bf16 ? 32 : 16; }
 // the blocks: a grid below the CU count runs at the per-CU L2 -> LDS fill rate of the CUs it occupies; 1.5 x the fill on 2 x the CUs)
 // cost model of the weight-gradient K split (plan_wgrad): [0] fixed cost of a block in K iterations x 10, [1] cost of a slab x 100
 inline int& wgrad_cost_knob(int i) { static int v[3] = {80, 15, 150}; return v[i]; }    // [2]: round 6 (0 before): bs 32 -0.2 ms, bs 8 -0.1, bs 4 -0.1 (profiles/r06_ab_wgrad_split_cost.txt)
+// [0] few-pixel kernel: blocks its K split aims at; [1] / [2] implicit GEMM: most K splits, fewest K chunks per split; [3] weight gradient: resident blocks per round of its cost model
+inline int& plan_misc_knob(int i) { static int v[4] = {384, 8, 4, 512}; return v[i]; }
 inline int& igemm_small_grid_knob() { static int v = 128; return v; }
 
 // tile choice for an igemm producing `rows` channels over P pixels
@@ -57,8 +59,8 @@ inline int pick_igemm_splitk(int blocks, int nchunk) {
   // round-2 sweep (scripts/ab.sh with VP_SPLITK_TARGET / _MAX / _MINCHUNK): target 128 / cap 8 / at least 4 chunks per split: 8.79 vs 8.97 ms at batch 32, 2.84 vs 3.00 ms at
   // batch 4 against the round-1 setting 512 / 32 / 2 - the slab reduce and the short blocks cost more than the idle CUs
   const int target = igemm_splitk_target_knob();      // resident blocks aimed at
-  constexpr int cap = 8;
-  constexpr int minchunk = 4;      // K chunks per split at least
+  const int cap = plan_misc_knob(1);           // vp_tune("igemm_splitk_cap"), default 8
+  const int minchunk = plan_misc_knob(2);      // K chunks per split at least: vp_tune("igemm_splitk_minchunk"), default 4
   if (blocks >= 256 || blocks >= target) return 1;
   int s = (target + blocks - 1) / blocks;
   if (s > nchunk / minchunk) s = nchunk / minchunk;
@@ -287,7 +289,7 @@ inline void plan_make_smallp(IgemmPlan& p, int rows, int is_bf16) {
   // K splits over blocks: aim at >= 384 blocks, keep >= 2 chunks per wave (4 waves per block share a block's K range)
   const int PT = a.sp_npt * 16;
   const int tiles = (a.CoutPad / 32) * a.nclass * ((Pc + PT - 1) / PT);
-  constexpr int target = 384;
+  const int target = plan_misc_knob(0);          // vp_tune("smallp_split_target"), default 384
   int s = (target + tiles - 1) / tiles;
   if (s > minchunks / 8) s = minchunks / 8;
   if (s > 64) s = 64;
@@ -469,7 +471,7 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
     const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
     double best = 1e30;
     for (int c = 1; c <= smax; ++c) {
-      const int rounds = (tiles * c + 511) / 512;
+      const int rounds = (tiles * c + plan_misc_knob(3) - 1) / plan_misc_knob(3);
       const double cost = rounds * ((double)nchunk / c + wg_fixed) + wg_slab * c;
       if (cost < best - 1e-9) { best = cost; s = c; }
     }
@@ -477,7 +479,7 @@ inline WgradPlan plan_wgrad(const ConvGeomX& g, int is_bf16, bool plain_operands
   // wgrad_tr pins K splits to XCDs (the blocks of a split share their pixels in one L2): a multiple of 8 splits when there are 8 or more
   if ((tr || tr_thin) && s >= 8 && (s & 7)) {
     const int smax = nchunk / 4 < 1 ? 1 : (nchunk / 4 > 512 ? 512 : nchunk / 4);
-    auto cost = [&](int c) { return ((tiles * c + 511) / 512) * ((double)nchunk / c + wg_fixed) + wg_slab * c; };
+    auto cost = [&](int c) { return ((tiles * c + plan_misc_knob(3) - 1) / plan_misc_knob(3)) * ((double)nchunk / c + wg_fixed) + wg_slab * c; };
     const int lo = s & ~7, hi = lo + 8;
     s = (hi <= smax && cost(hi) <= cost(lo)) ? hi : lo;
   }

@@ -79,6 +79,10 @@ int vp_tune(const char* key, int value) {
   if (k == "wgrad_fixed_x10") { wgrad_cost_knob(0) = value; return VP_OK; }
   if (k == "wgrad_slab_tile_x1000") { wgrad_cost_knob(2) = value < 0 ? 150 : value; return VP_OK; }      // (< 0: back to the default)
   if (k == "wgrad_slab_x100") { wgrad_cost_knob(1) = value; return VP_OK; }
+  if (k == "smallp_split_target") { plan_misc_knob(0) = value; return VP_OK; }
+  if (k == "igemm_splitk_cap") { plan_misc_knob(1) = value; return VP_OK; }
+  if (k == "igemm_splitk_minchunk") { plan_misc_knob(2) = value; return VP_OK; }
+  if (k == "wgrad_resident_blocks") { plan_misc_knob(3) = value; return VP_OK; }
   if (k == "igemm_small_grid") { igemm_small_grid_knob() = value; return VP_OK; }
   if (k == "phase_marks") { vp_phase_marks_enable(value); return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
