@@ -727,12 +727,23 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
 //     32+8q..32+8q+7 of its pixel: two 16-byte stores per lane, and the four lanes of a pixel write 64 contiguous bytes per store;
 //   * each wave walks 16-pixel tiles with the next tile's pieces in flight (double-buffered fragments).
 // ------------------------------------------------------------------------------------------------
-template <int S, bool ACTS>   // ACTS: also write the consumers' activations (xa_lrelu / xa_relu) - its own instantiation: the stores' code costs the plain form registers
+// Round 6: the tile loop is BRANCH-FREE.  The round-1 form guarded every load / finish / store by `tile < ntile`, a run-time switch on
+// out_act and null checks of the three output pointers: 8175 lines of ISA, and - what cost the time - hipcc's s_waitcnt pass, which merges
+// the pending-operation state at every join, put `vmcnt(2)` behind the loads of tile t + 2: a wave drained its previous tile's stores
+// and the loads of tile t + 1 in every iteration (ablation, profiles/r06_cin8_ablation.txt: conv1_1 0.178 ms = 0.053 instruction stream +
+// 0.12 stores, not overlapped: 3.1 TB/s with 16 waves x 2 KB of stores in flight per CU).  Now: tile indices are clamped to the wave's last
+// tile (a wave past its end recomputes and re-stores that tile: same bytes), the pixel count is a multiple of 16 (eligibility), out_act is
+// NONE or RELU as a floor value, which outputs exist is a template parameter (OUTS: 1 raw, 2 lrelu copy, 4 relu copy), and the three
+// fragment sets rotate through a loop unrolled by three: the compiler's own counts come out exact (the loads of tile t wait with the
+// stores of two tiles and the loads of two tiles still in flight).
+// (Forcing five / six waves per SIMD with amdgpu_waves_per_eu - the kernel allocates 104-124 registers, four / three waves - spills: conv1_1 0.155
+// -> 0.155 / 0.253 ms, the stride-2 layers 0.093 -> 0.117 / 0.183: profiles/r06_cin8_ablation.txt.)
+template <int S, int OUTS>
 __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int lgW, int lgH) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
   const int P = a.N << (lgW + lgH);
-  const int ntile = (P + 15) >> 4;
+  const int ntile = P >> 4;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
 
   // A fragments: packed weights are [K chunk s][row][32 k]; this lane's row of tile t is channel 32*(t>>1) + 8*(i>>2) + 4*(t&1) + (i&3).
@@ -742,7 +753,8 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
   __shared__ uint4 otile[4 * 16 * 144 / 16];
   // output rows are dense ([pixel][64]) and the pixel grid is the output grid: a tile's 16 pixels are one 2 KB run
   // (measured: conv1_1, stride 1, 64 images: 0.209 -> 0.178 ms; the stride-2 first layers, a quarter of the output, lose 8 us each)
-  const bool rowrun = a.sh == 1 && a.ldY == 64 && a.Hof == (1 << lgH) && a.Wof == (1 << lgW) && (P & 15) == 0 && !ACTS;
+  constexpr bool ACTS = (OUTS & 6) != 0;
+  const bool rowrun = a.sh == 1 && !ACTS;
   {
     const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
     for (int idx = threadIdx.x; idx < S * 4 * 64; idx += 256) {
@@ -756,6 +768,7 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
   float bias[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) bias[e] = a.bias ? a.bias[(e >> 3) * 32 + 8 * g + (e & 7)] : 0.f;
+  const float act_floor = a.out_act == ACT_RELU ? 0.f : -__builtin_inff();     // relu as a floor: no branch per element
   // this lane's tap of step s
   int tdh[S], tdw[S];
   bool tok[S];
@@ -770,22 +783,27 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
   }
   __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * 16));
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  // a wave's tiles: wave_global, + nwave, ...; indices past its last one are clamped to it
+  const int my_n = wave_global < ntile ? (ntile - 1 - wave_global) / nwave + 1 : 0;
+  if (my_n == 0) return;
+  const int tile_last = wave_global + (my_n - 1) * nwave;
 
-  auto load_tile = [&](int tile, uint4 (&fb)[S]) {
+  auto load_tile = [&](int tile_, uint4 (&fb)[S]) {
+    const int tile = tile_ < tile_last ? tile_ : tile_last;
     const int p = tile * 16 + i;
     const int ow = p & ((1 << lgW) - 1), oh = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
     const int bh = oh * a.sh, bw = ow * a.sw;
-    const bool pok = p < P;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int ih = bh + tdh[s], iw = bw + tdw[s];
-      const bool ok = pok && tok[s] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const bool ok = tok[s] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
       const unsigned off = ok ? (unsigned)(((n * a.Hin + ih) * a.Win + iw) * 16) : DMA_OOB;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0);
       fb[s] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
-  auto finish_tile = [&](int tile, const uint4 (&fb)[S]) {
+  auto finish_tile = [&](int tile_, const uint4 (&fb)[S]) {
+    const int tile = tile_ < tile_last ? tile_ : tile_last;
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -796,22 +814,22 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = mma16<bf16>(wfrag[(s * 4 + t) * 64 + wl], fb[s], acc[t]);
     const int p = tile * 16 + i;
-    if (p >= P) return;
-    float v[16];
+    float lo[8], hi[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[4 * t + e] = act_apply(a.out_act, acc[t][e] + bias[4 * t + e]);
-    float lo[8], hi[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[8 + e]; }
+      for (int e = 0; e < 4; ++e) {
+        const float x = fmaxf(acc[t][e] + bias[4 * t + e], act_floor);
+        if (t < 2) lo[4 * t + e] = x; else hi[4 * (t - 2) + e] = x;
+      }
+    const uint4 plo = Elem<bf16>::pack(lo), phi = Elem<bf16>::pack(hi);
     if (rowrun) {
       // the 16 pixels of a tile are 2 KB of consecutive output; a lane's own two pieces are 64-byte segments 128 bytes apart (half
       // cache lines per store instruction).  Transpose through a wave-private LDS tile (pixel pitch 144 bytes: conflict-free both
       // ways) so that each of the two store instructions writes one contiguous 1 KB run
       char* tb = reinterpret_cast<char*>(otile) + (threadIdx.x >> 6) * (16 * 144);
-      *reinterpret_cast<uint4*>(tb + i * 144 + g * 16) = Elem<bf16>::pack(lo);
-      *reinterpret_cast<uint4*>(tb + i * 144 + 64 + g * 16) = Elem<bf16>::pack(hi);
+      *reinterpret_cast<uint4*>(tb + i * 144 + g * 16) = plo;
+      *reinterpret_cast<uint4*>(tb + i * 144 + 64 + g * 16) = phi;
       __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own LDS writes have landed (same-wave, no barrier)
       __builtin_amdgcn_wave_barrier();
       const uint4 q0 = *reinterpret_cast<const uint4*>(tb + (lane >> 3) * 144 + (lane & 7) * 16);
@@ -824,17 +842,17 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
     }
     const int ow = p & ((1 << lgW) - 1), oh = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
     const size_t yo = ((size_t)(n * a.Hof + oh) * a.Wof + ow) * a.ldY + 8 * g;
-    if (!ACTS || a.Y != nullptr) {      // (ACTS: the raw output is optional - IgemmArgs::xa_lrelu)
+    if constexpr (OUTS & 1) {
       bf16* yp = reinterpret_cast<bf16*>(a.Y) + yo;
-      reinterpret_cast<uint4*>(yp)[0] = Elem<bf16>::pack(lo);
-      reinterpret_cast<uint4*>(yp + 32)[0] = Elem<bf16>::pack(hi);
+      reinterpret_cast<uint4*>(yp)[0] = plo;
+      reinterpret_cast<uint4*>(yp + 32)[0] = phi;
     }
     // the consumers' activations of the ROUNDED output (what act_apply computes from the stored tensor: same bits)
     if constexpr (ACTS) {
       float rl[8], rh[8];
-      Elem<bf16>::unpack(Elem<bf16>::pack(lo), rl);
-      Elem<bf16>::unpack(Elem<bf16>::pack(hi), rh);
-      if (a.xa_lrelu) {
+      Elem<bf16>::unpack(plo, rl);
+      Elem<bf16>::unpack(phi, rh);
+      if constexpr (OUTS & 2) {
         float t0[8], t1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { t0[e] = act_apply(ACT_LRELU, rl[e]); t1[e] = act_apply(ACT_LRELU, rh[e]); }
@@ -842,7 +860,7 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
         reinterpret_cast<uint4*>(xp)[0] = Elem<bf16>::pack(t0);
         reinterpret_cast<uint4*>(xp + 32)[0] = Elem<bf16>::pack(t1);
       }
-      if (a.xa_relu) {
+      if constexpr (OUTS & 4) {
         float t0[8], t1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { t0[e] = act_apply(ACT_RELU, rl[e]); t1[e] = act_apply(ACT_RELU, rh[e]); }
@@ -853,23 +871,19 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
     }
   };
 
-  // three fragment sets: two tiles of loads stay in flight behind the tile being finished
+  // three fragment sets: two tiles of loads stay in flight behind the tile being finished; trips of three tiles, no branch inside
   uint4 fb0[S], fb1[S], fb2[S];
   int tile = wave_global;
-  if (tile < ntile) load_tile(tile, fb0);
-  if (tile + nwave < ntile) load_tile(tile + nwave, fb1);
-  while (tile < ntile) {
-    if (tile + 2 * nwave < ntile) load_tile(tile + 2 * nwave, fb2);
+  load_tile(tile, fb0);
+  load_tile(tile + nwave, fb1);
+  for (int trip = (my_n + 2) / 3; trip > 0; --trip) {
+    load_tile(tile + 2 * nwave, fb2);
     finish_tile(tile, fb0);
-    tile += nwave;
-    if (tile >= ntile) break;
-    if (tile + 2 * nwave < ntile) load_tile(tile + 2 * nwave, fb0);
-    finish_tile(tile, fb1);
-    tile += nwave;
-    if (tile >= ntile) break;
-    if (tile + 2 * nwave < ntile) load_tile(tile + 2 * nwave, fb1);
-    finish_tile(tile, fb2);
-    tile += nwave;
+    load_tile(tile + 3 * nwave, fb0);
+    finish_tile(tile + nwave, fb1);
+    load_tile(tile + 4 * nwave, fb1);
+    finish_tile(tile + 2 * nwave, fb2);
+    tile += 3 * nwave;
   }
 }
 
@@ -1767,7 +1781,9 @@ bool conv_cin8_eligible(const IgemmArgs& a, int is_bf16) {
   const bool pow2 = (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0;
   return is_bf16 && a.Cin == 8 && a.x.C[0] == 8 && a.x.C[1] == 0 && a.Cout == 64 && a.ldY == 64 && a.nclass == 1 && a.splitk == 1 && a.os == 1 &&
          a.Hof == a.Hg && a.Wof == a.Wg && pow2 && !a.ref && !a.accumulate && !a.y_f32 && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
-         a.ntaps <= 16 && (a.Kpad == 96 || a.Kpad == 128) && (size_t)a.N * a.Hin * a.Win * 16 < 0x70000000ull;
+         a.ntaps <= 16 && (a.Kpad == 96 || a.Kpad == 128) && (size_t)a.N * a.Hin * a.Win * 16 < 0x70000000ull &&
+         (((long long)a.N * a.Hg * a.Wg) & 15) == 0 && (a.out_act == ACT_NONE || a.out_act == ACT_RELU) &&
+         (a.Kpad == 128 || !(a.xa_lrelu || a.xa_relu)) && !(a.xa_relu && !a.xa_lrelu);      // (the instantiated output combinations: conv_cin8_kernel)
 }
 
 template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int cfg, hipStream_t st) {
@@ -1789,14 +1805,20 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       int lgW = 0, lgH = 0;
       while ((1 << lgW) < a.Wg) ++lgW;
       while ((1 << lgH) < a.Hg) ++lgH;
-      const bool acts = a.xa_lrelu || a.xa_relu;
-      if (a.Kpad == 96) {
-        if (acts) hipLaunchKernelGGL((conv_cin8_kernel<3, true>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
-        else hipLaunchKernelGGL((conv_cin8_kernel<3, false>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
-      } else {
-        if (acts) hipLaunchKernelGGL((conv_cin8_kernel<4, true>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
-        else hipLaunchKernelGGL((conv_cin8_kernel<4, false>), dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
+      // which outputs exist is a template parameter (bit 0 raw output, 1 lrelu copy, 2 relu copy): the tile loop has no branch
+      const int outs = (a.Y ? 1 : 0) | (a.xa_lrelu ? 2 : 0) | (a.xa_relu ? 4 : 0);
+      void (*kern)(const IgemmArgs, int, int) = nullptr;
+      if (a.Kpad == 96) kern = outs == 1 ? conv_cin8_kernel<3, 1> : nullptr;
+      else switch (outs) {
+        case 1: kern = conv_cin8_kernel<4, 1>; break;
+        case 2: kern = conv_cin8_kernel<4, 2>; break;
+        case 3: kern = conv_cin8_kernel<4, 3>; break;
+        case 6: kern = conv_cin8_kernel<4, 6>; break;
+        case 7: kern = conv_cin8_kernel<4, 7>; break;
+        default: break;
       }
+      if (!kern) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, a, lgW, lgH);
       return hipGetLastError();
     }
   }

@@ -708,7 +708,7 @@ static int run_layer_fwd_half(vp_pixrefer* h, Net& n, Layer& L, int half, hipStr
 static bool first_layer_acts_fused(const vp_pixrefer* h, const Net& n, const Layer& L) {
   if (!h->bf16 || L.has_bn || L.tapgemm || L.out_act != ACT_NONE) return false;
   const Tens& to = n.t[L.out];
-  if (!(to.need_act[ACT_LRELU] || to.need_act[ACT_RELU]) || to.is_f32) return false;
+  if (!to.need_act[ACT_LRELU] || to.is_f32) return false;      // (the kernel's output combinations: lrelu copy [+ relu copy] [+ raw])
   IgemmArgs a = L.fwd.a;
   fill_src(n, L, a.x, n.batch / n.groups, 0, 0, h->es);
   a.ldY = to.C; a.y_f32 = 0; a.out_act = L.out_act;
