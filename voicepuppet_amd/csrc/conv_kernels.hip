@@ -733,9 +733,9 @@ __global__ __launch_bounds__((WC * WP + 4) * 64) void igemm_ws_kernel(const Igem
 // and the loads of tile t + 1 in every iteration (ablation, profiles/r06_cin8_ablation.txt: conv1_1 0.178 ms = 0.053 instruction stream +
 // 0.12 stores, not overlapped: 3.1 TB/s with 16 waves x 2 KB of stores in flight per CU).  Now: tile indices are clamped to the wave's last
 // tile (a wave past its end recomputes and re-stores that tile: same bytes), the pixel count is a multiple of 16 (eligibility), out_act is
-// NONE or RELU as a floor value, which outputs exist is a template parameter (OUTS: 1 raw, 2 lrelu copy, 4 relu copy), and the three
-// fragment sets rotate through a loop unrolled by three: the compiler's own counts come out exact (the loads of tile t wait with the
-// stores of two tiles and the loads of two tiles still in flight).
+// NONE or RELU as a floor value, which outputs exist is a template parameter (OUTS: 1 raw, 2 lrelu copy, 4 relu copy), and the four
+// fragment sets rotate through a loop unrolled by four: the compiler's own counts come out exact (the loads of tile t wait with the
+// stores of the previous tiles and the loads of three tiles still in flight).
 // (Forcing five / six waves per SIMD with amdgpu_waves_per_eu - the kernel allocates 104-124 registers, four / three waves - spills: conv1_1 0.155
 // -> 0.155 / 0.253 ms, the stride-2 layers 0.093 -> 0.117 / 0.183: profiles/r06_cin8_ablation.txt.)
 template <int S, int OUTS>
@@ -871,19 +871,23 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
     }
   };
 
-  // three fragment sets: two tiles of loads stay in flight behind the tile being finished; trips of three tiles, no branch inside
-  uint4 fb0[S], fb1[S], fb2[S];
+  // four fragment sets: three tiles of loads stay in flight behind the tile being finished; trips of four tiles, no branch inside
+  // (four sets, three tiles of loads in flight: the stride-2 first layers 0.053 / 0.043 -> 0.045 / 0.038 ms against three sets; conv1_1 +-0)
+  uint4 fb0[S], fb1[S], fb2[S], fb3[S];
   int tile = wave_global;
   load_tile(tile, fb0);
   load_tile(tile + nwave, fb1);
-  for (int trip = (my_n + 2) / 3; trip > 0; --trip) {
-    load_tile(tile + 2 * nwave, fb2);
+  load_tile(tile + 2 * nwave, fb2);
+  for (int trip = (my_n + 3) / 4; trip > 0; --trip) {
+    load_tile(tile + 3 * nwave, fb3);
     finish_tile(tile, fb0);
-    load_tile(tile + 3 * nwave, fb0);
+    load_tile(tile + 4 * nwave, fb0);
     finish_tile(tile + nwave, fb1);
-    load_tile(tile + 4 * nwave, fb1);
+    load_tile(tile + 5 * nwave, fb1);
     finish_tile(tile + 2 * nwave, fb2);
-    tile += 3 * nwave;
+    load_tile(tile + 6 * nwave, fb2);
+    finish_tile(tile + 3 * nwave, fb3);
+    tile += 4 * nwave;
   }
 }
 
