@@ -1097,10 +1097,15 @@ __global__ __launch_bounds__(256) void deconv_cout4_tile_kernel(const IgemmArgs 
 // stages the 6 x 18 pixel halo once in LDS (one tile ahead in registers), wave w multiplies row w against the weight fragments -
 // which are only 18 x 16 bytes per lane and stay in registers.  Rows 0..7 of the MFMA tile are the channels: lanes g = 0 / 1 hold
 // channels 0..3 / 4..7 of pixel i, one cross-lane move joins them into the 16-byte output row (epi_store8).
+// Round 6: branch-free tile loop (as conv_cin8_kernel, EXPERIMENTS.md 0.7): the block's tile index is clamped to its last tile, the LDS
+// staging writes of the threads beyond the halo's 864 pieces go to a dummy slot, the output store is a buffer store whose offset is out of
+// range for the lanes that hold no output piece (dropped by the hardware), and the epilogue is the plain one (no bias / activation /
+// reference / accumulation: eligibility) - so hipcc's s_waitcnt pass counts exactly and the tile's store stays in flight across the next
+// tile's barrier instead of being drained by a vmcnt(0) in front of it.
 __global__ __launch_bounds__(256) void conv3x3_cout8_tile_kernel(const IgemmArgs a, int lgW, int lgH) {
   constexpr int PIXB = 64 * 2 + 16, TPX = 6 * 18, NPIECE = TPX * 8, NJ = (NPIECE + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* stage = smem;                                             // [6][18][PIXB]
+  char* stage = smem;                                             // [6][18][PIXB], then 256 dummy 16-byte slots
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   uint4 af[18];
@@ -1119,38 +1124,47 @@ __global__ __launch_bounds__(256) void conv3x3_cout8_tile_kernel(const IgemmArgs
   }
   const int tw = 1 << (lgW - 4), th = 1 << (lgH - 2);
   const int ntile = a.N * tw * th;
+  const int my_n = (int)blockIdx.x < ntile ? (ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  if (my_n == 0) return;
+  const int tile_last = blockIdx.x + (my_n - 1) * gridDim.x;
   __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * 64 * 2));
+  __amdgpu_buffer_rsrc_t rsY = make_rsrc(a.Y, (unsigned)((size_t)a.N * a.Hof * a.Wof * a.ldY * 2));
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   int soff[NJ], spix_r[NJ], spix_c[NJ], sch[NJ];
+  bool sok[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int idx = threadIdx.x + 256 * j;
     const int px = idx >> 3, c = (idx & 7) * 8;
     spix_r[j] = px / 18; spix_c[j] = px - spix_r[j] * 18;
     sch[j] = c;
-    soff[j] = idx < NPIECE ? px * PIXB + c * 2 : -1;
+    sok[j] = idx < NPIECE;
+    soff[j] = sok[j] ? px * PIXB + c * 2 : TPX * PIXB + (int)threadIdx.x * 16;      // (beyond the halo: the thread's dummy slot)
   }
   uint4 pre[NJ];
-  auto load_tile = [&](int tile) {
+  auto load_tile = [&](int tile_) {
+    const int tile = tile_ < tile_last ? tile_ : tile_last;
     const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int ih = tr * 4 - 1 + spix_r[j], iw = tc * 16 - 1 + spix_c[j];
-      const bool ok = soff[j] >= 0 && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const bool ok = sok[j] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
       const unsigned off = ok ? (unsigned)((((n * a.Hin + ih) * a.Win + iw) * 64 + sch[j]) * 2) : DMA_OOB;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)off, 0, 0);
       pre[j] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
   int tile = blockIdx.x;
-  if (tile < ntile) load_tile(tile);
-  while (tile < ntile) {
+  load_tile(tile);
+  // (a store that goes nowhere - offset out of range - behind the first tile's loads: the loop's first trip then looks like every other one
+  // to the s_waitcnt pass, which otherwise merges "no store pending" with "one store pending" into vmcnt(0) at the loop header)
+  __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, rsY, (int)DMA_OOB, 0, 0);
+  for (int it = my_n; it > 0; --it) {
     __syncthreads();                                              // previous tile's fragment reads are done
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) if (soff[j] >= 0) *reinterpret_cast<uint4*>(stage + soff[j]) = pre[j];
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<uint4*>(stage + soff[j]) = pre[j];
     __syncthreads();
-    const int nxt = tile + gridDim.x;
-    if (nxt < ntile) load_tile(nxt);
+    load_tile(tile + gridDim.x);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const char* px = stage + (wv * 18 + i) * PIXB + g * 16;
 #pragma unroll
@@ -1160,12 +1174,12 @@ __global__ __launch_bounds__(256) void conv3x3_cout8_tile_kernel(const IgemmArgs
     float v[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = acc[e]; v[4 + e] = __shfl(acc[e], (lane + 16) & 63); }
-    if (g == 0) {
-      const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
-      const size_t off = ((size_t)(n * a.Hof + tr * 4 + wv) * a.Wof + tc * 16 + i) * a.ldY;
-      epi_store8<bf16>(a, 0, 0, off, v);
-    }
-    tile = nxt;
+    const int tl = tile < tile_last ? tile : tile_last;
+    const int tc = tl & (tw - 1), tr = (tl >> (lgW - 4)) & (th - 1), n = tl >> (lgW - 4 + lgH - 2);
+    const unsigned yo = g == 0 ? (unsigned)((((n * a.Hof + tr * 4 + wv) * a.Wof + tc * 16 + i) * a.ldY) * 2) : DMA_OOB;
+    const uint4 pk = Elem<bf16>::pack(v);
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk.x, pk.y, pk.z, pk.w}, rsY, (int)yo, 0, 0);
+    tile += gridDim.x;
   }
 }
 
@@ -1833,7 +1847,8 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     if (near && a.zeros && a.nclass == 1 && a.sh == 1 && a.sw == 1 && a.os == 1 && a.Cin == 64 && a.x.C[0] == 64 && a.x.C[1] == 0 &&
         a.CoutPad == 16 && a.Cout <= 8 && a.ldY == 8 && a.splitk == 1 && !a.rowperm && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE &&
         (a.Wg & (a.Wg - 1)) == 0 && (a.Hg & (a.Hg - 1)) == 0 && a.Wg >= 16 && a.Hg >= 4 && a.Hof == a.Hg && a.Wof == a.Wg && a.Hin == a.Hg &&
-        a.Win == a.Wg && !a.y_f32 && (size_t)a.N * a.Hin * a.Win * 64 * 2 < 0x70000000ull) {
+        a.Win == a.Wg && !a.y_f32 && (size_t)a.N * a.Hin * a.Win * 64 * 2 < 0x70000000ull &&
+        !a.bias && a.out_act == ACT_NONE && !a.ref && !a.accumulate && !a.split_c) {          // (the kernel's plain epilogue)
       ProfScope prof("cout8", true, 16, 64, 2.0 * Pn * a.Cout * kreal,
                      es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.Cout + Pn * a.Cout), st);
       int lgW = 0, lgH = 0;
@@ -1841,7 +1856,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       while ((1 << lgH) < a.Hg) ++lgH;
       int tblocks = a.N << (lgW - 4 + lgH - 2);
       if (tblocks > 4096) tblocks = 4096;
-      hipLaunchKernelGGL(conv3x3_cout8_tile_kernel, dim3(tblocks), dim3(256), (size_t)6 * 18 * 144, st, a, lgW, lgH);
+      hipLaunchKernelGGL(conv3x3_cout8_tile_kernel, dim3(tblocks), dim3(256), (size_t)6 * 18 * 144 + 256 * 16, st, a, lgW, lgH);
       return hipGetLastError();
     }
   }
