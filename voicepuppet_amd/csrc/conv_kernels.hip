@@ -999,13 +999,13 @@ __global__ __launch_bounds__(256) void deconv_cout4_kernel(const IgemmArgs a, in
 // 6 x 18 pixel halo tile (1.7x the interior) with 16-byte loads - one tile ahead, in registers, while the current tile computes - and
 // store it to LDS at a padded pixel pitch (Cin * 2 + 16 bytes: the 16 lanes of a fragment read hit 64 distinct banks); wave w then
 // builds the B fragments of row w for all nine taps from LDS.  Same MFMA tile, weight image and output mapping as above.
-template <int SPT>
+template <int SPT, int HALVED>
 __global__ __launch_bounds__(256) void deconv_cout4_tile_kernel(const IgemmArgs a, int lgW, int lgH) {
   constexpr int S = 9 * SPT, CIN = SPT * 32, PPP = CIN / 8;       // 16-byte pieces per pixel
   constexpr int PIXB = CIN * 2 + 16, TPX = 6 * 18, NPIECE = TPX * PPP, NJ = (NPIECE + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* wfrag = reinterpret_cast<uint4*>(smem);                  // [S][64]
-  char* stage = smem + (size_t)S * 64 * 16;                       // [6][18][PIXB]
+  char* stage = smem + (size_t)S * 64 * 16;                       // [6][18][PIXB], then 256 dummy 16-byte slots
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   {
@@ -1032,47 +1032,59 @@ __global__ __launch_bounds__(256) void deconv_cout4_tile_kernel(const IgemmArgs 
   }
   const int tw = 1 << (lgW - 4), th = 1 << (lgH - 2);             // tiles per row / per column of one image
   const int ntile = a.N * tw * th;
-  const int C0 = a.x.C[0], C1 = a.x.C[1];
-  __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * C0 * 2));
-  __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.x.ptr[1] ? a.x.ptr[1] : a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * C1 * 2));
+  const int my_n = (int)blockIdx.x < ntile ? (ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  if (my_n == 0) return;
+  const int tile_last = blockIdx.x + (my_n - 1) * gridDim.x;
+  // One source per wave: with two equally wide concatenated sources (HALVED: the decoder's skip connection) waves 0-1 fetch the first
+  // one's channels and waves 2-3 the second's, so that the buffer descriptor is a scalar select and every piece is ONE load; otherwise
+  // (HALVED == 0) there is a single source.
+  const int src = HALVED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
+  const int CS = HALVED ? CIN / 2 : CIN;                          // channels of one source
+  constexpr int PPS = HALVED ? PPP / 2 : PPP, NTH = HALVED ? 128 : 256;
+  __amdgpu_buffer_rsrc_t rs0 = make_rsrc(src ? a.x.ptr[1] : a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * CS * 2));
+  __amdgpu_buffer_rsrc_t rsY = make_rsrc(a.Y, (unsigned)((size_t)a.N * a.Hof * a.Wof * 4 * 4));
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   float bias[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) bias[e] = a.bias ? a.bias[e] : 0.f;
 
-  // this thread's pieces of a halo tile: (pixel slot, 8-channel group) -> LDS byte offset, source, channel offset
+  // this thread's pieces of a halo tile: (pixel slot, 8-channel group) -> LDS byte offset, channel offset inside the source
   int soff[NJ], spix_r[NJ], spix_c[NJ], sch[NJ];
+  bool sok[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int idx = threadIdx.x + 256 * j;
-    const int px = idx / PPP, c = (idx - px * PPP) * 8;
+    const int idx = (int)(threadIdx.x & (NTH - 1)) + NTH * j;
+    const int px = idx / PPS, c = (idx - px * PPS) * 8;
     spix_r[j] = px / 18; spix_c[j] = px - spix_r[j] * 18;
     sch[j] = c;
-    soff[j] = idx < NPIECE ? px * PIXB + c * 2 : -1;
+    sok[j] = idx < TPX * PPS;
+    soff[j] = sok[j] ? px * PIXB + (src * CS + c) * 2 : TPX * PIXB + (int)threadIdx.x * 16;   // (beyond the halo: the thread's dummy slot)
   }
   uint4 pre[NJ];
-  auto load_tile = [&](int tile) {
+  // The tile loop is branch-free (see conv3x3_cout8_tile_kernel): tiles beyond the block's last one are clamped to it, threads beyond the
+  // halo write a dummy LDS slot.
+  auto load_tile = [&](int tile_) {
+    const int tile = tile_ < tile_last ? tile_ : tile_last;
+    const bool live = tile_ <= tile_last;                         // (beyond the block's last tile: every offset out of range, no data moves)
     const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int ih = tr * 4 - 1 + spix_r[j], iw = tc * 16 - 1 + spix_c[j];
-      const bool ok = soff[j] >= 0 && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-      const int pix = (n * a.Hin + ih) * a.Win + iw;
-      const bool s1 = sch[j] >= C0;
-      const unsigned off = ok ? (unsigned)((pix * (s1 ? C1 : C0) + (s1 ? sch[j] - C0 : sch[j])) * 2) : DMA_OOB;
-      const u32x4 v = s1 ? __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)off, 0, 0);
+      const bool ok = live && sok[j] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const unsigned off = ok ? (unsigned)((((n * a.Hin + ih) * a.Win + iw) * CS + sch[j]) * 2) : DMA_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)off, 0, 0);
       pre[j] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
   int tile = blockIdx.x;
-  if (tile < ntile) load_tile(tile);
-  while (tile < ntile) {
+  load_tile(tile);
+  __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, rsY, (int)DMA_OOB, 0, 0);   // (see conv3x3_cout8_tile_kernel)
+  for (int it = my_n; it > 0; --it) {
     __syncthreads();                                              // previous tile's fragment reads are done (first pass: wfrag is complete)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) if (soff[j] >= 0) *reinterpret_cast<uint4*>(stage + soff[j]) = pre[j];
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<uint4*>(stage + soff[j]) = pre[j];
     __syncthreads();
-    const int nxt = tile + gridDim.x;
-    if (nxt < ntile) load_tile(nxt);
+    load_tile(tile + gridDim.x);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     int wl = lane;
     asm volatile("" : "+v"(wl));                                  // keep the weight image in LDS (no hoisting into registers)
@@ -1085,9 +1097,10 @@ __global__ __launch_bounds__(256) void deconv_cout4_tile_kernel(const IgemmArgs 
     }
     const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
     const int q = tr * 4 + wv, r = tc * 16 + i;
-    float* yp = reinterpret_cast<float*>(a.Y) + ((size_t)(n * a.Hof + 2 * q + (g >> 1)) * a.Wof + 2 * r + (g & 1)) * 4;
-    *reinterpret_cast<float4*>(yp) = make_float4(acc[0] + bias[0], acc[1] + bias[1], acc[2] + bias[2], acc[3] + bias[3]);
-    tile = nxt;
+    const unsigned yo = (unsigned)(((n * a.Hof + 2 * q + (g >> 1)) * a.Wof + 2 * r + (g & 1)) * 16);
+    const float4 o = make_float4(acc[0] + bias[0], acc[1] + bias[1], acc[2] + bias[2], acc[3] + bias[3]);
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)}, rsY, (int)yo, 0, 0);
+    tile += gridDim.x;
   }
 }
 
@@ -1144,11 +1157,12 @@ __global__ __launch_bounds__(256) void conv3x3_cout8_tile_kernel(const IgemmArgs
   uint4 pre[NJ];
   auto load_tile = [&](int tile_) {
     const int tile = tile_ < tile_last ? tile_ : tile_last;
+    const bool live = tile_ <= tile_last;                         // (beyond the block's last tile: every offset out of range, no data moves)
     const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int ih = tr * 4 - 1 + spix_r[j], iw = tc * 16 - 1 + spix_c[j];
-      const bool ok = sok[j] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const bool ok = live && sok[j] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
       const unsigned off = ok ? (unsigned)((((n * a.Hin + ih) * a.Win + iw) * 64 + sch[j]) * 2) : DMA_OOB;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)off, 0, 0);
       pre[j] = make_uint4(v.x, v.y, v.z, v.w);
@@ -1193,7 +1207,7 @@ __global__ __launch_bounds__(256) void deconv_cout8_tile_kernel(const IgemmArgs 
   constexpr int PIXB = CIN * 2 + 16, TPX = 6 * 18, NPIECE = TPX * PPP, NJ = (NPIECE + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* wfrag = reinterpret_cast<uint4*>(smem);                  // [2][S][64]
-  char* stage = smem + (size_t)2 * S * 64 * 16;                   // [6][18][PIXB]
+  char* stage = smem + (size_t)2 * S * 64 * 16;                   // [6][18][PIXB], then 256 dummy 16-byte slots
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   {
@@ -1220,38 +1234,49 @@ __global__ __launch_bounds__(256) void deconv_cout8_tile_kernel(const IgemmArgs 
   }
   const int tw = 1 << (lgW - 4), th = 1 << (lgH - 2);
   const int ntile = a.N * tw * th;
+  const int my_n = (int)blockIdx.x < ntile ? (ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  if (my_n == 0) return;
+  const int tile_last = blockIdx.x + (my_n - 1) * gridDim.x;
   __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.x.ptr[0], (unsigned)((size_t)a.N * a.Hin * a.Win * CIN * 2));
+  __amdgpu_buffer_rsrc_t rsY = make_rsrc(a.Y, (unsigned)((size_t)a.N * a.Hof * a.Wof * a.ldY * 2));
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   int soff[NJ], spix_r[NJ], spix_c[NJ], sch[NJ];
+  bool sok[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int idx = threadIdx.x + 256 * j;
     const int px = idx / PPP, c = (idx - px * PPP) * 8;
     spix_r[j] = px / 18; spix_c[j] = px - spix_r[j] * 18;
     sch[j] = c;
-    soff[j] = idx < NPIECE ? px * PIXB + c * 2 : -1;
+    sok[j] = idx < NPIECE;
+    soff[j] = sok[j] ? px * PIXB + c * 2 : TPX * PIXB + (int)threadIdx.x * 16;      // (beyond the halo: the thread's dummy slot)
   }
   uint4 pre[NJ];
-  auto load_tile = [&](int tile) {
+  // The tile loop is branch-free (see conv3x3_cout8_tile_kernel): tiles beyond the block's last one are clamped to it, threads beyond the
+  // halo write a dummy LDS slot, lanes without an output row store to an out-of-range offset.
+  auto load_tile = [&](int tile_) {
+    const int tile = tile_ < tile_last ? tile_ : tile_last;
+    const bool live = tile_ <= tile_last;                         // (beyond the block's last tile: every offset out of range, no data moves)
     const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int ih = tr * 4 - 1 + spix_r[j], iw = tc * 16 - 1 + spix_c[j];
-      const bool ok = soff[j] >= 0 && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const bool ok = live && sok[j] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
       const unsigned off = ok ? (unsigned)((((n * a.Hin + ih) * a.Win + iw) * CIN + sch[j]) * 2) : DMA_OOB;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)off, 0, 0);
       pre[j] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
   int tile = blockIdx.x;
-  if (tile < ntile) load_tile(tile);
-  while (tile < ntile) {
+  load_tile(tile);
+  __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, rsY, (int)DMA_OOB, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, rsY, (int)DMA_OOB, 0, 0);
+  for (int it = my_n; it > 0; --it) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) if (soff[j] >= 0) *reinterpret_cast<uint4*>(stage + soff[j]) = pre[j];
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<uint4*>(stage + soff[j]) = pre[j];
     __syncthreads();
-    const int nxt = tile + gridDim.x;
-    if (nxt < ntile) load_tile(nxt);
+    load_tile(tile + gridDim.x);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     int wl = lane;
     asm volatile("" : "+v"(wl));                                  // keep the weight image in LDS
@@ -1265,7 +1290,8 @@ __global__ __launch_bounds__(256) void deconv_cout8_tile_kernel(const IgemmArgs 
         acc1 = mma16<bf16>(wfrag[(S + u * SPT + k) * 64 + wl], b, acc1);
       }
     }
-    const int tc = tile & (tw - 1), tr = (tile >> (lgW - 4)) & (th - 1), n = tile >> (lgW - 4 + lgH - 2);
+    const int tl = tile < tile_last ? tile : tile_last;
+    const int tc = tl & (tw - 1), tr = (tl >> (lgW - 4)) & (th - 1), n = tl >> (lgW - 4 + lgH - 2);
     const int q = tr * 4 + wv, r = tc * 16 + i;
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
@@ -1273,13 +1299,12 @@ __global__ __launch_bounds__(256) void deconv_cout8_tile_kernel(const IgemmArgs 
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = acc[e]; v[4 + e] = __shfl(acc[e], (lane + 16) & 63); }
-      if ((g & 1) == 0) {
-        const int cls = 2 * T + (g >> 1);
-        const size_t off = ((size_t)(n * a.Hof + 2 * q + (cls >> 1)) * a.Wof + 2 * r + (cls & 1)) * a.ldY;
-        epi_store8<bf16>(a, 0, 0, off, v);
-      }
+      const int cls = 2 * T + (g >> 1);
+      const unsigned yo = (g & 1) == 0 ? (unsigned)((((n * a.Hof + 2 * q + (cls >> 1)) * a.Wof + 2 * r + (cls & 1)) * a.ldY) * 2) : DMA_OOB;
+      const uint4 pk = Elem<bf16>::pack(v);
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){pk.x, pk.y, pk.z, pk.w}, rsY, (int)yo, 0, 0);
     }
-    tile = nxt;
+    tile += gridDim.x;
   }
 }
 
@@ -1819,7 +1844,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
                      es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.Cout + Pn * a.Cout), st);
       const int ntile = (int)((Pn + 15) / 16);
       int blocks = (ntile + 3) / 4;
-      if (blocks > 2048) blocks = 2048;
+      if (blocks > thin_blocks_knob(3)) blocks = thin_blocks_knob(3);
       int lgW = 0, lgH = 0;
       while ((1 << lgW) < a.Wg) ++lgW;
       while ((1 << lgH) < a.Hg) ++lgH;
@@ -1855,7 +1880,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       while ((1 << lgW) < a.Wg) ++lgW;
       while ((1 << lgH) < a.Hg) ++lgH;
       int tblocks = a.N << (lgW - 4 + lgH - 2);
-      if (tblocks > 4096) tblocks = 4096;
+      if (tblocks > thin_blocks_knob(0)) tblocks = thin_blocks_knob(0);
       hipLaunchKernelGGL(conv3x3_cout8_tile_kernel, dim3(tblocks), dim3(256), (size_t)6 * 18 * 144 + 256 * 16, st, a, lgW, lgH);
       return hipGetLastError();
     }
@@ -1865,15 +1890,16 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     if (a.zeros && a.nclass == 4 && a.os == 2 && a.ntaps == 4 && a.Cin == 64 && a.x.C[0] == 64 && a.x.C[1] == 0 && a.CoutPad == 16 && a.Cout <= 8 &&
         a.ldY == 8 && !a.y_f32 && a.splitk == 1 && !a.rowperm && !a.bn_part && !a.x.aff_a[0] && a.x.act == ACT_NONE && (a.Wg & (a.Wg - 1)) == 0 &&
         (a.Hg & (a.Hg - 1)) == 0 && a.Wg >= 16 && a.Hg >= 4 && a.Hof == 2 * a.Hg && a.Wof == 2 * a.Wg && a.Hin == a.Hg && a.Win == a.Wg &&
-        (size_t)a.N * a.Hin * a.Win * 64 * 2 < 0x70000000ull) {
+        (size_t)a.N * a.Hin * a.Win * 64 * 2 < 0x70000000ull && (size_t)a.N * a.Hof * a.Wof * 8 * 2 < 0x70000000ull &&
+        !a.bias && a.out_act == ACT_NONE && !a.ref && !a.accumulate && !a.split_c) {          // (the kernel's plain epilogue)
       ProfScope prof("dcout8", true, 32, 64, 2.0 * Pn * a.Cout * kreal,
                      es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout + Pn * a.Cout), st);
       int lgW = 0, lgH = 0;
       while ((1 << lgW) < a.Wg) ++lgW;
       while ((1 << lgH) < a.Hg) ++lgH;
       int tblocks = a.N << (lgW - 4 + lgH - 2);
-      if (tblocks > 4096) tblocks = 4096;
-      const size_t smt = (size_t)2 * 18 * 64 * 16 + (size_t)6 * 18 * 144;
+      if (tblocks > thin_blocks_knob(1)) tblocks = thin_blocks_knob(1);
+      const size_t smt = (size_t)2 * 18 * 64 * 16 + (size_t)6 * 18 * 144 + 256 * 16;
       (void)hipFuncSetAttribute((const void*)deconv_cout8_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smt);
       hipLaunchKernelGGL(deconv_cout8_tile_kernel<2>, dim3(tblocks), dim3(256), smt, st, a, lgW, lgH);
       return hipGetLastError();
@@ -1886,7 +1912,7 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
     if (a.zeros && a.nclass == 4 && a.os == 2 && a.ntaps == 4 && a.Cout == 4 && a.y_f32 && a.ldY == 4 && a.splitk == 1 && pow2 &&
         a.Cin % 32 == 0 && (spt == 2 || spt == 4) && a.x.C[0] % 32 == 0 && a.x.C[0] + a.x.C[1] == a.Cin && !a.ref && !a.accumulate &&
         a.out_act == ACT_NONE && !a.x.aff_a[0] && !a.x.aff_a[1] && a.x.act == ACT_NONE && a.Hof == 2 * a.Hg && a.Wof == 2 * a.Wg &&
-        (size_t)a.N * a.Hin * a.Win * a.Cin * 2 < 0x70000000ull) {
+        (size_t)a.N * a.Hin * a.Win * a.Cin * 2 < 0x70000000ull && (size_t)a.N * a.Hof * a.Wof * 16 < 0x70000000ull) {
       ProfScope prof("cout4", true, 16, 16, 2.0 * Pn * a.Cout * kreal,
                      es * ((double)a.N * a.Hin * a.Win * a.cin_real + kreal * a.nclass * a.Cout) + 4.0 * Pn * a.Cout, st);
       const int ntile = (a.N * a.Hg * a.Wg + 15) / 16;
@@ -1896,11 +1922,13 @@ template <typename T> static hipError_t launch_igemm_t(const IgemmArgs& a, int c
       while ((1 << lgW) < a.Wg) ++lgW;
       while ((1 << lgH) < a.Hg) ++lgH;
       const size_t sm = (size_t)9 * spt * 64 * 16;
-      if (lgW >= 4 && lgH >= 2) {                        // 4 x 16 base-pixel tiles with the halo staged once in LDS
-        const size_t smt = sm + (size_t)6 * 18 * (a.Cin * 2 + 16);
+      const bool halved = a.x.C[1] == a.x.C[0];
+      if (lgW >= 4 && lgH >= 2 && (halved || a.x.C[1] == 0)) {    // 4 x 16 base-pixel tiles with the halo staged once in LDS
+        const size_t smt = sm + (size_t)6 * 18 * (a.Cin * 2 + 16) + 256 * 16;
         int tblocks = a.N << (lgW - 4 + lgH - 2);
-        if (tblocks > 2048) tblocks = 2048;
-        auto kern = spt == 2 ? deconv_cout4_tile_kernel<2> : deconv_cout4_tile_kernel<4>;
+        if (tblocks > thin_blocks_knob(2)) tblocks = thin_blocks_knob(2);
+        auto kern = spt == 2 ? (halved ? deconv_cout4_tile_kernel<2, 1> : deconv_cout4_tile_kernel<2, 0>)
+                             : (halved ? deconv_cout4_tile_kernel<4, 1> : deconv_cout4_tile_kernel<4, 0>);
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smt);
         hipLaunchKernelGGL(kern, dim3(tblocks), dim3(256), smt, st, a, lgW, lgH);
         return hipGetLastError();

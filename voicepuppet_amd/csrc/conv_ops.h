@@ -36,6 +36,11 @@ inline int& wgrad_cost_knob(int i) { static int v[3] = {80, 15, 150}; return v[i
 // [0] few-pixel kernel: blocks its K split aims at; [1] / [2] implicit GEMM: most K splits, fewest K chunks per split; [3] weight gradient: resident blocks per round of its cost model
 inline int& plan_misc_knob(int i) { static int v[4] = {384, 8, 4, 512}; return v[i]; }
 inline int& igemm_small_grid_knob() { static int v = 128; return v; }
+// grid caps of the thin-layer tile kernels (conv3x3_cout8_tile / deconv_cout8_tile / deconv_cout4_tile): vp_tune("thin_blocks_cout8" /
+// "thin_blocks_dcout8" / "thin_blocks_cout4") and of conv_cin8_kernel ("thin_blocks_cin8").  The blocks are persistent and build a
+// fragment-ordered weight image in LDS first: with the round-5 caps (4096 / 4096 / 2048) a block of layer_1's backward-data launch
+// owned two tiles and the prologue was most of its time (EXPERIMENTS.md 0.8)
+inline int& thin_blocks_knob(int i) { static int v[4] = {1024, 512, 512, 512}; return v[i]; }
 
 // tile choice for an igemm producing `rows` channels over P pixels
 inline int pick_igemm_cfg(int rows, int P, int Kpad = 0) {

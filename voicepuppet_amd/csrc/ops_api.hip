@@ -84,6 +84,10 @@ int vp_tune(const char* key, int value) {
   if (k == "igemm_splitk_minchunk") { plan_misc_knob(2) = value; return VP_OK; }
   if (k == "wgrad_resident_blocks") { plan_misc_knob(3) = value; return VP_OK; }
   if (k == "igemm_small_grid") { igemm_small_grid_knob() = value; return VP_OK; }
+  if (k == "thin_blocks_cout8" && value > 0) { thin_blocks_knob(0) = value; return VP_OK; }
+  if (k == "thin_blocks_dcout8" && value > 0) { thin_blocks_knob(1) = value; return VP_OK; }
+  if (k == "thin_blocks_cout4" && value > 0) { thin_blocks_knob(2) = value; return VP_OK; }
+  if (k == "thin_blocks_cin8" && value > 0) { thin_blocks_knob(3) = value; return VP_OK; }
   if (k == "phase_marks") { vp_phase_marks_enable(value); return VP_OK; }
   set_err("vp_tune: unknown key %s", key);
   return VP_ERR_ARG;
