@@ -180,9 +180,32 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnArgs a) {
       }
     }
   }
-  // reduce over the pixel lanes that share a channel group
+  // reduce over the pixel lanes that share a channel group.  Fewer than 64 groups (<= 256 channels in bf16): a wave holds 64 / ncg lanes
+  // per group - folded with xor shuffles first, then the four waves through LDS.  (The one-thread-per-group serial walk over all 256 /
+  // ncg rows that this replaces was most of the kernel for narrow tensors: the 8-channel gradient of decoder_1, 4096 dependent LDS
+  // reads, took 90 us for 33 MB.)
   __shared__ double sm[256 * 2];
   double* out = a.partial + ((size_t)(grp * a.nchunk + blockIdx.x) * 2) * a.C;
+  if (ncg < 64) {
+    for (int off = 32; off >= ncg; off >>= 1) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) { s0[e] += __shfl_xor(s0[e], off); s1[e] += __shfl_xor(s1[e], off); }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // (per element e as below: sm is [2][4 waves][ncg])
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      __syncthreads();
+      if (lane < ncg) { sm[wv * ncg + lane] = s0[e]; sm[256 + wv * ncg + lane] = s1[e]; }
+      __syncthreads();
+      if ((int)threadIdx.x < ncg) {
+        const int c = threadIdx.x;
+        out[c * E + e] = (sm[c] + sm[ncg + c]) + (sm[2 * ncg + c] + sm[3 * ncg + c]);
+        out[a.C + c * E + e] = (sm[256 + c] + sm[256 + ncg + c]) + (sm[256 + 2 * ncg + c] + sm[256 + 3 * ncg + c]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     __syncthreads();
