@@ -212,7 +212,9 @@ int vp_pixrefer_pack_frames(const unsigned char* example_frames, const unsigned 
 int vp_tune(const char* key, int value);
 /* Round-6 plan heuristics: "igemm_small_grid" (default 128: a launch whose 128 x 128 tiling has at most that many blocks per class takes the
  * 64-row x 128-pixel tile - twice the blocks; 0: off), "igemm_splitk_target" (default 64, rounds 2-5: 128: resident blocks a K split aims at;
- * < 0: back to the default). */
+ * < 0: back to the default); "thin_blocks_cout8" / "thin_blocks_dcout8" / "thin_blocks_cout4" / "thin_blocks_cin8" (defaults 1024 / 512 /
+ * 512 / 512: grid caps of the persistent thin-layer kernels conv3x3_cout8_tile / deconv_cout8_tile / deconv_cout4_tile / conv_cin8;
+ * values <= 0 are ignored). */
 /* Further keys: "smallp_max_pixels" (largest pixel count per parity class that runs on the few-pixel kernel conv_smallp.hip,
  * default 256, 0: off), "phase_marks" (1: the step executor records HIP events on the caller's stream at its phase boundaries).
  * vp_pixrefer_phase_ms: milliseconds between consecutive marks of the last step (synchronises on them): generator forward,

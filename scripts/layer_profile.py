@@ -7,14 +7,16 @@ from voicepuppet_amd.engine import PixReferEngine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 h = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dt = sys.argv[3] if len(sys.argv) > 3 else "bf16"
-eng = PixReferEngine(n, h, 64, 64, dtype=dt, training=True)
-eng.load_params(eng.random_params(0))
-for kv in sys.argv[4:]:          # plan options, e.g. bwd_sums_in_epilogue=0; library knobs as tune:thin_blocks_cout4=1024
+for kv in sys.argv[4:]:          # library knobs (before the plan is made), e.g. tune:thin_blocks_cout4=1024
   k, v = kv.split("=")
   if k.startswith("tune:"):
     from voicepuppet_amd import _lib
     _lib.check(_lib.lib().vp_tune(k[5:].encode(), int(v)))
-  else:
+eng = PixReferEngine(n, h, 64, 64, dtype=dt, training=True)
+eng.load_params(eng.random_params(0))
+for kv in sys.argv[4:]:          # plan options, e.g. bwd_sums_in_epilogue=0
+  k, v = kv.split("=")
+  if not k.startswith("tune:"):
     eng.set_option(k, int(v))
 batch = bench.synth_batch(n, h, 1, torch.device("cuda"))
 for _ in range(2): eng.train_step(*batch, lr=3e-4)

@@ -751,10 +751,10 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
   // which leaves the registers to occupancy and to the pixel pieces in flight.
   __shared__ uint4 wfrag[S * 4 * 64];
   __shared__ uint4 otile[4 * 16 * 144 / 16];
-  // output rows are dense ([pixel][64]) and the pixel grid is the output grid: a tile's 16 pixels are one 2 KB run
-  // (measured: conv1_1, stride 1, 64 images: 0.209 -> 0.178 ms; the stride-2 first layers, a quarter of the output, lose 8 us each)
+  // output rows are dense ([pixel][64]) and the pixel grid is the output grid: a tile's 16 pixels are one 2 KB run in every output
+  // (measured: conv1_1, stride 1, 64 images: 0.209 -> 0.178 ms in round 5, where the stride-2 first layers lost 8 us each with it; on the
+  // branch-free loop of round 6 they gain: layer_1 0.093 -> 0.089 ms, encoder_1 0.046 -> 0.044 - one store path for every output)
   constexpr bool ACTS = (OUTS & 6) != 0;
-  const bool rowrun = a.sh == 1 && !ACTS;
   {
     const bf16* wp = reinterpret_cast<const bf16*>(a.Wp);
     for (int idx = threadIdx.x; idx < S * 4 * 64; idx += 256) {
@@ -823,30 +823,23 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
         if (t < 2) lo[4 * t + e] = x; else hi[4 * (t - 2) + e] = x;
       }
     const uint4 plo = Elem<bf16>::pack(lo), phi = Elem<bf16>::pack(hi);
-    if (rowrun) {
-      // the 16 pixels of a tile are 2 KB of consecutive output; a lane's own two pieces are 64-byte segments 128 bytes apart (half
-      // cache lines per store instruction).  Transpose through a wave-private LDS tile (pixel pitch 144 bytes: conflict-free both
-      // ways) so that each of the two store instructions writes one contiguous 1 KB run
-      char* tb = reinterpret_cast<char*>(otile) + (threadIdx.x >> 6) * (16 * 144);
-      *reinterpret_cast<uint4*>(tb + i * 144 + g * 16) = plo;
-      *reinterpret_cast<uint4*>(tb + i * 144 + 64 + g * 16) = phi;
+    // the 16 pixels of a tile are 2 KB of consecutive output (dense [pixel][64] rows, pixel grid == output grid: eligibility); a lane's own
+    // two pieces are 64-byte segments 128 bytes apart (half cache lines per store instruction).  Transpose through a wave-private LDS
+    // tile (pixel pitch 144 bytes: conflict-free both ways) so that each of the two store instructions writes one contiguous 1 KB run
+    char* tb = reinterpret_cast<char*>(otile) + (threadIdx.x >> 6) * (16 * 144);
+    auto store_run = [&](void* dst, const uint4& v0, const uint4& v1) {
+      *reinterpret_cast<uint4*>(tb + i * 144 + g * 16) = v0;
+      *reinterpret_cast<uint4*>(tb + i * 144 + 64 + g * 16) = v1;
       __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own LDS writes have landed (same-wave, no barrier)
       __builtin_amdgcn_wave_barrier();
       const uint4 q0 = *reinterpret_cast<const uint4*>(tb + (lane >> 3) * 144 + (lane & 7) * 16);
       const uint4 q1 = *reinterpret_cast<const uint4*>(tb + (8 + (lane >> 3)) * 144 + (lane & 7) * 16);
-      bf16* yt = reinterpret_cast<bf16*>(a.Y) + (size_t)tile * 16 * 64;
+      bf16* yt = reinterpret_cast<bf16*>(dst) + (size_t)tile * 16 * 64;
       reinterpret_cast<uint4*>(yt)[lane] = q0;
       reinterpret_cast<uint4*>(yt)[64 + lane] = q1;
       __builtin_amdgcn_wave_barrier();
-      return;
-    }
-    const int ow = p & ((1 << lgW) - 1), oh = (p >> lgW) & ((1 << lgH) - 1), n = p >> (lgW + lgH);
-    const size_t yo = ((size_t)(n * a.Hof + oh) * a.Wof + ow) * a.ldY + 8 * g;
-    if constexpr (OUTS & 1) {
-      bf16* yp = reinterpret_cast<bf16*>(a.Y) + yo;
-      reinterpret_cast<uint4*>(yp)[0] = plo;
-      reinterpret_cast<uint4*>(yp + 32)[0] = phi;
-    }
+    };
+    if constexpr (OUTS & 1) store_run(a.Y, plo, phi);
     // the consumers' activations of the ROUNDED output (what act_apply computes from the stored tensor: same bits)
     if constexpr (ACTS) {
       float rl[8], rh[8];
@@ -856,17 +849,13 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const IgemmArgs a, int l
         float t0[8], t1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { t0[e] = act_apply(ACT_LRELU, rl[e]); t1[e] = act_apply(ACT_LRELU, rh[e]); }
-        bf16* xp = reinterpret_cast<bf16*>(a.xa_lrelu) + yo;
-        reinterpret_cast<uint4*>(xp)[0] = Elem<bf16>::pack(t0);
-        reinterpret_cast<uint4*>(xp + 32)[0] = Elem<bf16>::pack(t1);
+        store_run(a.xa_lrelu, Elem<bf16>::pack(t0), Elem<bf16>::pack(t1));
       }
       if constexpr (OUTS & 4) {
         float t0[8], t1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { t0[e] = act_apply(ACT_RELU, rl[e]); t1[e] = act_apply(ACT_RELU, rh[e]); }
-        bf16* xp = reinterpret_cast<bf16*>(a.xa_relu) + yo;
-        reinterpret_cast<uint4*>(xp)[0] = Elem<bf16>::pack(t0);
-        reinterpret_cast<uint4*>(xp + 32)[0] = Elem<bf16>::pack(t1);
+        store_run(a.xa_relu, Elem<bf16>::pack(t0), Elem<bf16>::pack(t1));
       }
     }
   };
