@@ -15,4 +15,10 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $o/aprof -o audio --output-forma
 f=$(find $o/aprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $o/audio_kernel_stats.csv; rm -rf $o/aprof
 bash scripts/ab.sh -b "32 8 4" "" "VP_LIB=$PWD/voicepuppet_amd/libvp_r5.so" "tune:streams=1" > $o/ab_vs_r5.txt 2>&1
 scripts/probes/atomic_probe > $o/atomic_probe.txt 2>&1
+python scripts/exp_host_bound.py 4 8 32 2>&1 | grep -v amdgpu.ids > $o/exp_host_enqueue_rate.txt
+for b in 32 4; do
+  bash scripts/timeline.sh $b > /dev/null 2>&1
+  python3 scripts/timeline.py gpurun_out/timeline/on/on_kernel_trace.csv.gz 6 -v > $o/timeline_bs$b.txt 2>&1
+  rm -rf gpurun_out/timeline
+done
 tail -c 400 gpurun_out/r06_bench.json; grep "^batch" $o/ab_vs_r5.txt; cat $o/phases.txt $o/atomic_probe.txt
