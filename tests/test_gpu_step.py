@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle import pixrefer_ref as ref
+from voicepuppet_amd import _lib
 from voicepuppet_amd.engine import PixReferEngine
 
 import gpu_util as gu
@@ -784,3 +785,50 @@ def test_batch_norm_backward_sums_from_the_gradient_epilogue_in_situ(dtype, n, t
       e = gu.rel_l2(grads[1][which][k + f], grads[0][which][k + f])
       assert e < tol_stat, (k + f, e)
   print("bwd sums in the epilogue (%s): %d launches, worst rel-L2 vs the reduce pass: %s" % (dtype, counts[1], worst))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [24, 8])
+def test_one_output_channel_backward_kernel_in_situ(n):
+  """Round 6: the backward-data pass of the PatchGAN's last layer (4x4, stride 1, 512 -> 1 channel) runs on its own kernel
+  (conv_cout1.hip: one MFMA step per 16 channels, the lrelu' product, and the two sums of layer_4's batch-norm backward from the same
+  launch) in both passes - the discriminator-loss pass over the three applications and the generator-loss pass over the fake one.  Against
+  the same full-width bf16 plan on the generic implicit-GEMM kernel + the reduce pass (vp_tune "cout1_bwd" 0): every discriminator and
+  generator gradient to the roundings a different summation order flips (the K = 16 products are exact in float32, the tap sums are not
+  associative), layer_4's dgamma / dbeta - the sums themselves - tightly.  n = 24: both passes on the kernel; n = 8: the
+  discriminator-loss pass only (the generator-loss pass is below the kernel's 16384-pixel floor); 961 pixels per image: the last 16-pixel
+  tile of every batch-norm group is ragged."""
+  L = _lib.lib()
+  grads = {}
+  try:
+    for on in (1, 0):
+      L.vp_tune(b"cout1_bwd", 256 if on else 0)
+      eng = PixReferEngine(n, 256, 64, 64, dtype="bf16", training=True)
+      eng.load_params(eng.random_params(6))
+      g = torch.Generator(device="cpu").manual_seed(10)
+      batch = [torch.rand(n, 256, 256, c, generator=g).cuda() for c in (6, 6, 3, 3)]
+      eng.profile(1)
+      eng.forward(*batch); eng.backward()
+      torch.cuda.synchronize()
+      classes = {r["name"] for r in eng.profile_collect()}
+      eng.profile(0)
+      assert any(c.startswith("cout1bwd_") for c in classes) == bool(on), classes
+      grads[on] = (eng.get_params(1, src=eng.grads_d), eng.get_params(0, src=eng.grads_g))
+      del eng
+  finally:
+    L.vp_tune(b"cout1_bwd", -1)
+  worst = 0.0
+  for which in (0, 1):
+    for k, ref_v in grads[0][which].items():
+      got = grads[1][which][k]
+      if not np.abs(ref_v).max() > 0:
+        assert not np.abs(got).max() > 0, k
+        continue
+      e = gu.rel_l2(got, ref_v)
+      worst = max(worst, e)
+      assert e < 2e-2, (k, e)
+  for f in ("gamma", "beta"):
+    k = "discriminator/layer_4/batch_normalization/" + f
+    e = gu.rel_l2(grads[1][0][k], grads[0][0][k])
+    assert e < 1e-3, (k, e)
+  print("one-output-channel backward kernel, n = %d: worst gradient rel-L2 against the generic kernels %.2e" % (n, worst))

@@ -119,4 +119,20 @@ struct WgradArgs {
   int fast_tr;              // wgrad_tr.hip: buffer-descriptor DMAs with scalar per-chunk offsets (set by the launcher: tensors below 2 GiB)
 };
 
+// conv_cout1.hip: backward-data of a 4x4 stride-1 convolution with ONE output channel over 512 input channels (the discriminator's
+// layer_5), with the act'(reference) product and - optionally - the two raw moments of the producing layer's batch-norm backward
+struct Cout1Args {
+  const void* dy;       // [N, Ho, Wo, ld_dy] bf16: channel 0 is the gradient of the one output channel
+  int ld_dy;
+  const float* w;       // [ks * ks][C] float32 master weights (HWIO with O = 1); rounded to bf16 in the kernel as pack_weights rounds them
+  const void* ref;      // [N, H, W, C] bf16: the materialised activated input (lrelu'(ref) product)
+  int ref_act;
+  const void* y;        // [N, H, W, C] bf16 raw (pre-norm) output of the producer: only read when `part` is set
+  double* part;         // null, or [groups * rows][2][C]: one partial row (sum dx, sum dx * y of the gradient as stored) per block
+  void* dx;             // [N, H, W, C] bf16 out
+  int N, H, W, C, Ho, Wo, ks, pad;
+  int groups, rows;     // batch-norm groups of the N images; blocks (= partial rows) per group
+  int pix_per_group, tiles_per_group;  // (filled by the launcher) pixels and 16-pixel tiles per group (the last tile of a group may be ragged)
+};
+
 }  // namespace vp

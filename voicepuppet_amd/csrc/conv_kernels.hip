@@ -2017,6 +2017,14 @@ hipError_t launch_smallp_fused(const SmallPArgs& s, int is_bf16, hipStream_t st)
   return launch_smallp(s, is_bf16, st);
 }
 
+// the one-output-channel backward-data kernel (conv_cout1.hip), launched by the step executor; timed like every other conv launch
+hipError_t launch_cout1_bwd_prof(const Cout1Args& a, hipStream_t st) {
+  const double px = (double)a.N * a.H * a.W;
+  ProfScope prof("cout1bwd", true, 512, 16, 2.0 * px * a.C * a.ks * a.ks,
+                 2.0 * ((double)a.N * a.Ho * a.Wo + (double)a.ks * a.ks * a.C + px * a.C), st);
+  return launch_conv_cout1_bwd(a, st);
+}
+
 hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st) {
   return is_bf16 ? launch_igemm_t<bf16>(a, cfg, st) : launch_igemm_t<float>(a, cfg, st);
 }

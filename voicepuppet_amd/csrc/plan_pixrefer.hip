@@ -1010,6 +1010,33 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       VP_HIP_CHECK(launch_smallp_fused(sp, h->bf16, st));
       continue;
     }
+    // the PatchGAN's last layer (4x4, stride 1, ONE output channel over 512): its own kernel (conv_cout1.hip), which also leaves the two
+    // sums of the producer's batch-norm backward behind - when that backward is not the one-launch form and the tensor has a table
+    if (L.tapgemm && h->bf16 && cout1_knob() > 0 && !ts.is_input && !ts.hi && !a.accumulate && L.in_act == ACT_LRELU && L.g.ks == 4 && L.g.stride == 1) {
+      const int groups = (gpass || alt) ? 1 : n.groups;
+      Cout1Args c;
+      memset(&c, 0, sizeof(c));
+      c.dy = dy; c.ld_dy = L.g.CoutT;
+      c.w = n.params + L.w_off;
+      c.ref = a.ref; c.ref_act = a.ref_act;
+      c.dx = a.Y;
+      c.N = nb; c.H = ts.H; c.W = ts.W; c.C = ts.C; c.Ho = L.g.Hout; c.Wo = L.g.Wout; c.ks = L.g.ks; c.pad = L.g.pad;
+      c.groups = groups;
+      const int tiles = nb % groups ? 0 : ((nb / groups) * ts.H * ts.W + 15) >> 4;
+      const int cap = gpass ? ts.pbg_cap : ts.pb_cap;
+      const bool sums = h->bst_on && ts.has_bn && ts.producer >= 0 && (nb / groups) * ts.H * ts.W > 2048 && cap > 0;
+      // at least eight tiles per (persistent) block - its prologue loads the block's 32 KB of weights -, and not for launches below 16384
+      // pixels (8 frames, generator-loss pass: 0.025 ms against 0.020 on the generic kernel)
+      c.rows = tiles / 8 < cout1_knob() ? tiles / 8 : cout1_knob();
+      if (sums && c.rows > cap) c.rows = cap;
+      if ((long long)nb * ts.H * ts.W < 16384 || c.rows < 1) c.rows = 0;
+      if (sums) { c.part = gpass ? ts.bn.pbg : ts.bn.pb; c.y = (const char*)ts.y + (size_t)sample0 * ts.H * ts.W * ts.C * es; }
+      if (tiles > 0 && c.rows > 0 && conv_cout1_bwd_eligible(c)) {
+        if (sums) { (gpass ? ts.bst_chunks_g : ts.bst_chunks) = c.rows; h->bst_count++; }
+        VP_HIP_CHECK(launch_cout1_bwd_prof(c, st));
+        continue;
+      }
+    }
     // the bias gradient of a producer without batch-norm (layer_1, encoder_1, encoder_fg_1) from this launch's epilogue when it completes
     // the tensor's gradient on conv_dc64.hip (the only kernel with that epilogue)
     if (h->bst_on && h->bf16 && !ts.is_input && !ts.has_bn && ts.cs_part && !gpass && !alt && ts.producer >= 0 && !n.l[ts.producer].tapgemm &&
