@@ -215,7 +215,8 @@ int vp_tune(const char* key, int value);
  * < 0: back to the default); "thin_blocks_cout8" / "thin_blocks_dcout8" / "thin_blocks_cout4" / "thin_blocks_cin8" (defaults 1024 / 512 /
  * 512 / 512: grid caps of the persistent thin-layer kernels conv3x3_cout8_tile / deconv_cout8_tile / deconv_cout4_tile / conv_cin8;
  * values <= 0 are ignored); "cout1_bwd" (default 256: most blocks per batch-norm group of the one-output-channel backward-data kernel
- * conv_cout1.hip - the discriminator's layer_5 -, 0: that pass on the generic kernels, < 0: back to the default). */
+ * conv_cout1.hip - the discriminator's layer_5 -, 0: that layer's backward passes on the generic kernels, < 0: back to the default), "cout1_wgrad_rows"
+ * (default 512: most blocks = slabs of its weight-gradient kernel). */
 /* Further keys: "smallp_max_pixels" (largest pixel count per parity class that runs on the few-pixel kernel conv_smallp.hip,
  * default 256, 0: off), "phase_marks" (1: the step executor records HIP events on the caller's stream at its phase boundaries).
  * vp_pixrefer_phase_ms: milliseconds between consecutive marks of the last step (synchronises on them): generator forward,

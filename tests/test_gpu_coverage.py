@@ -29,6 +29,8 @@ IN_STEP = {
                              "straddles the concat: generic loader); tests/test_gpu_step.py::test_step_parity[bf16] checks decoder_1/ tightly",
     "cout1bwd_bf16_512x16": "layer_5 backward-data (512 <- 1 channel, with layer_4's batch-norm backward sums): "
                             "tests/test_gpu_step.py::test_one_output_channel_backward_kernel_in_situ against the generic kernels, test_gpu_fullwidth.py against the oracle",
+    "cout1wgrad_bf16_16x512": "layer_5 weight gradient (a wave per pixel, 16 x 8 sums per lane): "
+                              "tests/test_gpu_step.py::test_one_output_channel_backward_kernel_in_situ against the generic kernels, test_gpu_fullwidth.py against the oracle",
     "cout4_bf16_16x16": "decoder_1 forward (128 -> 4 channels, f32 output): tests/test_gpu_step.py::test_step_parity[bf16], "
                         "test_thin_decoder_tile_kernel_in_situ, test_gpu_fullwidth.py",
 }

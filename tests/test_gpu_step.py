@@ -792,7 +792,7 @@ def test_batch_norm_backward_sums_from_the_gradient_epilogue_in_situ(dtype, n, t
 def test_one_output_channel_backward_kernel_in_situ(n):
   """Round 6: the backward-data pass of the PatchGAN's last layer (4x4, stride 1, 512 -> 1 channel) runs on its own kernel
   (conv_cout1.hip: one MFMA step per 16 channels, the lrelu' product, and the two sums of layer_4's batch-norm backward from the same
-  launch) in both passes - the discriminator-loss pass over the three applications and the generator-loss pass over the fake one.  Against
+  launch; its weight gradient on cout1_wgrad_kernel: a wave per pixel, no tap spreading) in both passes - the discriminator-loss pass over the three applications and the generator-loss pass over the fake one.  Against
   the same full-width bf16 plan on the generic implicit-GEMM kernel + the reduce pass (vp_tune "cout1_bwd" 0): every discriminator and
   generator gradient to the roundings a different summation order flips (the K = 16 products are exact in float32, the tap sums are not
   associative), layer_4's dgamma / dbeta - the sums themselves - tightly.  n = 24: both passes on the kernel; n = 8: the
@@ -813,6 +813,7 @@ def test_one_output_channel_backward_kernel_in_situ(n):
       classes = {r["name"] for r in eng.profile_collect()}
       eng.profile(0)
       assert any(c.startswith("cout1bwd_") for c in classes) == bool(on), classes
+      assert any(c.startswith("cout1wgrad_") for c in classes) == bool(on), classes
       grads[on] = (eng.get_params(1, src=eng.grads_d), eng.get_params(0, src=eng.grads_g))
       del eng
   finally:

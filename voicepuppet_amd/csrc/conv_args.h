@@ -132,6 +132,8 @@ struct Cout1Args {
   void* dx;             // [N, H, W, C] bf16 out
   int N, H, W, C, Ho, Wo, ks, pad;
   int groups, rows;     // batch-norm groups of the N images; blocks (= partial rows) per group
+  float* slabs;         // weight-gradient form (cout1_wgrad_kernel): [rows][ks * ks][C] float32 scratch, one slab per block
+  float* dW;            // ... and the gradient [ks * ks][C] float32 (HWIO with O = 1), overwritten
   int pix_per_group, tiles_per_group;  // (filled by the launcher) pixels and 16-pixel tiles per group (the last tile of a group may be ragged)
 };
 

@@ -156,4 +156,134 @@ hipError_t launch_conv_cout1_bwd(const Cout1Args& a0, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// cout1_wgrad_kernel: the weight gradient of the same layer, dW[kh, kw, c] = sum over pixels of dy[n, ih - kh + pad, iw - kw + pad] *
+// x[n, ih, iw, c].  As a GEMM it is 16 "rows" against 512 channels with K = all pixels, K being the strided dimension of both operands:
+// the generic register-transposing kernel ran it at 1.4 TB/s behind a tap-spreading pass (tap_spread_kernel) and in front of a slab
+// reduce.  Here a WAVE owns a pixel at a time: its 64 lanes hold the pixel's 512 channels (one coalesced 1 KB read, 8 channels per lane),
+// the 16 values of dy around the pixel reach it as wave-uniform scalars, and every lane keeps 16 x 8 float32 sums in registers - 128 fused
+// multiply-adds per 16 bytes read.  The four waves of a block fold through LDS and leave one [16][512] slab; cout1_wgrad_reduce_kernel
+// adds the slabs in a fixed order.
+__global__ __launch_bounds__(256) void cout1_wgrad_kernel(const Cout1Args a) {
+  constexpr int C = 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 waves][64 sums][64 lanes] float
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int npix = a.N * a.H * a.W, HW = a.H * a.W;
+  const int nw = gridDim.x * 4, w = blockIdx.x * 4 + wv;
+  // the wave's pixels: a contiguous range
+  const int p0 = (int)((long long)npix * w / nw), p1 = (int)((long long)npix * (w + 1) / nw);
+  __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.ref, (unsigned)((size_t)npix * C * 2));
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  float acc[16][8];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+  // per pixel: one 16-byte load of x per lane and ONE 2-byte load of dy - lane t < 16 fetches tap t of the pixel's neighbourhood (an
+  // out-of-range buffer offset where the tap falls into the padding: zero) -, both U pixels ahead; the sixteen values then reach the
+  // multiply-adds as scalars through v_readlane.  (As sixteen scalar loads per pixel hipcc either sank each load into a branch on its
+  // bounds test, waited for each one in front of its four multiply-adds, or - all of them hoisted - spilled the scalar registers:
+  // 0.10 - 0.12 ms for the launch.)
+  __amdgpu_buffer_rsrc_t rsD = make_rsrc(a.dy, (unsigned)((size_t)a.N * a.Ho * a.Wo * a.ld_dy * 2));
+  constexpr int U = 4;                       // pixels in flight
+  u32x4 xq[U];
+  unsigned dq[U];
+  const int tkh = (lane & 15) >> 2, tkw = lane & 3;
+  // (pixels beyond the wave's range are clamped to its last one - always a valid address, no test around the loads - and their dy is
+  // zeroed where it is used)
+  auto fetch = [&](int p, u32x4& dst, unsigned& ddst) {
+    const int pc = p < p1 ? p : p1 - 1;                           // wave-uniform
+    dst = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)((unsigned)pc * (unsigned)(C * 2) + (unsigned)lane * 16u), 0, 0);
+    const int n = pc / HW, rem = pc - n * HW;
+    const int ih = rem / a.W, iw = rem - ih * a.W;
+    const int oh = ih - tkh + a.pad, ow = iw - tkw + a.pad;
+    const bool ok = lane < 16 && (unsigned)oh < (unsigned)a.Ho && (unsigned)ow < (unsigned)a.Wo;
+    const unsigned doff = ok ? (unsigned)((((n * a.Ho + oh) * a.Wo + ow) * a.ld_dy) * 2) : DMA_OOB;
+    ddst = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsD, (int)doff, 0, 0);
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) fetch(p0 + u, xq[u], dq[u]);
+  for (int pb = p0; pb < p1; pb += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32x4 xv = xq[u];
+      const unsigned dv = pb + u < p1 ? dq[u] : 0u;
+      fetch(pb + u + U, xq[u], dq[u]);
+      float x[8];
+      Elem<bf16>::unpack(make_uint4(xv.x, xv.y, xv.z, xv.w), x);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float d = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)dv, t) << 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(d, x[e], acc[t][e]);
+      }
+    }
+  }
+  // fold the block's four waves (waves 1 .. 3 through LDS, in that order; two rounds of eight taps: 48 KB), one slab per block
+  float* sm = reinterpret_cast<float*>(smem);
+  float* slab = a.slabs + (size_t)blockIdx.x * 16 * C;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm[((wv - 1) * 64 + t * 8 + e) * 64 + lane] = acc[8 * half + t][e];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = ((acc[8 * half + t][e] + sm[(t * 8 + e) * 64 + lane]) + sm[(64 + t * 8 + e) * 64 + lane]) + sm[(128 + t * 8 + e) * 64 + lane];
+        float4* dst = reinterpret_cast<float4*>(slab + (8 * half + t) * C + lane * 8);
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  }
+}
+
+// dW[i] = sum over slabs, in a fixed order: a block owns 16 consecutive elements, its 256 threads are 16 slab phases x 16 elements (a
+// one-thread-per-element walk over 256 - 512 slabs was 100 us of load latency)
+__global__ __launch_bounds__(256) void cout1_wgrad_reduce_kernel(const float* slabs, int nslab, float* dW, int n) {
+  __shared__ float sm[16][17];
+  const int j = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + j;
+  float s = 0.f;
+  for (int k = ph; k < nslab; k += 16 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k + 16 * u < nslab && i < n) ? slabs[(size_t)(k + 16 * u) * n + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  sm[ph][j] = s;
+  __syncthreads();
+  if (ph == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm[q][j];
+    dW[i] = t;
+  }
+}
+
+bool conv_cout1_wgrad_eligible(const Cout1Args& a) {
+  const long long px = (long long)a.N * a.H * a.W;
+  return a.C == 512 && a.ks == 4 && a.dy && a.ref && a.dW && a.slabs && a.rows >= 1 && (a.ld_dy & 1) == 0 && px * 512 * 2 < 0x70000000ll && px >= 4 * (long long)a.rows;
+}
+
+// a.ref = the layer's (materialised, activated) input, a.rows = blocks = slabs, a.slabs >= rows * 16 * 512 floats, a.dW [16][512]
+hipError_t launch_conv_cout1_wgrad(const Cout1Args& a, hipStream_t st) {
+  const int smem = 3 * 64 * 64 * 4;
+  (void)hipFuncSetAttribute((const void*)cout1_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(a.rows), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(cout1_wgrad_reduce_kernel, dim3(16 * 512 / 16), dim3(256), 0, st, a.slabs, a.rows, a.dW, 16 * 512);
+  return hipGetLastError();
+}
+
 }  // namespace vp

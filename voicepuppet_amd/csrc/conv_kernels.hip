@@ -2025,6 +2025,13 @@ hipError_t launch_cout1_bwd_prof(const Cout1Args& a, hipStream_t st) {
   return launch_conv_cout1_bwd(a, st);
 }
 
+hipError_t launch_cout1_wgrad_prof(const Cout1Args& a, hipStream_t st) {
+  const double px = (double)a.N * a.H * a.W;
+  ProfScope prof("cout1wgrad", true, 16, 512, 2.0 * px * a.C * a.ks * a.ks,
+                 2.0 * ((double)a.N * a.Ho * a.Wo + px * a.C) + 4.0 * a.ks * a.ks * a.C, st);
+  return launch_conv_cout1_wgrad(a, st);
+}
+
 hipError_t launch_igemm(const IgemmArgs& a, int is_bf16, int cfg, hipStream_t st) {
   return is_bf16 ? launch_igemm_t<bf16>(a, cfg, st) : launch_igemm_t<float>(a, cfg, st);
 }

@@ -29,6 +29,9 @@ int conv_s2c64_tiles_per_image(const IgemmArgs& a);
 hipError_t launch_conv_s2c64(const IgemmArgs& a, hipStream_t st);
 bool conv_cout1_bwd_eligible(const Cout1Args& a);                                                                 // conv_cout1.hip
 hipError_t launch_conv_cout1_bwd(const Cout1Args& a, hipStream_t st);
+bool conv_cout1_wgrad_eligible(const Cout1Args& a);
+hipError_t launch_conv_cout1_wgrad(const Cout1Args& a, hipStream_t st);
+hipError_t launch_cout1_wgrad_prof(const Cout1Args& a, hipStream_t st);
 hipError_t launch_cout1_bwd_prof(const Cout1Args& a, hipStream_t st);                                               // ... with the per-launch profile record (conv_kernels.hip)
 hipError_t launch_igemm_patch2(const IgemmArgs& a, int is_bf16, int bc, int bp, hipStream_t st);                   // conv_patch2.hip
 hipError_t launch_igemm_smallp(const IgemmArgs& a, int is_bf16, hipStream_t st);                                   // conv_smallp.hip (plain epilogue)

@@ -67,6 +67,7 @@ int vp_tune(const char* key, int value) {
   if (k == "patch3") { patch3_knob() = value; return VP_OK; }
   if (k == "c64") { c64_knob() = value; return VP_OK; }
   if (k == "dc64") { dc64_knob() = value; return VP_OK; }
+  if (k == "cout1_wgrad_rows" && value > 0) { wgrad1_rows_knob() = value; return VP_OK; }
   if (k == "cout1_bwd") { cout1_knob() = value < 0 ? 256 : value; return VP_OK; }
   if (k == "s2c64") { s2c64_knob() = value; return VP_OK; }
   if (k == "wgrad_big") { wgrad_big_knob() = value; return VP_OK; }

@@ -837,7 +837,28 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     PixSrc ds;
     set_single_src(ds, dy, L.g.CoutT, nullptr, nullptr, ACT_NONE, 0);
     if (L.g.kind == 0) { w.g = xs; w.d = ds; } else { w.g = ds; w.d = xs; }
-    if (L.tapgemm) {
+    bool own_wgrad = false;
+    if (L.tapgemm && h->bf16 && cout1_knob() > 0 && L.nsrc == 1 && !n.t[L.src[0]].is_input && !n.t[L.src[0]].hi && n.t[L.src[0]].xa[L.in_act] &&
+        L.g.ks == 4 && L.g.stride == 1) {
+      // the one-output-channel layer's weight gradient on its own kernel (conv_cout1.hip): no tap spreading, no transposes
+      Tens& tx = n.t[L.src[0]];
+      Cout1Args c;
+      memset(&c, 0, sizeof(c));
+      c.dy = dy; c.ld_dy = L.g.CoutT;
+      c.ref = (const char*)tx.xa[L.in_act] + (size_t)sample0 * tx.H * tx.W * tx.C * es;
+      c.N = nb; c.H = tx.H; c.W = tx.W; c.C = tx.C; c.Ho = L.g.Hout; c.Wo = L.g.Wout; c.ks = L.g.ks; c.pad = L.g.pad;
+      c.slabs = (float*)scratch; c.dW = n.grads + L.w_off;
+      const long long px = (long long)nb * tx.H * tx.W;
+      const size_t cap = h->scratch_bytes / ((size_t)16 * 512 * sizeof(float));
+      c.rows = (int)(px / 96 < wgrad1_rows_knob() ? px / 96 : wgrad1_rows_knob());            // >= 24 pixels per wave
+      if ((size_t)c.rows > cap) c.rows = (int)cap;
+      if (c.rows >= 1 && L.g.Cin == 512 && conv_cout1_wgrad_eligible(c)) {
+        profile_tag((L.scope + ":wgrad").c_str());
+        VP_HIP_CHECK(launch_cout1_wgrad_prof(c, st));
+        own_wgrad = true;
+      }
+    }
+    if (L.tapgemm && !own_wgrad) {
       TapArgs ta;
       memset(&ta, 0, sizeof(ta));
       ta.dy = dy; ta.dyS = L.tap_dyS; ta.ld_dy = L.g.CoutT;
@@ -850,8 +871,10 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
     w.dW = n.grads + L.w_off;
     w.accumulate = 0;
     w.zeros = h->zeros;
-    profile_tag((L.scope + ":wgrad").c_str());
-    VP_HIP_CHECK(launch_wgrad(w, h->bf16, L.wg.cfg, st));
+    if (!own_wgrad) {
+      profile_tag((L.scope + ":wgrad").c_str());
+      VP_HIP_CHECK(launch_wgrad(w, h->bf16, L.wg.cfg, st));
+    }
     float* db = n.grads + L.b_off;
     if (L.has_bn) {
       // analytically zero: written by this layer's batch-norm backward (run_bn_bwd, dbias_zero) - no separate memset launch
