@@ -1,6 +1,6 @@
-// conv_cout1.hip - the backward-data pass of a 4x4 stride-1 convolution with ONE output channel over 512 input channels: the PatchGAN's
-// last layer (pixrefer.py:111-131, `layer_5`), in both of its passes (the discriminator-loss pass over the three applications, the
-// generator-loss pass over the fake one).
+// conv_cout1.hip - the backward passes of a 4x4 stride-1 convolution with ONE output channel over 512 input channels: the PatchGAN's
+// last layer (pixrefer.py:111-131, `layer_5`).  First the backward-data pass, in both of its uses (the discriminator-loss pass over the
+// three applications, the generator-loss pass over the fake one); the weight gradient (cout1_wgrad_kernel) is at the end of the file.
 //
 // dx[n, ih, iw, c] = act'(ref[n, ih, iw, c]) * sum over (kh, kw) of dy[n, ih - kh + pad, iw - kw + pad] * w[kh, kw, c]
 //
