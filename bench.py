@@ -534,10 +534,13 @@ def main():
   ceiling = None
   if world == 1 and not args.no_scaling_ceiling and args.scaling == "strong" and args.global_batch % 8 == 0:
     share = args.global_batch // 8
-    r = run_config(share, args.height, args.dtype, max(10, args.steps), 5, rank, world, device, group, False)
-    ceiling = {"per_gpu_batch_at_8_gpus": share, "ms_per_step_at_that_batch": r["ms_per_step"],
-               "ceiling_8_gpus": main_res["ms_per_step"] / r["ms_per_step"],
-               "note": "single-GPU step time at the 8-GPU share of the global batch, no gradient exchange: an upper bound of value(8 GPUs) / value(1 GPU)"}
+    # two engines, the faster one counts: the few-frame step is sensitive to which hardware queues the HIP runtime hands the executor's
+    # streams (about one process in fifteen gets an assignment that serialises two of them: 2.8 - 4.6 ms instead of 2.2 at 4 frames,
+    # profiles/r06_INDEX.md); the record is an upper bound by definition
+    runs = [run_config(share, args.height, args.dtype, max(10, args.steps), 5, rank, world, device, group, False)["ms_per_step"] for _ in range(2)]
+    ceiling = {"per_gpu_batch_at_8_gpus": share, "ms_per_step_at_that_batch": min(runs), "ms_per_step_of_each_engine": runs,
+               "ceiling_8_gpus": main_res["ms_per_step"] / min(runs),
+               "note": "single-GPU step time at the 8-GPU share of the global batch (the faster of two engines), no gradient exchange: an upper bound of value(8 GPUs) / value(1 GPU)"}
 
   pcie = None
   if world == 1 and not args.no_input_pipeline:
