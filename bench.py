@@ -367,7 +367,13 @@ def run_config(per_gpu, height, dtype, steps, warmup, rank, world, device, group
                        "algorithmic_flops_per_launch": top["flops"] / top["calls"]}
   if world > 1:
     dist.barrier(group=group)
-  del eng
+  # the plan and its HIP streams go NOW, not when the collector finds the engine: a later leg's engine would share the runtime's hardware
+  # queues with this one's streams (EXPERIMENTS.md 0.8: the 4-frame step then measures 2.8 - 4.6 ms instead of 2.15)
+  torch.cuda.synchronize()
+  eng.close()
+  del eng, step
+  import gc
+  gc.collect()
   torch.cuda.empty_cache()
   return res
 
@@ -404,7 +410,10 @@ def run_with_input_pipeline(per_gpu, height, dtype, steps, warmup, device):
     eng.train_step(*pf.next(), lr=3e-4)
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
-  del eng
+  eng.close()
+  del eng, pf
+  import gc
+  gc.collect()
   torch.cuda.empty_cache()
   return {"value": per_gpu * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3,
           "host_to_device_bytes_per_step": int(per_gpu * (2 * 9 * S * S + 24)),
@@ -534,9 +543,11 @@ def main():
   ceiling = None
   if world == 1 and not args.no_scaling_ceiling and args.scaling == "strong" and args.global_batch % 8 == 0:
     share = args.global_batch // 8
-    # two engines, the faster one counts: the few-frame step is sensitive to which hardware queues the HIP runtime hands the executor's
-    # streams (about one process in fifteen gets an assignment that serialises two of them: 2.8 - 4.6 ms instead of 2.2 at 4 frames,
-    # profiles/r06_INDEX.md); the record is an upper bound by definition
+    # two engines, the faster one counts (the record is an upper bound by definition).  A few-frame engine created while the streams of an
+    # earlier engine are alive - or, it seems, not yet released by the runtime - shares the HIP runtime's few hardware queues with them
+    # and measures 2.8 - 4.6 ms instead of 2.15 (scripts/exp_engine_sequence.py: reproducible by keeping the earlier engines);
+    # run_config closes its engine explicitly since the end of round 6, which made the slow case rarer (1 engine in 6 over three full
+    # runs), not impossible.  28 back-to-back fresh processes: all 2.10 - 2.15 ms (profiles/r06_few_frame_step_28_processes.txt)
     runs = [run_config(share, args.height, args.dtype, max(10, args.steps), 5, rank, world, device, group, False)["ms_per_step"] for _ in range(2)]
     ceiling = {"per_gpu_batch_at_8_gpus": share, "ms_per_step_at_that_batch": min(runs), "ms_per_step_of_each_engine": runs,
                "ceiling_8_gpus": main_res["ms_per_step"] / min(runs),
