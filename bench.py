@@ -544,8 +544,8 @@ def main():
   if world == 1 and not args.no_scaling_ceiling and args.scaling == "strong" and args.global_batch % 8 == 0:
     share = args.global_batch // 8
     # two engines, the faster one counts (the record is an upper bound by definition).  A few-frame engine created while the streams of an
-    # earlier engine are alive - or, it seems, not yet released by the runtime - shares the HIP runtime's few hardware queues with them
-    # and measures 2.8 - 4.6 ms instead of 2.15 (scripts/exp_engine_sequence.py: reproducible by keeping the earlier engines);
+    # earlier engine are alive - or, it seems, not yet released by the runtime - measures 2.8 - 4.6 ms instead of 2.15
+    # (scripts/exp_engine_sequence.py: reproducible by keeping the earlier engines; more hardware queues do not help);
     # run_config closes its engine explicitly since the end of round 6, which made the slow case rarer (1 engine in 6 over three full
     # runs), not impossible.  28 back-to-back fresh processes: all 2.10 - 2.15 ms (profiles/r06_few_frame_step_28_processes.txt)
     runs = [run_config(share, args.height, args.dtype, max(10, args.steps), 5, rank, world, device, group, False)["ms_per_step"] for _ in range(2)]

@@ -80,8 +80,8 @@ class PixReferEngine:
 
   def close(self):
     """Destroys the plan NOW (its HIP streams with it).  An engine that merely went out of scope may live until the cyclic collector runs,
-    and a second engine created meanwhile shares the runtime's few hardware queues with the first one's streams: the few-frame step then
-    takes 2.8 - 4.6 ms instead of 2.15 (scripts/exp_engine_sequence.py, profiles/r06_exp_engine_sequence.txt)."""
+    and a second engine created while the first one's streams exist runs slow: the few-frame step takes 2.8 - 4.6 ms instead of 2.15
+    (scripts/exp_engine_sequence.py, profiles/r06_exp_engine_sequence.txt)."""
     if getattr(self, "h", None):
       self.L.vp_pixrefer_destroy(self.h)
       self.h = None
