@@ -833,3 +833,26 @@ def test_one_output_channel_backward_kernel_in_situ(n):
     e = gu.rel_l2(grads[1][0][k], grads[0][0][k])
     assert e < 1e-3, (k, e)
   print("one-output-channel backward kernel, n = %d: worst gradient rel-L2 against the generic kernels %.2e" % (n, worst))
+
+
+@pytest.mark.gpu
+def test_engine_close_releases_the_plan_and_later_calls_fail_loudly():
+  """PixReferEngine.close() destroys the plan (and its HIP streams) at once - a process that builds several engines closes the ones it
+  is done with (EXPERIMENTS.md 0.8 of round 6: an engine created beside the live streams of an earlier one runs slow).  Closing twice is
+  harmless; a step on a closed engine is an error from the library, not a crash; a new engine of the same shape reproduces the first
+  one's step bit for bit."""
+  p = ref.init_params(8, 8, seed=2, dtype=np.float32)
+  rng = np.random.default_rng(4)
+  batch = [torch.tensor(rng.uniform(size=(1, 256, 256, c)).astype(np.float32), device="cuda") for c in (6, 6, 3, 3)]
+  out = []
+  for _ in range(2):
+    eng = PixReferEngine(1, 256, 8, 8, dtype="f32", training=True)
+    eng.load_params(p)
+    eng.train_step(*batch, lr=3e-4)
+    torch.cuda.synchronize()
+    out.append((eng.params_g.clone(), eng.params_d.clone(), dict(eng.losses())))
+    eng.close()
+    eng.close()
+    with pytest.raises(RuntimeError):
+      eng.train_step(*batch, lr=3e-4)
+  assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
