@@ -135,7 +135,7 @@ inline int& patch3_knob() { static int v = 1; return v; }   // 3x3 layers on the
 inline int& wgrad_big_knob() { static int v = 1; return v; }   // 256 x 256 tile of wgrad_tr.hip where the grid still fills the CUs
 inline int& patch4_knob() { static int v = 1; return v; }   // 4x4 stride-1 backward-data passes on the unrolled patch kernel (conv_patch3.hip, KW = 4)
 inline int& c64_knob() { static int v = 1; return v; }   // 64 -> 64 channel 3x3 layers on the register-resident-weights kernel (conv_c64.hip)
-inline int& cout1_knob() { static int v = 256; return v; }  // most blocks (= partial rows) per batch-norm group of the one-output-channel backward-data kernel (conv_cout1.hip); 0: the generic kernels
+inline int& cout1_knob() { static int v = 256; return v; }  // most blocks (= partial rows, <= 256: the tables plan_net carves) per batch-norm group of the one-output-channel backward-data kernel (conv_cout1.hip); 0: the generic kernels
 inline int& wgrad1_rows_knob() { static int v = 512; return v; }  // most blocks (= slabs) of cout1_wgrad_kernel: vp_tune("cout1_wgrad_rows")
 inline int& dc64_knob() { static int v = 1; return v; }  // 128 -> 64 channel transposed-conv classes on conv_dc64.hip
 inline int& s2c64_knob() { static int v = 512; return v; }   // 64 -> 128 channel 4x4 / stride-2 convolutions on conv_s2c64.hip from this many 4 x 16-pixel tiles (0: off)

@@ -460,6 +460,12 @@ static void plan_net(Net& n, int bf16, bool training, bool want_wgrad, int alt_b
         cap(ts, L.bwd[s], n.batch, n.groups, ts.pb_cap);
         if (alt_batch > 0) cap(ts, L.bwd_alt[s], alt_batch, 1, ts.pbg_cap);
         if (L.has_pair) cap(ts, L.bwd_pair, n.batch, n.groups, ts.pb_cap);
+        // the one-output-channel layer's own backward-data kernel (conv_cout1.hip) leaves one row per block, whatever the generic plan
+        // could do (its 128-pixel tiles straddle the three groups of the discriminator-loss pass: 961 pixels per image)
+        if (L.tapgemm && bf16 && ts.has_bn && !ts.hi && L.g.ks == 4 && L.g.stride == 1 && L.g.Cin == 512) {
+          if (ts.pb_cap < 256) ts.pb_cap = 256;
+          if (alt_batch > 0 && ts.pbg_cap < 256) ts.pbg_cap = 256;
+        }
       }
     }
   for (size_t i = 0; i < n.l.size(); ++i) n.l[i].desc1 = i + 1 < n.l.size() ? n.l[i + 1].desc0 : n.descs.size();
