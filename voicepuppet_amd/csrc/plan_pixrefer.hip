@@ -1057,6 +1057,7 @@ static int run_layer_bwd(vp_pixrefer* h, Net& n, Layer& L, const void* dy, bool 
       // at least eight tiles per (persistent) block - its prologue loads the block's 32 KB of weights -, and not for launches below 16384
       // pixels (8 frames, generator-loss pass: 0.025 ms against 0.020 on the generic kernel)
       c.rows = tiles / 8 < cout1_knob() ? tiles / 8 : cout1_knob();
+      if (c.rows > 512 / groups) c.rows = 512 / groups;          // 512 resident blocks in all (two per compute unit): three groups x 170 rows 0.059 ms, x 256 0.065
       if (sums && c.rows > cap) c.rows = cap;
       if ((long long)nb * ts.H * ts.W < 16384 || c.rows < 1) c.rows = 0;
       if (sums) { c.part = gpass ? ts.bn.pbg : ts.bn.pb; c.y = (const char*)ts.y + (size_t)sample0 * ts.H * ts.W * ts.C * es; }
