@@ -634,8 +634,8 @@ def test_bucketed_train_step_through_rccl_single_rank():
       torch.cuda.synchronize()
       if mode != "plain":
         bk = eng._exchange.bucket_ms()
-        assert [b["name"] for b in bk] == ["generator stage 0", "generator stage 1", "generator stage 2", "discriminator"]
-        nel = [hi - lo for lo, hi in eng.grad_buckets_g()] + [eng.grads_d.numel()]
+        assert [b["name"] for b in bk] == ["discriminator", "generator stage 0", "generator stage 1", "generator stage 2"]      # (round 6: the discriminator's bucket right behind its loss pass)
+        nel = [eng.grads_d.numel()] + [hi - lo for lo, hi in eng.grad_buckets_g()]
         assert [b["bytes"] for b in bk] == [n * (2 if mode == "bf16" else 4) for n in nel]
         assert all(b["allreduce_ms"] > 0 and b["update_ms"] > 0 for b in bk) and bk[0]["wait_ms"] is None and all(b["wait_ms"] >= 0 for b in bk[1:])
       outs[mode] = (eng.params_g.clone(), eng.params_d.clone(), eng.grads_g.clone(), eng.grads_d.clone())

@@ -240,12 +240,20 @@ class PixReferEngine:
                                      "vp_pixrefer_update_bucket")
       ex.begin_step()
       _lib.check(self.L.vp_pixrefer_backward_d_fork(self.h, _stream()), "vp_pixrefer_backward_d_fork")
+      d_early = not self.dp_own_stream
       for stage, (lo, hi) in enumerate(self.grad_buckets_g()):
         self.backward_g_stage(stage)
+        if stage == 0 and d_early:
+          # the discriminator's (small) bucket right behind its loss pass: stage 0 has started that pass on the side stream - where the
+          # collectives are issued too, so stream order covers it - and holds the last read of the discriminator's weights (the
+          # generator-loss pass through D), so the bucket's Adam update + re-pack may follow at once.  As the LAST bucket (rounds 3-5) its
+          # all-reduce -> Adam -> re-pack chain was the tail of every data-parallel step
+          ex.start(self.grads_d, then=update(1, 0), name="discriminator")
         ex.start(self.grads_g[lo:hi], then=update(0, stage), name="generator stage %d" % stage)
-      # the discriminator-loss pass ran on the side stream under the generator's stages; its (small) bucket goes last
       _lib.check(self.L.vp_pixrefer_backward_d_join(self.h, _stream()), "vp_pixrefer_backward_d_join")
-      ex.start(self.grads_d, then=update(1, 0), name="discriminator")       # (an event on this stream covers the joined pass: include/vp_hip.h)
+      if not d_early:
+        # a communication stream of the exchange's own: the discriminator-loss pass has to be joined first; its bucket goes last
+        ex.start(self.grads_d, then=update(1, 0), name="discriminator")       # (an event on this stream covers the joined pass: include/vp_hip.h)
       ex.finish()
       return
     self.adam_step(lr, beta1)
