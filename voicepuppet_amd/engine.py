@@ -222,7 +222,12 @@ class PixReferEngine:
       # weight re-pack follow right behind the collective on that stream - under the stages that still compute
       from .parallel import GradExchange
       if not self._dp_streams_set:
-        self.use_streams(3)        # RCCL brings streams of its own: the executor keeps to three (include/vp_hip.h vp_pixrefer_use_streams)
+        # a communication stream of the exchange's own is a fifth busy stream: the executor then keeps to three (include/vp_hip.h
+        # vp_pixrefer_use_streams).  With the collectives on the executor's side stream (the default) it keeps its fourth: one-rank RCCL,
+        # bf16 transport, 16 / 8 / 4 frames: 4.54 / 3.08 / 2.35 ms with three executor streams, 4.45 / 3.00 / 2.29 with four
+        # (profiles/r06_exp_dp1_one_rank_rccl.txt)
+        if self.dp_own_stream:
+          self.use_streams(3)
         self._dp_streams_set = True
       ex = self._exchange
       if ex is None or ex.group is not group or ex.transport != self.grad_transport:
