@@ -137,6 +137,12 @@ int vp_pixrefer_backward_d_join(vp_pixrefer_t* h, void* stream);
  * stream of its own (the device has few hardware queues; streams beyond them share one).  Work the host enqueues on it runs behind the
  * discriminator-loss pass of the step.  NULL if the plan runs on a single stream (vp_pixrefer_desc::streams = 1). */
 void* vp_pixrefer_side_stream(vp_pixrefer_t* h);
+/* The executor's three extra HIP streams are process-wide (one device per process), created once - by this call, or by the first
+ * training plan - and shared by every plan of the process; they are never destroyed.  A host that also creates an RCCL communicator (or
+ * any other busy stream) calls this FIRST: streams created behind other streams get the HIP runtime's leftover hardware queues and the
+ * step runs 8 % (32 frames) to 30 % (4 frames) slow (scripts/exp_dp_order.py).  No counterpart in the reference (tf.Session owns its
+ * executor, train_pixrefer.py:34). */
+int vp_reserve_streams(void);
 /* Streams a training step is spread over: 4 (default) or 3.  A host that runs a busy stream of its own beside the step (an input
  * prefetcher) asks for 3: the device has few hardware queues, a fifth busy stream shares one with an executor stream. */
 int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n);

@@ -856,3 +856,39 @@ def test_engine_close_releases_the_plan_and_later_calls_fail_loudly():
     with pytest.raises(RuntimeError):
       eng.train_step(*batch, lr=3e-4)
   assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
+@pytest.mark.gpu
+def test_executor_streams_are_process_wide_and_shared_by_every_plan():
+  """Round 6: the executor's three extra HIP streams are created once per process (vp_reserve_streams, or the first training plan) and
+  shared by every plan - streams created behind an RCCL communicator's or an earlier plan's got the runtime's leftover hardware queues
+  and ran the step 8 - 30 % slow (scripts/exp_dp_order.py, scripts/exp_engine_sequence.py).  Two engines of one process report the same
+  side stream, before and after one of them is closed; reserving again changes nothing; two engines stepping alternately on the shared
+  streams stay bit-identical to an engine stepping alone."""
+  L = _lib.lib()
+  _lib.check(L.vp_reserve_streams())
+  p = ref.init_params(8, 8, seed=3, dtype=np.float32)
+  rng = np.random.default_rng(5)
+  batch = [torch.tensor(rng.uniform(size=(1, 256, 256, c)).astype(np.float32), device="cuda") for c in (6, 6, 3, 3)]
+
+  def make():
+    e = PixReferEngine(1, 256, 8, 8, dtype="bf16", training=True)
+    e.load_params(p)
+    return e
+  a, b = make(), make()
+  sa, sb = int(L.vp_pixrefer_side_stream(a.h)), int(L.vp_pixrefer_side_stream(b.h))
+  assert sa == sb and sa != 0
+  for _ in range(3):
+    a.train_step(*batch, lr=3e-4); b.train_step(*batch, lr=3e-4)
+  torch.cuda.synchronize()
+  assert torch.equal(a.params_g, b.params_g) and torch.equal(a.params_d, b.params_d)
+  got = (a.params_g.clone(), a.params_d.clone())
+  a.close()
+  _lib.check(L.vp_reserve_streams())
+  c = make()
+  assert int(L.vp_pixrefer_side_stream(c.h)) == sb
+  for _ in range(3):
+    c.train_step(*batch, lr=3e-4)
+  torch.cuda.synchronize()
+  assert torch.equal(c.params_g, got[0]) and torch.equal(c.params_d, got[1])
+  b.close(); c.close()

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -1289,6 +1290,44 @@ int vp_pixrefer_validate_plan(const vp_pixrefer_desc* d) {
   return rc;
 }
 
+// The executor's three extra streams are PROCESS-WIDE (per device), created once and never destroyed: every plan of the process uses the
+// same ones.  Which hardware queues the HIP runtime gives a stream depends on what exists when it is created, and streams created behind
+// other busy ones (an RCCL communicator's, an earlier plan's) run the step slow - a plan created after dist.init_process_group(device_id)
+// measured 7.8 ms instead of 7.2 at 32 frames and 2.85 instead of 2.19 at 4 (scripts/exp_dp_order.py), a second engine beside a live
+// first one 3.4 - 4.6 ms instead of 2.15 (scripts/exp_engine_sequence.py).  vp_reserve_streams() creates them NOW: a host calls it first
+// thing (before it creates a communicator); otherwise the first training plan does.  Plans that share the streams serialise on them,
+// which is what two plans stepping in one process do on the device anyway; fork / join events stay per plan.
+struct StreamPool {
+  int dev = -1;
+  hipStream_t side = nullptr, branch = nullptr, branch2 = nullptr;
+};
+static StreamPool g_pool;
+static std::mutex g_pool_mu;
+
+static int pool_streams(bool want_b2, hipStream_t* side, hipStream_t* branch, hipStream_t* branch2) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int dev = 0;
+  VP_HIP_CHECK(hipGetDevice(&dev));
+  if (g_pool.dev >= 0 && g_pool.dev != dev) { set_err("the step executor's streams were created on device %d, this plan is on device %d (one device per process)", g_pool.dev, dev); return VP_ERR_STATE; }
+  if (!g_pool.side) {
+    // lowest priority: the side stream only fills the CUs the main stream's (longer, critical-path) passes leave idle
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    VP_HIP_CHECK(hipStreamCreateWithPriority(&g_pool.side, hipStreamNonBlocking, prio_lo));
+    VP_HIP_CHECK(hipStreamCreateWithFlags(&g_pool.branch, hipStreamNonBlocking));
+    g_pool.dev = dev;
+  }
+  // the fourth stream on first use (the backward pass of a plan that still wants four streams, or vp_reserve_streams): hardware queues
+  // are handed out as streams are created, and a host stream created later (an input prefetcher's) must not be pushed onto a shared one
+  if (want_b2 && !g_pool.branch2) VP_HIP_CHECK(hipStreamCreateWithFlags(&g_pool.branch2, hipStreamNonBlocking));
+  if (side) *side = g_pool.side;
+  if (branch) *branch = g_pool.branch;
+  if (branch2) *branch2 = g_pool.branch2;
+  return VP_OK;
+}
+
+int vp_reserve_streams(void) { return pool_streams(true, nullptr, nullptr, nullptr); }
+
 int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t workspace_bytes,
                        float* params_g, float* params_d, const float* params_vgg,
                        float* grads_g, float* grads_d, void* stream, vp_pixrefer_t** out) {
@@ -1318,16 +1357,10 @@ int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t worksp
   h->bst_on = 1; h->vgg_fork_layer = 3;
   h->ov_on = true; h->store_first_raw = false; h->dfork_point = d->d_backward_fork ? d->d_backward_fork - 1 : 2; h->dsplit_on = d->d_beside_vgg != 1;
   if (d->training && d->streams != 1) {
-    // lowest priority: the side stream only fills the CUs the main stream's (longer, critical-path) passes leave idle
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    VP_HIP_CHECK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
+    // the process-wide executor streams (StreamPool above); the fourth one on first use unless vp_reserve_streams() made it already
+    { const int rc = pool_streams(false, &h->side, &h->branch, &h->branch2); if (rc) { delete h; return rc; } }
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch, hipStreamNonBlocking));
-    // the fourth stream is created on first use (the backward pass of a handle that still wants four streams): hardware queues are
-    // handed out as streams are created, and a host stream created later (an input prefetcher's) must not be pushed onto a shared one
-    h->branch2 = nullptr;
     h->use_b2 = d->streams != 3;
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_b2join, hipEventDisableTiming));
     VP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_bfork, hipEventDisableTiming));
@@ -1344,18 +1377,17 @@ void vp_pixrefer_destroy(vp_pixrefer_t* h) {
   if (!h) return;
   if (h->marks_made) for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->mark[i]);
   if (h->overlap) {
+    // the streams belong to the process (StreamPool): this plan's work on them is waited for, they live on
     (void)hipStreamSynchronize(h->side);
     (void)hipEventDestroy(h->ev_fork);
     (void)hipEventDestroy(h->ev_join);
-    (void)hipStreamDestroy(h->side);
     (void)hipStreamSynchronize(h->branch);
     (void)hipEventDestroy(h->ev_bfork);
     (void)hipEventDestroy(h->ev_bjoin);
     (void)hipEventDestroy(h->ev_b2join);
-    if (h->branch2) { (void)hipStreamSynchronize(h->branch2); (void)hipStreamDestroy(h->branch2); }
+    if (h->branch2) (void)hipStreamSynchronize(h->branch2);
     (void)hipEventDestroy(h->ev_upd_b);
     (void)hipEventDestroy(h->ev_upd_m);
-    (void)hipStreamDestroy(h->branch);
   }
   delete h;
 }
@@ -1844,7 +1876,7 @@ int vp_pixrefer_backward_g_stage(vp_pixrefer_t* h, int stage, void* stream) {
     const bool fg = split_enc && L.scope.rfind("encoder_fg_", 0) == 0;
     if (fg && !fg_forked) {      // the branch's first layer needs merged_encoder_2's data gradient, enqueued on `st` just before
       VP_HIP_CHECK(hipEventRecord(h->ev_bfork, st));
-      if (h->use_b2 && !h->branch2) VP_HIP_CHECK(hipStreamCreateWithFlags(&h->branch2, hipStreamNonBlocking));
+      if (h->use_b2 && !h->branch2) { const int rc2 = pool_streams(true, nullptr, nullptr, &h->branch2); if (rc2) return rc2; }
       VP_HIP_CHECK(hipStreamWaitEvent(h->use_b2 ? h->branch2 : h->branch, h->ev_bfork, 0));
       forked = fg_forked = true;
       b2_used = h->use_b2;

@@ -31,6 +31,12 @@ def init_distributed(backend="nccl", timeout_s=None, **kw):
     timeout_s = float(os.environ.get("VP_COLLECTIVE_TIMEOUT_S", "600"))
   os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
   os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  if backend == "nccl":
+    # the step executor's streams FIRST (the caller has selected its device): streams created behind the communicator's get the HIP
+    # runtime's leftover hardware queues and every step of the job runs 8 % (32 frames per GPU) to 30 % (4 frames) slow
+    # (include/vp_hip.h vp_reserve_streams, scripts/exp_dp_order.py)
+    from . import _lib
+    _lib.check(_lib.lib().vp_reserve_streams(), "vp_reserve_streams")
   dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
   return dist.group.WORLD
 
