@@ -543,11 +543,10 @@ def main():
   ceiling = None
   if world == 1 and not args.no_scaling_ceiling and args.scaling == "strong" and args.global_batch % 8 == 0:
     share = args.global_batch // 8
-    # two engines, the faster one counts (the record is an upper bound by definition).  A few-frame engine created while the streams of an
-    # earlier engine are alive - or, it seems, not yet released by the runtime - measures 2.8 - 4.6 ms instead of 2.15
-    # (scripts/exp_engine_sequence.py: reproducible by keeping the earlier engines; more hardware queues do not help);
-    # run_config closes its engine explicitly since the end of round 6, which made the slow case rarer (1 engine in 6 over three full
-    # runs), not impossible.  28 back-to-back fresh processes: all 2.10 - 2.15 ms (profiles/r06_few_frame_step_28_processes.txt)
+    # two engines, the faster one counts (the record is an upper bound by definition).  Until the end of round 6 this leg now and then
+    # measured 2.8 - 4.6 ms instead of 2.15: its engine's HIP streams were created while streams of earlier legs' engines existed and got
+    # the runtime's leftover hardware queues; the executor's streams are process-wide now (include/vp_hip.h vp_reserve_streams,
+    # EXPERIMENTS.md 0.8 of round 6) and every engine of a process measures alike
     runs = [run_config(share, args.height, args.dtype, max(10, args.steps), 5, rank, world, device, group, False)["ms_per_step"] for _ in range(2)]
     ceiling = {"per_gpu_batch_at_8_gpus": share, "ms_per_step_at_that_batch": min(runs), "ms_per_step_of_each_engine": runs,
                "ceiling_8_gpus": main_res["ms_per_step"] / min(runs),

@@ -79,9 +79,9 @@ class PixReferEngine:
     self._keep = None
 
   def close(self):
-    """Destroys the plan NOW (its HIP streams with it).  An engine that merely went out of scope may live until the cyclic collector runs,
-    and a second engine created while the first one's streams exist runs slow: the few-frame step takes 2.8 - 4.6 ms instead of 2.15
-    (scripts/exp_engine_sequence.py, profiles/r06_exp_engine_sequence.txt)."""
+    """Destroys the plan NOW and returns its 7 GB workspace's owner to the collector.  (The executor's HIP streams are process-wide and
+    stay: until they were, an engine created while an earlier one's streams existed ran slow - scripts/exp_engine_sequence.py,
+    profiles/r06_exp_engine_sequence.txt.)"""
     if getattr(self, "h", None):
       self.L.vp_pixrefer_destroy(self.h)
       self.h = None
