@@ -143,6 +143,10 @@ void* vp_pixrefer_side_stream(vp_pixrefer_t* h);
  * step runs 8 % (32 frames) to 30 % (4 frames) slow (scripts/exp_dp_order.py).  No counterpart in the reference (tf.Session owns its
  * executor, train_pixrefer.py:34). */
 int vp_reserve_streams(void);
+/* The fourth of those streams, for a host with ONE busy stream of its own (an input prefetcher: generator/device_pipeline.py
+ * FramePrefetcher) whose plans keep to three (vp_pixrefer_use_streams(h, 3)): a stream the host created itself would be the process's
+ * fifth and share a hardware queue (the PCIe-inclusive step: 9.2 ms instead of 7.4).  NULL on error (vp_last_error). */
+void* vp_host_stream(void);
 /* Streams a training step is spread over: 4 (default) or 3.  A host that runs a busy stream of its own beside the step (an input
  * prefetcher) asks for 3: the device has few hardware queues, a fifth busy stream shares one with an executor stream. */
 int vp_pixrefer_use_streams(vp_pixrefer_t* h, int n);

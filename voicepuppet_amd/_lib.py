@@ -97,6 +97,7 @@ _SIGNATURES = {
     "vp_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "vp_tune": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "vp_reserve_streams": (ctypes.c_int, []),
+    "vp_host_stream": (ctypes.c_void_p, []),
     "vp_pixrefer_pack_frames": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, _P]),
     "vp_profile_collect": (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
     "vp_pixrefer_tensor": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64),

@@ -1328,6 +1328,14 @@ static int pool_streams(bool want_b2, hipStream_t* side, hipStream_t* branch, hi
 
 int vp_reserve_streams(void) { return pool_streams(true, nullptr, nullptr, nullptr); }
 
+// The process's fourth executor stream for a host with ONE busy stream of its own (an input prefetcher) whose plans keep to three
+// (vp_pixrefer_use_streams(h, 3)): a fifth stream, created behind the four, would get a shared hardware queue.
+void* vp_host_stream(void) {
+  hipStream_t b2 = nullptr;
+  if (pool_streams(true, nullptr, nullptr, &b2)) return nullptr;
+  return (void*)b2;
+}
+
 int vp_pixrefer_create(const vp_pixrefer_desc* d, void* workspace, size_t workspace_bytes,
                        float* params_g, float* params_d, const float* params_vgg,
                        float* grads_g, float* grads_d, void* stream, vp_pixrefer_t** out) {

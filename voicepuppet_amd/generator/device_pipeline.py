@@ -61,7 +61,12 @@ class FramePrefetcher:
   def __init__(self, source, batch, img_size, depth=2, device=None):
     self.source = iter(source)
     self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-    self.stream = torch.cuda.Stream(device=self.device)
+    # the process's fourth executor stream (include/vp_hip.h vp_host_stream): the training engine beside this prefetcher keeps to three
+    # (vp_pixrefer_use_streams), a stream created here would be a fifth one on a shared hardware queue
+    sp = _lib.lib().vp_host_stream()
+    if not sp:
+      _lib.check(-1, "vp_host_stream")
+    self.stream = torch.cuda.ExternalStream(sp, device=self.device)
     S = img_size
     self.slots = []
     for _ in range(depth):
